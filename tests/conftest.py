@@ -1,0 +1,56 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+  config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_golden(name):
+  """Return (arrays, cfg): cfg_* scalars become a dict, NaN -> None."""
+  z = np.load(os.path.join(GOLDEN, name + ".npz"))
+  arrays, cfg = {}, {}
+  for k in z.files:
+    if k.startswith("cfg_"):
+      v = z[k]
+      if v.ndim == 0:
+        v = v.item()
+        if isinstance(v, float) and np.isnan(v):
+          v = None
+      else:
+        v = v.tolist()
+      cfg[k[4:]] = v
+    else:
+      arrays[k] = z[k]
+  return arrays, cfg
+
+
+def project_kwargs(cfg, intrinsics_fn):
+  """Split a MapProjector config into orth_project keyword arguments the way
+  MapProjector.orth_project forwards them (reference maps.py:1438-1465)."""
+  cx, cy, fx, fy = intrinsics_fn(cfg["width"], cfg["height"], cfg["hfov"], cfg.get("vfov"))
+  kw = dict(center_x=cx, center_y=cy, focal_x=fx, focal_y=fy)
+  for k in ("cam_pose", "width_offset", "height_offset", "cam_pitch", "cam_height",
+            "map_res", "map_width", "map_height", "trunc_depth_min", "trunc_depth_max",
+            "trunc_height_max", "clip_border", "reduction"):
+    kw[k] = cfg.get(k)
+  kw["to_global"] = bool(cfg.get("to_global", False))
+  kw["flip_h"] = bool(cfg.get("flip_h", True))
+  kw["fill_value"] = cfg.get("fill_value", -np.inf) if "fill_value" in cfg else -np.inf
+  return kw
+
+
+@pytest.fixture(scope="session")
+def oracle():
+  from oracle import oracle as orc
+  orc.build()
+  return orc

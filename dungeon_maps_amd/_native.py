@@ -1,0 +1,91 @@
+"""ctypes binding of libdungeon_maps_amd.so (include/dungeon_maps_amd.h).
+
+The HIP library IS the product: there is no eager/PyTorch or CPU fallback.  If
+the shared object is missing or a symbol is absent this module raises at
+import-of-use time with the build command.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libdungeon_maps_amd.so")
+
+ABI_VERSION = 1
+
+# dm_reduction
+REDUCE_MAX, REDUCE_MIN, REDUCE_SUM, REDUCE_MEAN, REDUCE_PROD = range(5)
+
+FRAME_FLOATS = 32  # sizeof(dm_frame) / 4
+
+
+class Params(ctypes.Structure):
+  """dm_params"""
+  _fields_ = [(n, ctypes.c_int32) for n in (
+      "B", "dc", "vc", "H", "W", "mh", "mw", "clip_border", "flip_h", "to_global",
+      "reduction", "has_dmin", "has_dmax", "has_hmax", "valid_c")] + [
+      (n, ctypes.c_float) for n in (
+          "cx", "cy", "fx", "fy", "res", "fill", "dmin", "dmax", "hmax")]
+
+
+class NativeError(RuntimeError):
+  pass
+
+
+_SIGNATURES = {
+    "dm_version": (ctypes.c_int, []),
+    "dm_last_error": (ctypes.c_char_p, []),
+    "dm_orth_project_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Params)]),
+    "dm_orth_project_f32": (ctypes.c_int, [
+        ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "dm_orth_project_fused_f32": (ctypes.c_int, [
+        ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "dm_mask_from_map_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
+        ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+  """Names include/dungeon_maps_amd.h declares (checked by the CPU tests)."""
+  return sorted(_SIGNATURES)
+
+
+def lib():
+  """Load the shared library once; fail loudly when it is not there."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise NativeError(
+        f"{LIB_PATH} is missing: the HIP extension is the only compute path of "
+        "dungeon_maps_amd (no CPU/eager fallback).  Build it with "
+        "`make -C dungeon_maps_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+  try:
+    handle = ctypes.CDLL(LIB_PATH)
+  except OSError as e:
+    raise NativeError(f"cannot load {LIB_PATH}: {e}") from e
+  for name, (restype, argtypes) in _SIGNATURES.items():
+    try:
+      fn = getattr(handle, name)
+    except AttributeError as e:
+      raise NativeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+    fn.restype = restype
+    fn.argtypes = argtypes
+  if handle.dm_version() != ABI_VERSION:
+    raise NativeError(
+        f"ABI mismatch: library {handle.dm_version()} vs binding {ABI_VERSION}; rebuild")
+  _lib = handle
+  return _lib
+
+
+def check(rc):
+  if rc != 0:
+    msg = lib().dm_last_error()
+    raise NativeError(f"dungeon_maps_amd native call failed ({rc}): "
+                      f"{msg.decode() if msg else 'unknown error'}")

@@ -1,0 +1,109 @@
+// C ABI of libdungeon_maps_amd.so (include/dungeon_maps_amd.h): argument
+// validation, path selection, error reporting.  No torch types, no allocation.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "dm_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_params(const dm_params* p) {
+  if (!p) return fail(DM_ERR_INVALID_ARGUMENT, "params is NULL");
+  if (p->B < 0 || p->dc < 1 || p->vc < 0 || p->H < 1 || p->W < 1 || p->mh < 1 || p->mw < 1)
+    return fail(DM_ERR_INVALID_ARGUMENT, "bad shape B=%d dc=%d vc=%d H=%d W=%d mh=%d mw=%d",
+                p->B, p->dc, p->vc, p->H, p->W, p->mh, p->mw);
+  if (p->vc && !(p->dc == 1 || p->dc == p->vc))
+    return fail(DM_ERR_INVALID_ARGUMENT,
+                "depth channels (%d) must be 1 or equal to value channels (%d)", p->dc, p->vc);
+  if (!(p->valid_c == 0 || p->valid_c == 1 || p->valid_c == p->dc))
+    return fail(DM_ERR_INVALID_ARGUMENT, "valid_c=%d must be 0, 1 or dc=%d", p->valid_c, p->dc);
+  if (p->reduction < DM_REDUCE_MAX || p->reduction > DM_REDUCE_PROD)
+    return fail(DM_ERR_INVALID_ARGUMENT, "unknown reduction %d", p->reduction);
+  if ((int64_t)p->H * p->W >= (1ll << 31) || (int64_t)p->mh * p->mw >= (1ll << 31))
+    return fail(DM_ERR_UNSUPPORTED, "image or map has more than 2^31 elements");
+  if (p->B > 65535 || p->dc > 65535)
+    return fail(DM_ERR_UNSUPPORTED, "B and dc are limited to 65535 per call");
+  return DM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dm_version(void) { return DM_ABI_VERSION; }
+
+const char* dm_last_error(void) { return g_err; }
+
+size_t dm_orth_project_workspace_bytes(const dm_params* p) {
+  if (check_params(p) != DM_OK) return 0;
+  return dm::generic_workspace_bytes(*p);
+}
+
+int dm_orth_project_f32(const dm_params* p, const dm_frame* frames_dev, const float* depth_dev,
+                        const float* value_dev, const uint8_t* valid_dev, float* out_dev,
+                        uint8_t* mask_dev, float* height_dev, void* workspace_dev,
+                        size_t workspace_bytes, void* stream) {
+  int rc = check_params(p);
+  if (rc != DM_OK) return rc;
+  if (p->B == 0) return DM_OK;
+  if (!frames_dev || !depth_dev || !out_dev || !mask_dev)
+    return fail(DM_ERR_INVALID_ARGUMENT, "frames/depth/out/mask must not be NULL");
+  if ((p->vc > 0) != (value_dev != nullptr))
+    return fail(DM_ERR_INVALID_ARGUMENT, "value pointer and vc=%d disagree", p->vc);
+  if ((p->valid_c > 0) != (valid_dev != nullptr))
+    return fail(DM_ERR_INVALID_ARGUMENT, "valid pointer and valid_c=%d disagree", p->valid_c);
+  const size_t need = dm_orth_project_workspace_bytes(p);
+  if (need > workspace_bytes || (need && !workspace_dev))
+    return fail(DM_ERR_WORKSPACE_TOO_SMALL, "workspace %zu B < required %zu B", workspace_bytes,
+                need);
+  hipError_t e = dm::run_generic(*p, frames_dev, depth_dev, value_dev, valid_dev, out_dev,
+                                 mask_dev, p->vc ? height_dev : nullptr, workspace_dev,
+                                 static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
+int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames_dev,
+                              const float* depth_dev, const float* value_dev,
+                              const uint8_t* valid_dev, float* out_dev, uint8_t* mask_dev,
+                              int accumulate, void* workspace_dev, size_t workspace_bytes,
+                              void* stream) {
+  (void)workspace_dev; (void)workspace_bytes;
+  int rc = check_params(p);
+  if (rc != DM_OK) return rc;
+  if (p->reduction != DM_REDUCE_MAX && p->reduction != DM_REDUCE_MIN)
+    return fail(DM_ERR_UNSUPPORTED, "fused projection supports max/min only (got %d)",
+                p->reduction);
+  if (!out_dev || !mask_dev || (p->B > 0 && (!frames_dev || !depth_dev)))
+    return fail(DM_ERR_INVALID_ARGUMENT, "frames/depth/out/mask must not be NULL");
+  if ((p->vc > 0) != (value_dev != nullptr) && p->B > 0)
+    return fail(DM_ERR_INVALID_ARGUMENT, "value pointer and vc=%d disagree", p->vc);
+  if ((p->valid_c > 0) != (valid_dev != nullptr) && p->B > 0)
+    return fail(DM_ERR_INVALID_ARGUMENT, "valid pointer and valid_c=%d disagree", p->valid_c);
+  hipError_t e = dm::run_generic_fused(*p, frames_dev, depth_dev, value_dev, valid_dev, out_dev,
+                                       mask_dev, accumulate, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
+int dm_mask_from_map_f32(const float* map_dev, float fill, uint8_t* mask_dev, size_t n,
+                         void* stream) {
+  if (n == 0) return DM_OK;
+  if (!map_dev || !mask_dev) return fail(DM_ERR_INVALID_ARGUMENT, "map/mask must not be NULL");
+  hipError_t e = dm::run_mask_from_map(map_dev, fill, mask_dev, n,
+                                       static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
+}  // extern "C"

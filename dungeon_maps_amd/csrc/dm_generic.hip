@@ -1,0 +1,187 @@
+// Generic (always-correct) path: fill -> per-pixel global atomics -> finalize.
+//
+// Handles every reduction, every map size and every channel layout.  It is the
+// fallback behind the LDS-windowed fast path (dm_window.hip) and the reference
+// implementation the fast path is tested against on the device.  Memory-side
+// atomics make it ~10-50x slower than the roofline, see DESIGN.md.
+#include "dm_kernels.hpp"
+
+namespace dm {
+
+// ---- float atomics on global memory, native integer/float instructions -----
+__device__ inline void atomic_max_f32(float* addr, float v) {
+  if (!(v == v)) return;                 // torch_scatter stores only if new > old
+  v += 0.0f;                             // -0 -> +0 so the sign test is an order test
+  if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ inline void atomic_min_f32(float* addr, float v) {
+  if (!(v == v)) return;
+  v += 0.0f;
+  if (v >= 0.0f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ inline void atomic_mul_f32(float* addr, float v) {
+  unsigned int* a = reinterpret_cast<unsigned int*>(addr);
+  unsigned int old = *a, assumed;
+  do {
+    assumed = old;
+    old = atomicCAS(a, assumed, __float_as_uint(__uint_as_float(assumed) * v));
+  } while (old != assumed);
+}
+
+template <int RED>
+__device__ inline void reduce_into(float* addr, float v) {
+  if (RED == DM_REDUCE_MAX) atomic_max_f32(addr, v);
+  else if (RED == DM_REDUCE_MIN) atomic_min_f32(addr, v);
+  else if (RED == DM_REDUCE_PROD) atomic_mul_f32(addr, v);
+  else atomicAdd(addr, v);               // sum, mean
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_fill(float* __restrict__ a, float va, size_t na, float* __restrict__ b, float vb,
+       size_t nb) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) a[i] = va;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) b[i] = vb;
+}
+
+// One thread per pixel; grid = (ceil(N/256), dc, B).  FUSED: all frames write
+// the same (oc, mh, mw) map.
+template <int RED, bool FUSED>
+__global__ void __launch_bounds__(256)
+k_scatter_generic(View v, int dc, int vc, int valid_c, const dm_frame* __restrict__ frames,
+                  const float* __restrict__ depth, const float* __restrict__ value,
+                  const uint8_t* __restrict__ valid, float* __restrict__ out,
+                  float* __restrict__ height, float* __restrict__ count) {
+  const int b = blockIdx.z, ch = blockIdx.y;
+  const int N = v.H * v.W;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const Cam cam = load_cam(frames + b);
+  const int r = i / v.W, q = i - r * v.W;
+  bool ok = border_ok(v, r, q);
+  if (valid) ok = ok && valid[((size_t)b * valid_c + (valid_c == 1 ? 0 : ch)) * N + i] != 0;
+  const float z = depth[((size_t)b * dc + ch) * N + i];
+  const Hit h = project_pixel(v, cam, z, ray_x(v, q), ray_y(v, r), ok);
+  if (h.cell < 0) return;
+  const size_t M = (size_t)v.mh * v.mw;
+  const int oc = vc ? vc : dc;
+  float* ob = out + (FUSED ? 0 : (size_t)b * oc * M);
+  if (!vc) {
+    reduce_into<RED>(ob + (size_t)ch * M + h.cell, h.y);
+    if (RED == DM_REDUCE_MEAN) atomicAdd(count + ((size_t)b * oc + ch) * M + h.cell, 1.0f);
+  } else if (dc == 1) {
+    for (int k = 0; k < vc; ++k) {
+      reduce_into<RED>(ob + (size_t)k * M + h.cell, value[((size_t)b * vc + k) * N + i]);
+      if (RED == DM_REDUCE_MEAN) atomicAdd(count + ((size_t)b * oc + k) * M + h.cell, 1.0f);
+    }
+  } else {
+    reduce_into<RED>(ob + (size_t)ch * M + h.cell, value[((size_t)b * vc + ch) * N + i]);
+    if (RED == DM_REDUCE_MEAN) atomicAdd(count + ((size_t)b * oc + ch) * M + h.cell, 1.0f);
+  }
+  if (height) atomic_max_f32(height + ((size_t)b * dc + ch) * M + h.cell, h.y);
+}
+
+// mask (+ mean division).  n = elements of out.
+__global__ void __launch_bounds__(256)
+k_finalize(float* __restrict__ out, const float* __restrict__ count, float fill,
+           uint8_t* __restrict__ mask, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float o = out[i];
+    if (count) {
+      const float c = count[i];
+      o = o / (c < 1.0f ? 1.0f : c);
+      out[i] = o;
+    }
+    mask[i] = mask_of(o, fill);
+  }
+}
+
+static inline int blocks_for(size_t n, int per_block, int cap) {
+  size_t b = (n + per_block - 1) / per_block;
+  if (b > (size_t)cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <bool FUSED>
+static hipError_t launch_scatter(const dm_params& p, const View& v, dim3 grid,
+                                 const dm_frame* frames, const float* depth,
+                                 const float* value, const uint8_t* valid, float* out,
+                                 float* height, float* count, hipStream_t s) {
+#define DM_CASE(R)                                                                     \
+  case R:                                                                              \
+    hipLaunchKernelGGL((k_scatter_generic<R, FUSED>), grid, dim3(256), 0, s, v, p.dc,   \
+                       p.vc, p.valid_c, frames, depth, value, valid, out, height, count); \
+    break;
+  switch (p.reduction) {
+    DM_CASE(DM_REDUCE_MAX)
+    DM_CASE(DM_REDUCE_MIN)
+    DM_CASE(DM_REDUCE_SUM)
+    DM_CASE(DM_REDUCE_MEAN)
+    DM_CASE(DM_REDUCE_PROD)
+    default: return hipErrorInvalidValue;
+  }
+#undef DM_CASE
+  return hipGetLastError();
+}
+
+size_t generic_workspace_bytes(const dm_params& p) {
+  if (p.reduction != DM_REDUCE_MEAN) return 0;
+  const size_t oc = p.vc ? p.vc : p.dc;
+  return (size_t)p.B * oc * p.mh * p.mw * sizeof(float);
+}
+
+hipError_t run_generic(const dm_params& p, const dm_frame* frames, const float* depth,
+                       const float* value, const uint8_t* valid, float* out,
+                       uint8_t* mask, float* height, void* ws, hipStream_t s) {
+  const View v = make_view(p);
+  const size_t M = (size_t)p.mh * p.mw, oc = p.vc ? p.vc : p.dc;
+  const size_t n_out = (size_t)p.B * oc * M;
+  const size_t n_h = height ? (size_t)p.B * p.dc * M : 0;
+  float* count = p.reduction == DM_REDUCE_MEAN ? static_cast<float*>(ws) : nullptr;
+  hipLaunchKernelGGL(k_fill, dim3(blocks_for(n_out > n_h ? n_out : n_h, 1024, 4096)), dim3(256),
+                     0, s, out, p.fill, n_out, height, -__builtin_inff(), n_h);
+  if (count)
+    hipLaunchKernelGGL(k_fill, dim3(blocks_for(n_out, 1024, 4096)), dim3(256), 0, s, count, 0.0f,
+                       n_out, (float*)nullptr, 0.0f, (size_t)0);
+  const int N = p.H * p.W;
+  dim3 grid((N + 255) / 256, p.dc, p.B);
+  hipError_t e = launch_scatter<false>(p, v, grid, frames, depth, value, valid, out, height,
+                                       count, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize, dim3(blocks_for(n_out, 1024, 4096)), dim3(256), 0, s, out, count,
+                     p.fill, mask, n_out);
+  return hipGetLastError();
+}
+
+hipError_t run_generic_fused(const dm_params& p, const dm_frame* frames, const float* depth,
+                             const float* value, const uint8_t* valid, float* out,
+                             uint8_t* mask, int accumulate, hipStream_t s) {
+  const View v = make_view(p);
+  const size_t M = (size_t)p.mh * p.mw, oc = p.vc ? p.vc : p.dc;
+  const size_t n_out = oc * M;
+  if (!accumulate)
+    hipLaunchKernelGGL(k_fill, dim3(blocks_for(n_out, 1024, 4096)), dim3(256), 0, s, out, p.fill,
+                       n_out, (float*)nullptr, 0.0f, (size_t)0);
+  const int N = p.H * p.W;
+  dim3 grid((N + 255) / 256, p.dc, p.B);
+  hipError_t e = launch_scatter<true>(p, v, grid, frames, depth, value, valid, out, nullptr,
+                                      nullptr, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize, dim3(blocks_for(n_out, 1024, 4096)), dim3(256), 0, s, out,
+                     (const float*)nullptr, p.fill, mask, n_out);
+  return hipGetLastError();
+}
+
+hipError_t run_mask_from_map(const float* map, float fill, uint8_t* mask, size_t n,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(k_finalize, dim3(blocks_for(n, 1024, 4096)), dim3(256), 0, s,
+                     const_cast<float*>(map), (const float*)nullptr, fill, mask, n);
+  return hipGetLastError();
+}
+
+}  // namespace dm

@@ -1,0 +1,21 @@
+// Internal launcher declarations shared by the translation units of
+// libdungeon_maps_amd.so.  The public surface is include/dungeon_maps_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dm_pixel.hpp"
+
+namespace dm {
+
+// dm_generic.hip -- fill / global-atomic scatter / finalize
+size_t generic_workspace_bytes(const dm_params& p);
+hipError_t run_generic(const dm_params& p, const dm_frame* frames, const float* depth,
+                       const float* value, const uint8_t* valid, float* out,
+                       uint8_t* mask, float* height, void* ws, hipStream_t s);
+hipError_t run_generic_fused(const dm_params& p, const dm_frame* frames, const float* depth,
+                             const float* value, const uint8_t* valid, float* out,
+                             uint8_t* mask, int accumulate, hipStream_t s);
+hipError_t run_mask_from_map(const float* map, float fill, uint8_t* mask, size_t n,
+                             hipStream_t s);
+
+}  // namespace dm

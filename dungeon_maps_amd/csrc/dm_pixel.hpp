@@ -1,0 +1,131 @@
+// Per-pixel geometry of the projector: depth pixel -> (map cell, height).
+//
+// This is the arithmetic contract of the whole library: float32 throughout,
+// one rounding per written operation (the translation unit is compiled with
+// -ffp-contract=off), true IEEE division, and the two rotations evaluated as
+// the 3-term FMA chain  fma(p2, R[6+i], fma(p1, R[3+i], p0 * R[i]))  -- the
+// order in which the reference's einsum->bmm accumulates on its CPU path
+// (reference dungeon_maps/utils.py:329).  Cell indices therefore match the
+// reference bit for bit; see tests/test_hip_parity.py.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dungeon_maps_amd.h"
+
+namespace dm {
+
+// Call-wide constants in the form the kernels consume them.
+struct View {
+  int H, W, mh, mw;
+  int clip;            // 0 = off
+  int flip_h, to_global;
+  int has_dmin, has_dmax, has_hmax;
+  float cx, cy, fx, fy, res;
+  float dmin, dmax, hmax;
+  float Hm1, mhm1;     // float(H-1), float(mh-1)
+  float fmw, fmh;      // float(mw), float(mh)
+};
+
+__host__ inline View make_view(const dm_params& p) {
+  View v;
+  v.H = p.H; v.W = p.W; v.mh = p.mh; v.mw = p.mw;
+  v.clip = p.clip_border > 0 ? p.clip_border : 0;
+  v.flip_h = p.flip_h != 0; v.to_global = p.to_global != 0;
+  v.has_dmin = p.has_dmin != 0; v.has_dmax = p.has_dmax != 0; v.has_hmax = p.has_hmax != 0;
+  v.cx = p.cx; v.cy = p.cy; v.fx = p.fx; v.fy = p.fy; v.res = p.res;
+  v.dmin = p.dmin; v.dmax = p.dmax; v.hmax = p.hmax;
+  v.Hm1 = (float)(p.H - 1); v.mhm1 = (float)(p.mh - 1);
+  v.fmw = (float)p.mw; v.fmh = (float)p.mh;
+  return v;
+}
+
+// One frame's camera state pulled into registers (wave-uniform: SGPRs).
+struct Cam {
+  float p[9];   // pitch rotation
+  float y[9];   // yaw rotation
+  float h, tx, tz, wo, ho;
+};
+
+__device__ inline Cam load_cam(const dm_frame* __restrict__ f) {
+  Cam c;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { c.p[i] = f->Rp[i]; c.y[i] = f->Ry[i]; }
+  c.h = f->cam_height; c.tx = f->tx; c.tz = f->tz;
+  c.wo = f->width_offset; c.ho = f->height_offset;
+  return c;
+}
+
+struct Hit {
+  int cell;     // zb * mw + xb, or -1 when the pixel does not land in the map
+  float y;      // height in the output frame (y2)
+};
+
+// Image column/row -> normalised ray slopes, reference maps.py:670-678.
+__device__ inline float ray_x(const View& v, int q) { return ((float)q - v.cx) / v.fx; }
+__device__ inline float ray_y(const View& v, int r) {
+  float yr = (float)r;
+  if (v.flip_h) yr = v.Hm1 - yr;
+  return (yr - v.cy) / v.fy;
+}
+
+// The projector proper.  `ax`, `ay` are ray_x(q), ray_y(r); `ok` carries the
+// validity known so far (valid_map, border clip).
+__device__ inline Hit project_pixel(const View& v, const Cam& c, float z, float ax,
+                                    float ay, bool ok) {
+  // camera space (maps.py:677-678)
+  const float X = ax * z;
+  const float Y = ay * z;
+  // depth truncation (maps.py:537-544); NaN compares false
+  if (v.has_dmax) ok = ok && (z <= v.dmax);
+  if (v.has_dmin) ok = ok && (z >= v.dmin);
+  // pitch about X then lift by the camera height (maps.py:790-797)
+  const float x1 = __builtin_fmaf(z, c.p[6], __builtin_fmaf(Y, c.p[3], X * c.p[0])) + 0.0f;
+  const float y1 = __builtin_fmaf(z, c.p[7], __builtin_fmaf(Y, c.p[4], X * c.p[1])) + c.h;
+  const float z1 = __builtin_fmaf(z, c.p[8], __builtin_fmaf(Y, c.p[5], X * c.p[2])) + 0.0f;
+  if (v.has_hmax) ok = ok && (y1 <= v.hmax);       // maps.py:286-288
+  float x2 = x1, y2 = y1, z2 = z1;
+  if (v.to_global) {                               // maps.py:884-892
+    x2 = __builtin_fmaf(z1, c.y[6], __builtin_fmaf(y1, c.y[3], x1 * c.y[0])) + c.tx;
+    y2 = __builtin_fmaf(z1, c.y[7], __builtin_fmaf(y1, c.y[4], x1 * c.y[1])) + 0.0f;
+    z2 = __builtin_fmaf(z1, c.y[8], __builtin_fmaf(y1, c.y[5], x1 * c.y[2])) + c.tz;
+  }
+  // quantise, round half up (maps.py:1004-1013)
+  float xf = x2 / v.res + c.wo;
+  float zf = z2 / v.res + c.ho;
+  if (v.flip_h) zf = v.mhm1 - zf;
+  xf = __builtin_floorf(xf + 0.5f);
+  zf = __builtin_floorf(zf + 0.5f);
+  // canvas bounds (maps.py:1150-1158) tested in float: NaN/inf fall out here,
+  // exactly like the reference's INT64_MIN after .to(int64)
+  ok = ok && (xf >= 0.0f) && (xf < v.fmw) && (zf >= 0.0f) && (zf < v.fmh);
+  Hit h;
+  h.cell = ok ? (int)zf * v.mw + (int)xf : -1;
+  h.y = y2;
+  return h;
+}
+
+__device__ inline bool border_ok(const View& v, int r, int q) {
+  // maps.py:48-70
+  return v.clip == 0 ||
+         (r >= v.clip && r < v.H - v.clip && q >= v.clip && q < v.W - v.clip);
+}
+
+// ---------------------------------------------------------------------------
+// order-preserving float <-> uint key: k(a) < k(b)  <=>  a < b (with -0 < +0)
+__device__ inline uint32_t f2key(float f) {
+  uint32_t u = __float_as_uint(f);
+  return u ^ ((u & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ inline float key2f(uint32_t k) {
+  uint32_t u = k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu);
+  return __uint_as_float(u);
+}
+
+// utils.py:489-491 as a function of (map, fill)
+__device__ inline uint8_t mask_of(float out, float fill) {
+  const float d = out - fill;     // inf - inf = NaN -> unchanged
+  return (d != 0.0f && d == d) ? 1 : 0;
+}
+
+}  // namespace dm

@@ -1,0 +1,460 @@
+"""Raw functional API (reference dungeon_maps/maps.py:121-1248), MI355X-native.
+
+``orth_project`` -- the hot path -- and ``project`` / ``scatter_nd`` run on the
+hand-written HIP library through the C ABI (include/dungeon_maps_amd.h).  The
+remaining functions are the small point-set helpers callers use around it
+(coordinate queries, offsets); they are thin float32 tensor formulas.
+
+Differences from the reference, on purpose:
+* batches work (the reference crashes for B > 1 in utils.rotate, utils.py:303-316);
+  per-frame arguments may have 1 or B rows.
+* inputs on the CPU are accepted, computed on the GPU and returned on the CPU;
+  without a GPU the call raises -- there is no CPU fallback.
+"""
+from typing import Any, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _native, frames, utils
+from .utils import NINF, Reduction
+
+__all__ = [
+    "CenterMode", "get", "orth_project", "orth_project_fused", "camera_affine_grid",
+    "depth_map_to_point_cloud", "height_map_to_point_cloud", "image_to_camera_space",
+    "camera_to_image_space", "camera_to_local_space", "local_to_camera_space",
+    "local_to_global_space", "global_to_local_space", "map_quantize",
+    "map_dequantize", "project", "compute_center_offsets",
+]
+
+import enum
+
+
+class CenterMode(str, enum.Enum):
+  """Where the map is centred (reference maps.py:26-39)."""
+  none = "none"
+  origin = "origin"
+  camera = "camera"
+
+  @classmethod
+  def _missing_(cls, value):
+    return cls.none if value is None else None
+
+
+def get(*args: Any) -> Any:
+  """First argument that is not None (the last one if all are)."""
+  for arg in args:
+    if arg is not None:
+      return arg
+  return args[-1] if args else None
+
+
+_REDUCTION_CODE = {
+    Reduction.max: _native.REDUCE_MAX, Reduction.min: _native.REDUCE_MIN,
+    Reduction.sum: _native.REDUCE_SUM, Reduction.mean: _native.REDUCE_MEAN,
+    Reduction.prod: _native.REDUCE_PROD,
+}
+
+
+def _reduction_code(reduction) -> int:
+  red = Reduction(reduction)
+  if red not in _REDUCTION_CODE:
+    raise ValueError(f"Invalid reduction method: {reduction}")
+  return _REDUCTION_CODE[red]
+
+
+def _compute_device(target: torch.device) -> torch.device:
+  """The GPU the kernels run on: the tensors' own device when that is a GPU,
+  else the current GPU.  No GPU -> error (no CPU path by design)."""
+  if target.type == "cuda":
+    return target
+  if not torch.cuda.is_available():
+    raise RuntimeError(
+        "dungeon_maps_amd computes on an AMD GPU through its HIP library and has no CPU "
+        "fallback; no GPU is visible to PyTorch in this process.")
+  return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream_ptr(device: torch.device) -> int:
+  return torch.cuda.current_stream(device).cuda_stream
+
+
+def _image(x, device, dtype) -> torch.Tensor:
+  t = utils.to_4D_image(utils.to_tensor(x))
+  return t.to(device=device, dtype=dtype).contiguous()
+
+
+class _Call:
+  """Canonicalised arguments of one orth_project call (maps.py:225-257)."""
+
+  def __init__(self, depth_map, value_map, valid_map, cam_pose, width_offset,
+               height_offset, cam_pitch, cam_height, map_res, map_width, map_height,
+               focal_x, focal_y, center_x, center_y, trunc_depth_min, trunc_depth_max,
+               trunc_height_max, clip_border, to_global, flip_h, fill_value, reduction,
+               device):
+    first = utils.to_tensor(depth_map)
+    self.target = torch.device(device) if device is not None else first.device
+    self.dev = _compute_device(self.target)
+    self.depth = _image(first, self.dev, torch.float32)
+    B, dc, H, W = self.depth.shape
+    self.value = None if value_map is None else _image(value_map, self.dev, torch.float32)
+    self.valid = None if valid_map is None else _image(valid_map, self.dev, torch.bool)
+    vc = 0
+    if self.value is not None:
+      if self.value.shape[0] != B or self.value.shape[2:] != (H, W):
+        raise ValueError(f"value_map {tuple(self.value.shape)} does not match depth_map "
+                         f"{tuple(self.depth.shape)}")
+      vc = self.value.shape[1]
+      if dc not in (1, vc):
+        raise ValueError(f"depth_map has {dc} channels; expected 1 or {vc} (value_map's)")
+    valid_c = 0
+    if self.valid is not None:
+      if self.valid.shape[2:] != (H, W) or self.valid.shape[0] not in (1, B) \
+          or self.valid.shape[1] not in (1, dc):
+        raise ValueError(f"valid_map {tuple(self.valid.shape)} does not broadcast to "
+                         f"depth_map {tuple(self.depth.shape)}")
+      if self.valid.shape[0] != B:
+        self.valid = self.valid.expand(B, -1, -1, -1).contiguous()
+      valid_c = self.valid.shape[1]
+    p = _native.Params()
+    p.B, p.dc, p.vc, p.H, p.W = B, dc, vc, H, W
+    p.mh, p.mw = int(map_height), int(map_width)
+    p.clip_border = int(clip_border) if clip_border is not None else 0
+    p.flip_h = int(bool(flip_h))
+    p.to_global = int(bool(to_global))
+    p.reduction = _reduction_code(reduction)
+    p.has_dmin = int(trunc_depth_min is not None)
+    p.has_dmax = int(trunc_depth_max is not None)
+    p.has_hmax = int(trunc_height_max is not None)
+    p.valid_c = valid_c
+    p.cx, p.cy, p.fx, p.fy = float(center_x), float(center_y), float(focal_x), float(focal_y)
+    p.res = float(map_res)
+    # fill_value None: the reference scatters into an all-zero canvas (maps.py:320)
+    p.fill = 0.0 if fill_value is None else float(fill_value)
+    p.dmin = float(trunc_depth_min) if trunc_depth_min is not None else 0.0
+    p.dmax = float(trunc_depth_max) if trunc_depth_max is not None else 0.0
+    p.hmax = float(trunc_height_max) if trunc_height_max is not None else 0.0
+    self.params = p
+    self.oc = vc if vc else dc
+    table = frames.build_frame_table(B, cam_pose, cam_pitch, cam_height, width_offset,
+                                     height_offset)
+    self.frames = frames.upload(table, self.dev)
+
+  def workspace(self) -> Tuple[Optional[torch.Tensor], int]:
+    import ctypes
+    need = _native.lib().dm_orth_project_workspace_bytes(ctypes.byref(self.params))
+    if need == 0:
+      return None, 0
+    return torch.empty(need, dtype=torch.uint8, device=self.dev), need
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+  return None if t is None else t.data_ptr()
+
+
+def orth_project(
+    depth_map, value_map, valid_map, cam_pose, width_offset, height_offset, cam_pitch,
+    cam_height, map_res: float, map_width: int, map_height: int, focal_x: float,
+    focal_y: float, center_x: float, center_y: float, trunc_depth_min: Optional[float],
+    trunc_depth_max: Optional[float], trunc_height_max: Optional[float],
+    clip_border: Optional[int], to_global: bool, flip_h: bool = True,
+    fill_value: Optional[float] = None, reduction: Optional[Reduction] = None,
+    get_height_map: bool = False, device: Optional[torch.device] = None,
+    _validate_args: bool = True
+) -> Union[Tuple[torch.Tensor, torch.Tensor],
+           Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+  """Orthographic projection of depth maps (b, c, h, w) to top-down maps.
+
+  Same signature, argument meaning and returns as reference maps.py:127-351:
+  ``(topdown (b,C,mh,mw) f32, mask (b,C,mh,mw) bool[, height_map])``.  Without
+  ``value_map`` the heights are projected and ``height_map`` is the very same
+  tensor as ``topdown``; with a ``value_map`` the height map is a second
+  NINF/max projection broadcast over the value channels (stride 0).
+
+  One fused HIP launch sequence replaces the reference's ~230 ATen calls:
+  unproject, pitch/yaw/translate, truncations, quantisation, scatter-reduce and
+  the changed-mask (dm_orth_project_f32).
+  """
+  import ctypes
+  call = _Call(depth_map, value_map, valid_map, cam_pose, width_offset, height_offset,
+               cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
+               center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
+               clip_border, to_global, flip_h, fill_value, reduction, device)
+  p = call.params
+  shape = (p.B, call.oc, p.mh, p.mw)
+  topdown = torch.empty(shape, dtype=torch.float32, device=call.dev)
+  mask = torch.empty(shape, dtype=torch.bool, device=call.dev)
+  height = None
+  if get_height_map and p.vc:
+    height = torch.empty((p.B, p.dc, p.mh, p.mw), dtype=torch.float32, device=call.dev)
+  ws, ws_bytes = call.workspace()
+  with torch.cuda.device(call.dev):
+    _native.check(_native.lib().dm_orth_project_f32(
+        ctypes.byref(p), _ptr(call.frames), _ptr(call.depth), _ptr(call.value),
+        _ptr(call.valid), _ptr(topdown), _ptr(mask), _ptr(height), _ptr(ws), ws_bytes,
+        _stream_ptr(call.dev)))
+  if call.target != call.dev:
+    topdown, mask = topdown.to(call.target), mask.to(call.target)
+    height = None if height is None else height.to(call.target)
+  if not get_height_map:
+    return topdown, mask
+  if height is None:
+    return topdown, mask, topdown
+  return topdown, mask, torch.broadcast_to(height, topdown.shape)
+
+
+def orth_project_fused(
+    depth_map, value_map, valid_map, cam_pose, width_offset, height_offset, cam_pitch,
+    cam_height, map_res, map_width, map_height, focal_x, focal_y, center_x, center_y,
+    trunc_depth_min, trunc_depth_max, trunc_height_max, clip_border, to_global=True,
+    flip_h=True, fill_value=NINF, reduction=None, out: Optional[torch.Tensor] = None,
+    device=None
+) -> Tuple[torch.Tensor, torch.Tensor]:
+  """Project a batch and fuse all frames into ONE (C, mh, mw) map (max/min).
+
+  New entry point (north_star "projected+fused"): the per-rank partial global
+  map.  Identical to reducing ``orth_project``'s output over the batch axis,
+  which in turn equals the reference's MapBuilder.merge for maps that share
+  resolution/offsets/size (element-wise max).  ``out`` (C, mh, mw),
+  if given, is the running world map: its content takes part in the reduction.
+  """
+  import ctypes
+  call = _Call(depth_map, value_map, valid_map, cam_pose, width_offset, height_offset,
+               cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
+               center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
+               clip_border, to_global, flip_h, fill_value, reduction, device)
+  p = call.params
+  shape = (call.oc, p.mh, p.mw)
+  accumulate = out is not None
+  if accumulate:
+    if tuple(out.shape) != shape or out.dtype != torch.float32 or out.device != call.dev \
+        or not out.is_contiguous():
+      raise ValueError(f"`out` must be a contiguous float32 {shape} tensor on {call.dev}")
+  else:
+    out = torch.empty(shape, dtype=torch.float32, device=call.dev)
+  mask = torch.empty(shape, dtype=torch.bool, device=call.dev)
+  ws, ws_bytes = call.workspace()
+  with torch.cuda.device(call.dev):
+    _native.check(_native.lib().dm_orth_project_fused_f32(
+        ctypes.byref(p), _ptr(call.frames), _ptr(call.depth), _ptr(call.value),
+        _ptr(call.valid), _ptr(out), _ptr(mask), int(accumulate), _ptr(ws), ws_bytes,
+        _stream_ptr(call.dev)))
+  return out, mask
+
+
+def mask_from_map(topdown: torch.Tensor, fill_value: Optional[float]) -> torch.Tensor:
+  """mask = (map - fill != 0, NaN -> False): reference utils.py:489-491 as a
+  function of the finished map (used after a cross-rank max all-reduce)."""
+  if topdown.device.type != "cuda":
+    raise RuntimeError("mask_from_map runs on the GPU")
+  t = topdown.contiguous()
+  mask = torch.empty(t.shape, dtype=torch.bool, device=t.device)
+  with torch.cuda.device(t.device):
+    _native.check(_native.lib().dm_mask_from_map_f32(
+        _ptr(t), 0.0 if fill_value is None else float(fill_value), _ptr(mask), t.numel(),
+        _stream_ptr(t.device)))
+  return mask
+
+
+# ---------------------------------------------------------------------------
+# Point-set helpers (small tensors; float32 formulas in the reference's order)
+# ---------------------------------------------------------------------------
+def _points(points, device=None) -> torch.Tensor:
+  t = utils.to_tensor(points, device=device).to(torch.float32)
+  return t.reshape(1, 3) if t.dim() < 2 else t
+
+
+def image_to_camera_space(points, focal_x, focal_y, center_x, center_y, flip_h=True,
+                          height=None, device=None, _validate_args=True) -> torch.Tensor:
+  """(col, row, depth) -> camera space X right / Y up / Z forward
+  (reference maps.py:616-682)."""
+  pts = utils.to_tensor(points, device=device).to(torch.float32)
+  shape = pts.shape
+  if pts.dim() < 2:
+    pts = pts.reshape(-1, 3)
+  if flip_h and height is None:
+    if pts.dim() < 3:
+      raise RuntimeError("The rank of `points` must be at least 3D (..., h, w, 3) "
+                         "or `height` should be provided if `flip_h` is enabled.")
+    height = pts.shape[-3]
+  x, y, z = pts.unbind(-1)
+  if flip_h:
+    y = (height - 1) - y
+  cx, cy, fx, fy = (utils.to_tensor_like(v, pts) for v in (center_x, center_y, focal_x, focal_y))
+  out = torch.stack(((x - cx) / fx * z, (y - cy) / fy * z, z), dim=-1)
+  return out.reshape(shape)
+
+
+def camera_to_image_space(points, focal_x, focal_y, center_x, center_y, flip_h=True,
+                          height=None, device=None, _validate_args=True) -> torch.Tensor:
+  """Camera space -> (col, row, depth) (reference maps.py:684-751)."""
+  pts = utils.to_tensor(points, device=device).to(torch.float32)
+  shape = pts.shape
+  if pts.dim() < 2:
+    pts = pts.reshape(-1, 3)
+  if flip_h and height is None:
+    if pts.dim() < 3:
+      raise RuntimeError("The rank of `points` must be at least 3D (..., h, w, 3) "
+                         "or `height` should be provided if `flip_h` is enabled.")
+    height = pts.shape[-3]
+  x, y, z = pts.unbind(-1)
+  cx, cy, fx, fy = (utils.to_tensor_like(v, pts) for v in (center_x, center_y, focal_x, focal_y))
+  z_eps = z + 1e-7
+  u = x / z_eps * fx + cx
+  v = y / z_eps * fy + cy
+  if flip_h:
+    v = (height - 1) - v
+  return torch.stack((u, v, z), dim=-1).reshape(shape)
+
+
+def _lift(cam_height: torch.Tensor, sign: float) -> torch.Tensor:
+  o = torch.zeros_like(cam_height)
+  return torch.stack((o, sign * cam_height, o), dim=-1)
+
+
+def camera_to_local_space(points, cam_pitch, cam_height, device=None,
+                          _validate_args=True) -> torch.Tensor:
+  """Rotate by the camera pitch about X, then lift by the camera height."""
+  pts = _points(points, device)
+  pitch = utils.to_tensor(cam_pitch, device=pts.device).to(torch.float32).reshape(-1)
+  h = utils.to_tensor(cam_height, device=pts.device).to(torch.float32).reshape(-1)
+  out = utils.rotate(pts.reshape(pts.shape[0], -1, 3), [1., 0., 0.], pitch)
+  return utils.translate(out, _lift(h, 1.0)).reshape(pts.shape)
+
+
+def local_to_camera_space(points, cam_pitch, cam_height, device=None,
+                          _validate_args=True) -> torch.Tensor:
+  pts = _points(points, device)
+  pitch = utils.to_tensor(cam_pitch, device=pts.device).to(torch.float32).reshape(-1)
+  h = utils.to_tensor(cam_height, device=pts.device).to(torch.float32).reshape(-1)
+  out = utils.translate(pts.reshape(pts.shape[0], -1, 3), _lift(h, -1.0))
+  return utils.rotate(out, [1., 0., 0.], -pitch).reshape(pts.shape)
+
+
+def _pose_offset(pose: torch.Tensor) -> torch.Tensor:
+  return torch.stack((pose[:, 0], torch.zeros_like(pose[:, 0]), pose[:, 1]), dim=-1)
+
+
+def local_to_global_space(points, cam_pose, device=None, _validate_args=True) -> torch.Tensor:
+  """Rotate by yaw about Y, then translate by (pose_x, 0, pose_z)."""
+  pts = _points(points, device)
+  pose = utils.to_tensor(cam_pose, device=pts.device).to(torch.float32).reshape(-1, 3)
+  out = utils.rotate(pts.reshape(pts.shape[0], -1, 3), [0., 1., 0.], pose[:, 2])
+  return utils.translate(out, _pose_offset(pose)).reshape(pts.shape)
+
+
+def global_to_local_space(points, cam_pose, device=None, _validate_args=True) -> torch.Tensor:
+  pts = _points(points, device)
+  pose = utils.to_tensor(cam_pose, device=pts.device).to(torch.float32).reshape(-1, 3)
+  out = utils.translate(pts.reshape(pts.shape[0], -1, 3), -_pose_offset(pose))
+  return utils.rotate(out, [0., 1., 0.], -pose[:, 2]).reshape(pts.shape)
+
+
+def _offset_column(v, like: torch.Tensor) -> torch.Tensor:
+  t = utils.to_tensor(v, device=like.device).to(torch.float32).reshape(-1)
+  return t.reshape((-1,) + (1,) * (like.dim() - 1))
+
+
+def map_quantize(x_coords, z_coords, width_offset, height_offset, map_res,
+                 map_height=None, flip_h=True, device=None, _validate_args=True
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+  """World x/z -> integer map column/row, round-half-up
+  (reference maps.py:944-1019)."""
+  x = utils.to_tensor(x_coords, device=device).to(torch.float32)
+  z = utils.to_tensor(z_coords, device=x.device).to(torch.float32)
+  x, z = torch.broadcast_tensors(x, z)
+  if x.dim() < 2:
+    x, z = x.reshape(1, -1), z.reshape(1, -1)
+  col = x / map_res + _offset_column(width_offset, x)
+  row = z / map_res + _offset_column(height_offset, x)
+  if flip_h:
+    assert map_height is not None
+    row = (torch.tensor(map_height, device=x.device) - 1) - row
+  return (torch.floor(col + 0.5).to(torch.int64), torch.floor(row + 0.5).to(torch.int64))
+
+
+def map_dequantize(x_coords, z_coords, width_offset, height_offset, map_res,
+                   map_height=None, flip_h=True, device=None, _validate_args=True
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
+  """Inverse of map_quantize (cell -> world x/z of its centre)."""
+  col = utils.to_tensor(x_coords, device=device).to(torch.float32)
+  row = utils.to_tensor(z_coords, device=col.device).to(torch.float32)
+  col, row = torch.broadcast_tensors(col, row)
+  if col.dim() < 2:
+    col, row = col.reshape(1, -1), row.reshape(1, -1)
+  if flip_h:
+    assert map_height is not None
+    row = (torch.tensor(map_height, device=col.device) - 1) - row
+  z = (row - _offset_column(height_offset, col)) * map_res
+  x = (col - _offset_column(width_offset, col)) * map_res
+  return x, z
+
+
+def depth_map_to_point_cloud(depth_map, valid_map, focal_x, focal_y, center_x, center_y,
+                             trunc_depth_min, trunc_depth_max, flip_h=True, device=None,
+                             _validate_args=True) -> Tuple[torch.Tensor, torch.Tensor]:
+  """Camera-space point cloud (..., h, w, 3) + validity (..., h, w) of a depth
+  map (reference maps.py:462-545).  Materialises the cloud -- orth_project does
+  NOT go through this; it is here for callers that want the points."""
+  depth = utils.to_4D_image(utils.to_tensor(depth_map, device=device)).to(torch.float32)
+  xs, ys = utils.generate_image_coords(depth.shape, torch.float32, depth.device)
+  cloud = image_to_camera_space(torch.stack((xs, ys, depth), dim=-1), focal_x, focal_y,
+                                center_x, center_y, flip_h, height=depth.shape[-2])
+  ok = torch.ones_like(depth, dtype=torch.bool)
+  if trunc_depth_max is not None:
+    ok = ok & (depth <= trunc_depth_max)
+  if trunc_depth_min is not None:
+    ok = ok & (depth >= trunc_depth_min)
+  if valid_map is not None:
+    vm = utils.to_4D_image(utils.to_tensor(valid_map, device=depth.device)).to(torch.bool)
+    ok = ok & vm
+  return cloud, ok
+
+
+def height_map_to_point_cloud(height_map, width_offset, height_offset, map_res, map_height,
+                              flip_h=True, device=None, _validate_args=True) -> torch.Tensor:
+  """Cell-centre point cloud (b, c, h, w, 3) of a height map
+  (reference maps.py:547-612)."""
+  hm = utils.to_4D_image(utils.to_tensor(height_map, device=device)).to(torch.float32)
+  cols, rows = utils.generate_image_coords(hm.shape, torch.float32, hm.device)
+  x, z = map_dequantize(cols, rows, width_offset, height_offset, map_res, map_height, flip_h)
+  return torch.stack((x, hm, z), dim=-1)
+
+
+def compute_center_offsets(cam_pose, width_offset, height_offset, map_res, map_width,
+                           map_height, to_global, center_mode=CenterMode.none, device=None,
+                           _validate_args=True) -> Tuple[torch.Tensor, torch.Tensor]:
+  """Offsets that put the global origin / the camera at the map centre
+  (reference maps.py:1175-1248)."""
+  mode = CenterMode(center_mode)
+  pose = utils.to_tensor(torch.zeros(3) if cam_pose is None else cam_pose,
+                         device=device).to(torch.float32)
+  woff = utils.to_tensor(0. if width_offset is None else width_offset,
+                         device=pose.device).to(torch.float32)
+  hoff = utils.to_tensor(0. if height_offset is None else height_offset,
+                         device=pose.device).to(torch.float32)
+  if mode is CenterMode.none:
+    return woff + 0., hoff + 0.
+  centre = torch.zeros_like(pose)
+  if mode is CenterMode.camera and to_global:
+    centre = local_to_global_space(centre, pose)
+  col, row = map_quantize(centre[..., 0], centre[..., 2], 0., 0., map_res, map_height,
+                          flip_h=False)
+  return woff + (map_width / 2. - col), hoff + (map_height / 2. - row)
+
+
+# ---------------------------------------------------------------------------
+# project / scatter (reference maps.py:1089-1173, utils.py:389-492)
+# ---------------------------------------------------------------------------
+def scatter_nd(canvas, indices, values, masks=None, fill_value=None, reduction=None):
+  raise NotImplementedError("scatter_nd lands with dm_scatter_f32")
+
+
+def project(coords, values, masks, canvas, canvas_masks=None, fill_value=None,
+            reduction=None, device=None, _validate_args=True):
+  raise NotImplementedError("project lands with dm_scatter_f32")
+
+
+def camera_affine_grid(depth_map, trans_pose, cam_pitch, cam_height, focal_x, focal_y,
+                       center_x, center_y, flip_h=True, device=None, _validate_args=True):
+  raise NotImplementedError("camera_affine_grid lands with dm_camera_affine_grid_f32")

@@ -1,0 +1,287 @@
+"""Object API: MapProjector, TopdownMap, MapBuilder (+ crop / fuse).
+
+Drop-in for reference ``dungeon_maps/maps.py:1252-2550``: same class names,
+constructor keywords, properties and method names.  ``MapProjector`` is the
+configuration holder: every functional API is reachable as a method whose
+``None`` arguments fall back to the projector's stored defaults.
+"""
+import inspect
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import functional as F
+from . import utils
+from .functional import *  # noqa: F401,F403  (module-level functional twins)
+from .functional import CenterMode, get
+from .utils import NINF, CameraIntrinsics, Reduction
+
+Float3D = Tuple[float, float, float]
+
+
+class MapProjector:
+  """Camera + map configuration and default-argument forwarding.
+
+  Keyword names, defaults and meaning as reference maps.py:1253-1340
+  (``fill_value`` defaults to NINF, ``flip_h`` to True, ``to_global`` to False).
+  """
+
+  _FIELDS = ("width", "height", "hfov", "vfov", "cam_pose", "width_offset",
+             "height_offset", "cam_pitch", "cam_height", "map_res", "map_width",
+             "map_height", "trunc_depth_min", "trunc_depth_max", "trunc_height_max",
+             "clip_border", "to_global", "flip_h", "fill_value", "reduction", "device")
+
+  def __init__(self, width: int, height: int, hfov: float, vfov: Optional[float] = None,
+               cam_pose: Optional[Float3D] = None, width_offset: Optional[float] = None,
+               height_offset: Optional[float] = None, cam_pitch: Optional[float] = None,
+               cam_height: Optional[float] = None, map_res: Optional[float] = None,
+               map_width: Optional[int] = None, map_height: Optional[int] = None,
+               trunc_depth_min: Optional[float] = None,
+               trunc_depth_max: Optional[float] = None,
+               trunc_height_max: Optional[float] = None,
+               clip_border: Optional[int] = None, to_global: bool = False,
+               flip_h: bool = True, fill_value: Optional[float] = NINF,
+               reduction: Optional[Reduction] = None,
+               device: Optional[torch.device] = None):
+    values = locals()
+    for name in self._FIELDS:
+      setattr(self, name, values[name])
+    self.cam_params: CameraIntrinsics = utils.get_camera_intrinsics(
+        width=width, height=height, hfov=hfov, vfov=vfov)
+
+  def clone(self, **overrides) -> "MapProjector":
+    """Shallow copy with some fields replaced (None = keep)."""
+    unknown = set(overrides) - set(self._FIELDS)
+    if unknown:
+      raise TypeError(f"clone() got unexpected keyword arguments {sorted(unknown)}")
+    return MapProjector(**{name: get(overrides.get(name), getattr(self, name))
+                           for name in self._FIELDS})
+
+  # projector attribute (or intrinsic) behind a functional-API argument name
+  def _default_for(self, name: str):
+    if name in ("focal_x", "focal_y", "center_x", "center_y"):
+      return getattr(self.cam_params, {"focal_x": "fx", "focal_y": "fy",
+                                       "center_x": "cx", "center_y": "cy"}[name])
+    if name in self._FIELDS:
+      return getattr(self, name)
+    return None
+
+
+def _forwarding_method(fn, doc_ref: str):
+  names = list(inspect.signature(fn).parameters)
+  defaults = {n: p.default for n, p in inspect.signature(fn).parameters.items()
+              if p.default is not inspect.Parameter.empty}
+
+  def method(self, *args, **kwargs):
+    if len(args) > len(names):
+      raise TypeError(f"{fn.__name__}() takes at most {len(names)} arguments")
+    given = dict(zip(names, args))
+    for k, v in kwargs.items():
+      if k not in names:
+        raise TypeError(f"{fn.__name__}() got an unexpected keyword argument '{k}'")
+      if k in given:
+        raise TypeError(f"{fn.__name__}() got multiple values for argument '{k}'")
+      given[k] = v
+    call = {}
+    for n in names:
+      v = given.get(n)
+      if v is None:
+        v = self._default_for(n)            # get(arg, self.<arg>)
+      if v is None and n not in given:
+        v = defaults.get(n)                 # the functional API's own default
+      call[n] = v
+    return fn(**call)
+
+  method.__name__ = fn.__name__
+  method.__doc__ = (f"``{fn.__name__}`` with None arguments taken from this projector "
+                    f"(reference {doc_ref}).\n\n" + (fn.__doc__ or ""))
+  return method
+
+
+for _fn, _ref in (
+    (F.orth_project, "maps.py:1406-1465"),
+    (F.orth_project_fused, "new: batch-fused partial global map"),
+    (F.camera_affine_grid, "maps.py:1467-1493"),
+    (F.depth_map_to_point_cloud, "maps.py:1495-1521"),
+    (F.height_map_to_point_cloud, "maps.py:1523-1543"),
+    (F.image_to_camera_space, "maps.py:1545-1567"),
+    (F.camera_to_image_space, "maps.py:1569-1591"),
+    (F.camera_to_local_space, "maps.py:1593-1607"),
+    (F.local_to_camera_space, "maps.py:1609-1623"),
+    (F.local_to_global_space, "maps.py:1625-1637"),
+    (F.global_to_local_space, "maps.py:1639-1651"),
+    (F.map_quantize, "maps.py:1653-1675"),
+    (F.map_dequantize, "maps.py:1677-1699"),
+    (F.project, "maps.py:1701-1723"),
+    (F.compute_center_offsets, "maps.py:1725-1749"),
+):
+  setattr(MapProjector, _fn.__name__, _forwarding_method(_fn, _ref))
+
+
+class TopdownMap:
+  """A top-down map with its mask, height map and the projector that made it
+  (reference maps.py:1753-1955)."""
+
+  def __init__(self, topdown_map: Optional[torch.Tensor] = None,
+               mask: Optional[torch.Tensor] = None,
+               height_map: Optional[torch.Tensor] = None,
+               map_projector: Optional[MapProjector] = None,
+               is_height_map: Optional[bool] = None):
+    self._proj = map_projector
+    self._topdown_map = topdown_map
+    self._mask = mask
+    self._height_map = height_map
+    if is_height_map is None:
+      is_height_map = topdown_map is not None and topdown_map is height_map
+    self._is_height_map = is_height_map
+
+  is_empty = property(lambda self: self._topdown_map is None)
+  is_height_map = property(lambda self: self._is_height_map)
+  map = property(lambda self: self._topdown_map)
+  topdown_map = property(lambda self: self._topdown_map)
+  mask = property(lambda self: self._mask)
+  proj = property(lambda self: self._proj)
+
+  @property
+  def height_map(self) -> torch.Tensor:
+    return self._topdown_map if self._is_height_map else self._height_map
+
+  def get_camera(self) -> torch.Tensor:
+    """Cell (col, row) of the camera, (b, 2) int64."""
+    return self.get_coords(torch.zeros(3), is_global=False).squeeze(-2)
+
+  def get_origin(self) -> torch.Tensor:
+    """Cell (col, row) of the global origin, (b, 2) int64."""
+    return self.get_coords(torch.zeros(3), is_global=True).squeeze(-2)
+
+  def get_coords(self, points, is_global: bool = True) -> torch.Tensor:
+    """Cells (b, n, 2) int64 of 3-D points given in global or local space."""
+    pts = utils.to_tensor(points)
+    if pts.dim() < 3:
+      pts = pts.reshape(1, -1, 3)
+    if self.proj.to_global and not is_global:
+      pts = self.proj.local_to_global_space(pts)
+    elif not self.proj.to_global and is_global:
+      pts = self.proj.global_to_local_space(pts)
+    col, row = self.proj.map_quantize(pts[..., 0], pts[..., 2])
+    return torch.stack((col, row), dim=-1)
+
+  def get_points(self, coords) -> torch.Tensor:
+    """World (x, z) (b, n, 2) float32 of cells (col, row)."""
+    cells = utils.to_tensor(coords)
+    if cells.dim() < 3:
+      cells = cells.reshape(1, -1, 2)
+    x, z = self.proj.map_dequantize(cells[..., 0], cells[..., 1])
+    return torch.stack((x, z), dim=-1)
+
+  def select(self, center, crop_width: int, crop_height: int,
+             fill_value: Optional[float] = None) -> "TopdownMap":
+    """Crop-or-pad a window around ``center`` (b, 2) cells."""
+    return crop_topdown_map(self, center=center, crop_width=crop_width,
+                            crop_height=crop_height, fill_value=fill_value)
+
+  def merge(self, *sources: "TopdownMap") -> "TopdownMap":
+    """Fuse other maps into this one's frame (the reference leaves this
+    unimplemented, maps.py:1951-1955)."""
+    return fuse_topdown_maps(self, *sources, map_projector=self.proj)
+
+
+def crop_topdown_map(source: TopdownMap, center, crop_width: int, crop_height: int,
+                     fill_value: Optional[float] = None, mode: str = "nearest",
+                     _validate_args: bool = True) -> TopdownMap:
+  """Crop a (crop_height, crop_width) window centred at ``center`` (b, 2) and
+  shift the projector's offsets accordingly (reference maps.py:1959-2037).
+  Unlike the reference the caller's ``center`` tensor is not modified."""
+  proj = source.proj
+  center = utils.to_tensor(center).reshape(-1, 2).clone()
+  dev = source.height_map.device
+  woff = utils.to_tensor(proj.width_offset, device=center.device)
+  hoff = utils.to_tensor(proj.height_offset, device=center.device)
+  grid = utils.generate_crop_grid(center.to(dev), proj.map_width, proj.map_height,
+                                  crop_width, crop_height)
+  height_map = utils.image_sample(source.height_map, grid, fill_value=NINF, mode=mode)
+  mask = utils.image_sample(source.mask, grid, fill_value=False, mode=mode)
+  topdown = height_map
+  if not source.is_height_map:
+    topdown = utils.image_sample(source.topdown_map, grid,
+                                 fill_value=get(fill_value, proj.fill_value), mode=mode)
+  cy = center[..., 1]
+  if proj.flip_h:
+    cy = (proj.map_height - 1) - cy
+  new_proj = proj.clone(width_offset=woff + crop_width / 2 - center[..., 0],
+                        height_offset=hoff + crop_height / 2 - cy,
+                        map_width=crop_width, map_height=crop_height)
+  return TopdownMap(topdown_map=topdown, mask=mask, height_map=height_map,
+                    is_height_map=source.is_height_map, map_projector=new_proj)
+
+
+def fuse_topdown_maps(*maps: TopdownMap, map_projector: Optional[MapProjector] = None,
+                      fill_value: Optional[float] = None,
+                      reduction: Optional[Reduction] = None) -> TopdownMap:
+  raise NotImplementedError("fuse_topdown_maps lands with dm_fuse (next row)")
+
+
+class MapBuilder:
+  """Stateful world-map builder (reference maps.py:2289-2550)."""
+
+  def __init__(self, map_projector: MapProjector, world_map: Optional[TopdownMap] = None):
+    self._proj = map_projector
+    self._world_map = world_map or TopdownMap(map_projector=map_projector.clone())
+
+  proj = property(lambda self: self._proj)
+  world_map = property(lambda self: self._world_map)
+
+  def reset(self, depth_map=None, value_map=None, valid_map=None, cam_pose=None,
+            center_mode: CenterMode = CenterMode.none, **kwargs):
+    """Drop the world map; optionally start a new one from a first frame."""
+    self._world_map = TopdownMap(map_projector=self.proj.clone())
+    if depth_map is None:
+      return None
+    return self.step(depth_map=depth_map, value_map=value_map, valid_map=valid_map,
+                     cam_pose=cam_pose, center_mode=center_mode, **kwargs)
+
+  def step(self, depth_map, value_map=None, valid_map=None, cam_pose=None,
+           center_mode: CenterMode = CenterMode.none, merge: bool = True,
+           keep_pose: bool = False, **kwargs: Dict[str, Any]) -> TopdownMap:
+    """Project a frame and (optionally) merge it into the world map."""
+    local = self.plot(depth_map=depth_map, value_map=value_map, valid_map=valid_map,
+                      cam_pose=cam_pose, center_mode=center_mode, **kwargs)
+    if merge:
+      self.merge(local, keep_pose=keep_pose)
+    return local
+
+  def plot(self, depth_map, value_map=None, valid_map=None, cam_pose=None,
+           center_mode: CenterMode = CenterMode.none, **kwargs: Dict[str, Any]) -> TopdownMap:
+    """Project a frame to a TopdownMap; ``kwargs`` override the projector's
+    orth_project defaults and are recorded in the returned map's projector."""
+    cam_pose = get(cam_pose, self.proj.cam_pose, np.zeros(3, dtype=np.float32))
+    woff, hoff = self._compute_offsets(cam_pose=cam_pose, center_mode=center_mode, **kwargs)
+    kwargs["width_offset"], kwargs["height_offset"] = woff, hoff
+    kwargs.pop("get_height_map", None)
+    topdown, mask, height = self.proj.orth_project(
+        depth_map=depth_map, value_map=value_map, valid_map=valid_map, cam_pose=cam_pose,
+        get_height_map=True, **kwargs)
+    return TopdownMap(topdown_map=topdown, mask=mask, height_map=height,
+                      map_projector=self.proj.clone(cam_pose=cam_pose, **kwargs),
+                      is_height_map=value_map is None)
+
+  def merge(self, topdown_map: TopdownMap, keep_pose: bool = False,
+            fill_value: Optional[float] = None,
+            reduction: Optional[Reduction] = None) -> TopdownMap:
+    """Fuse ``topdown_map`` into the world map."""
+    if self._world_map is None:
+      self._world_map = TopdownMap(map_projector=self.proj.clone())
+    pose = (self._world_map if keep_pose else topdown_map).proj.cam_pose
+    self._world_map = fuse_topdown_maps(
+        self._world_map, topdown_map, map_projector=self.proj.clone(cam_pose=pose),
+        fill_value=fill_value, reduction=reduction)
+    return self._world_map
+
+  def _compute_offsets(self, cam_pose, width_offset=None, height_offset=None, map_res=None,
+                       map_width=None, map_height=None, to_global=None, center_mode=None,
+                       **_unused):
+    return self.proj.compute_center_offsets(
+        cam_pose=cam_pose, width_offset=width_offset, height_offset=height_offset,
+        map_res=map_res, map_width=map_width, map_height=map_height, to_global=to_global,
+        center_mode=center_mode)

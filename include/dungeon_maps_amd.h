@@ -1,0 +1,145 @@
+/*
+ * dungeon_maps_amd.h -- C ABI of the MI355X-native depth -> top-down projector.
+ *
+ * The reference (Ending2015a/dungeon_maps) has no FFI of its own: its hot path
+ * is the Python function dungeon_maps.maps.orth_project and the torch_scatter
+ * call underneath it.  This header is the boundary a binding for that path
+ * binds; each entry point cites the reference interface it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer named *_dev is DEVICE memory
+ *    (hipMalloc / PyTorch caching allocator), contiguous, float32 unless said
+ *    otherwise.  The library never allocates or frees device memory: scratch is
+ *    a caller-provided workspace (size from dm_*_workspace_bytes).
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
+ *    the default stream).  No host synchronisation inside; safe to capture in
+ *    a hipGraph.
+ *  - return 0 on success, a negative dm_status otherwise; dm_last_error()
+ *    returns a thread-local message.  No exceptions cross the ABI.
+ *  - re-entrant; no global state besides the thread-local error string.
+ */
+#ifndef DUNGEON_MAPS_AMD_H
+#define DUNGEON_MAPS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM_ABI_VERSION 1
+
+typedef enum dm_status {
+  DM_OK = 0,
+  DM_ERR_INVALID_ARGUMENT = -1,
+  DM_ERR_UNSUPPORTED = -2,
+  DM_ERR_WORKSPACE_TOO_SMALL = -3,
+  DM_ERR_LAUNCH = -4
+} dm_status;
+
+/* utils.Reduction (dungeon_maps/utils.py:52-76) */
+typedef enum dm_reduction {
+  DM_REDUCE_MAX = 0,
+  DM_REDUCE_MIN = 1,
+  DM_REDUCE_SUM = 2,
+  DM_REDUCE_MEAN = 3,
+  DM_REDUCE_PROD = 4
+} dm_reduction;
+
+/*
+ * Per-frame camera state, one 128-byte record per frame b (device table).
+ * Built on the host with the reference's float32 op order so that no device
+ * sin/cos is involved:
+ *   Rp  = rotate([1,0,0], cam_pitch[b])   utils.py:303-327 via maps.py:790
+ *   Ry  = rotate([0,1,0], cam_pose[b,2])  utils.py:303-327 via maps.py:884-885
+ * R is stored row-major exactly as utils.py:326-327 builds it; a point is
+ * transformed as out_i = sum_j R[3*j+i] * p_j (utils.py:329).
+ */
+typedef struct dm_frame {
+  float Rp[9];
+  float cam_height;      /* maps.py:791-797 */
+  float Ry[9];
+  float tx, tz;          /* cam_pose[b,0], cam_pose[b,1]  (maps.py:887-892) */
+  float width_offset;    /* maps.py:1004 */
+  float height_offset;   /* maps.py:1005 */
+  float reserved[9];
+} dm_frame;
+
+/*
+ * Call-wide parameters of orth_project (maps.py:127-153).
+ *   depth   (B, dc, H, W)      value (B, vc, H, W) or NULL (vc = 0: project
+ *   heights, maps.py:311-313)  valid (B, valid_c, H, W) uint8/bool or NULL
+ * dc == 1 broadcasts the cell index over the vc value channels (torch_scatter
+ * index broadcast, utils.py:475-477); otherwise dc must equal vc.
+ */
+typedef struct dm_params {
+  int32_t B, dc, vc, H, W;
+  int32_t mh, mw;            /* map_height, map_width */
+  int32_t clip_border;       /* <=0: off            maps.py:273-277 */
+  int32_t flip_h;            /* maps.py:670-671, 1006-1009 */
+  int32_t to_global;         /* maps.py:290-295 */
+  int32_t reduction;         /* dm_reduction        utils.py:470-477 */
+  int32_t has_dmin, has_dmax, has_hmax;  /* trunc_* is not None */
+  int32_t valid_c;           /* 0 (no valid map), 1 or dc */
+  float cx, cy, fx, fy;      /* utils.py:94-116 cast to f32 (maps.py:672-675) */
+  float res;                 /* map_res */
+  float fill;                /* fill_value; None => 0 (zeros canvas, maps.py:320) */
+  float dmin, dmax, hmax;    /* maps.py:537-544, 286-288 */
+} dm_params;
+
+int dm_version(void);
+const char* dm_last_error(void);
+
+/* Scratch bytes dm_orth_project_f32 / dm_orth_project_fused_f32 need for `p`. */
+size_t dm_orth_project_workspace_bytes(const dm_params* p);
+
+/*
+ * Replaces orth_project (maps.py:127-351): depth_map_to_point_cloud (462-545),
+ * _mask_borders (48-70), camera_to_local_space (753-800), height truncation
+ * (286-288), local_to_global_space (850-895), map_quantize (944-1019),
+ * project (1089-1173) and utils.scatter_tensor incl. the torch_scatter call
+ * (utils.py:389-492), fused.
+ *   out_dev    (B, oc, mh, mw) f32, oc = vc ? vc : dc      -- topdown_map
+ *   mask_dev   (B, oc, mh, mw) u8 (0/1)                    -- masks
+ *   height_dev (B, dc, mh, mw) f32 or NULL: the second, NINF/max projection
+ *              of maps.py:332-350 (only meaningful when vc > 0; with vc == 0
+ *              the height map IS out, maps.py:333-334)
+ * Outputs are fully written (no pre-initialisation needed).
+ */
+int dm_orth_project_f32(const dm_params* p, const dm_frame* frames_dev,
+                        const float* depth_dev, const float* value_dev,
+                        const uint8_t* valid_dev, float* out_dev,
+                        uint8_t* mask_dev, float* height_dev,
+                        void* workspace_dev, size_t workspace_bytes,
+                        void* stream);
+
+/*
+ * Batch-fused projection: all B frames are reduced (max or min only) into ONE
+ * (oc, mh, mw) map in the shared global frame -- the per-rank partial of the
+ * "projected+fused" metric.  Equals the reference's MapBuilder.merge /
+ * fuse_topdown_maps (maps.py:2181-2287, 2471-2508) for maps that share
+ * res/offsets/size, which is an element-wise max.
+ *   out_dev (oc, mh, mw) f32, mask_dev (oc, mh, mw) u8
+ * If `accumulate` is non-zero, out_dev's current content takes part in the
+ * reduction (running world map); otherwise it starts from p->fill.
+ */
+int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames_dev,
+                              const float* depth_dev, const float* value_dev,
+                              const uint8_t* valid_dev, float* out_dev,
+                              uint8_t* mask_dev, int accumulate,
+                              void* workspace_dev, size_t workspace_bytes,
+                              void* stream);
+
+/*
+ * mask = (map - fill != 0) with NaN -> 0: utils.py:489-491 as a function of
+ * the finished map (used after the cross-rank max all-reduce).  n elements.
+ */
+int dm_mask_from_map_f32(const float* map_dev, float fill, uint8_t* mask_dev,
+                         size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUNGEON_MAPS_AMD_H */

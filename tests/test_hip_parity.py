@@ -1,0 +1,227 @@
+"""GPU parity: the HIP path (through the public API -> ctypes -> C ABI) against
+(a) the reference-generated golden fixtures and (b) the CPU oracle on seeded
+synthetic inputs.
+
+Bar (north_star): integer cell indices bit-exact -- checked through the masks
+and through exact equality of max/min maps; float heights within 1e-5 (they
+are in fact bit-equal); order-dependent sum/mean/prod within rtol 1e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, project_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dmap():
+  import dungeon_maps_amd as dmap
+  from dungeon_maps_amd import _native
+  _native.lib()  # the HIP library must be the thing under test
+  assert torch.cuda.is_available()
+  return dmap
+
+
+def _run(dmap, cfg, depth, value=None, valid=None, get_height_map=False, **call):
+  proj = dmap.MapProjector(**cfg)
+  dev = torch.device("cuda:0")
+  outs = proj.orth_project(
+      torch.from_numpy(depth).to(dev),
+      value_map=None if value is None else torch.from_numpy(value).to(dev),
+      valid_map=None if valid is None else torch.from_numpy(valid).to(dev),
+      get_height_map=get_height_map, **call)
+  torch.cuda.synchronize()
+  return [o.cpu().numpy() for o in outs]
+
+
+def _proj_cfg(cfg):
+  c = dict(cfg)
+  return c
+
+
+@pytest.mark.parametrize("name,height", [
+    ("g1_height_320x240_256", True),
+    ("g2_local_noflip_clip_64x48", False),
+    ("g6a_edge_depth_notrunc", True),
+    ("g6b_edge_depth_trunc", True),
+    ("g6c_fill_none", False),
+])
+def test_golden_height_maps(dmap, name, height):
+  g, cfg = load_golden(name)
+  outs = _run(dmap, _proj_cfg(cfg), g["depth"], get_height_map=height)
+  np.testing.assert_array_equal(outs[1], g["mask"])
+  np.testing.assert_array_equal(outs[0], g["topdown"])
+  if height:
+    np.testing.assert_array_equal(outs[2], g["height"])
+
+
+@pytest.mark.parametrize("name", ["g3_semantic_onehot5_64x48", "g3b_semantic_validmap_64x48"])
+def test_golden_semantic(dmap, name):
+  g, cfg = load_golden(name)
+  outs = _run(dmap, _proj_cfg(cfg), g["depth"], value=g["value"], valid=g.get("valid_map"),
+              get_height_map=True)
+  np.testing.assert_array_equal(outs[1], g["mask"])
+  np.testing.assert_array_equal(outs[0], g["topdown"])
+  np.testing.assert_array_equal(outs[2], g["height"])
+
+
+def test_golden_batched(dmap):
+  g, cfg = load_golden("g4_batched4_64x48")
+  outs = _run(dmap, _proj_cfg(cfg), g["depth"], get_height_map=True,
+              cam_pose=g["cam_pose"], cam_pitch=g["cam_pitch"], cam_height=g["cam_height"],
+              width_offset=g["width_offset"], height_offset=g["height_offset"])
+  np.testing.assert_array_equal(outs[1], g["mask"])
+  np.testing.assert_array_equal(outs[0], g["topdown"])
+  assert outs[2] is not None
+
+
+def test_golden_reductions(dmap):
+  g, cfg = load_golden("g7_reductions_64x48")
+  for red, fill in (("min", np.inf), ("min", 0.0), ("sum", 0.0), ("sum", 1.0),
+                    ("mean", 0.0), ("mean", 2.0), ("prod", 1.0), ("max", 0.0),
+                    ("max", 1.0)):
+    c = dict(cfg, fill_value=fill, reduction=red)
+    tag = f"{red}_fill{fill}"
+    for prefix, value in (("", g["value"]), ("height_", None)):
+      outs = _run(dmap, c, g["depth"], value=value)
+      want = g[f"{prefix}topdown_{tag}"]
+      if red in ("max", "min"):
+        np.testing.assert_array_equal(outs[0], want)
+        np.testing.assert_array_equal(outs[1], g[f"{prefix}mask_{tag}"])
+      else:
+        np.testing.assert_allclose(outs[0], want, rtol=1e-5, atol=1e-6)
+        assert (outs[1] != g[f"{prefix}mask_{tag}"]).mean() < 1e-3
+
+
+# --------------------------------------------------------------------------
+# seeded synthetic inputs vs the oracle
+# --------------------------------------------------------------------------
+def _synthetic(B, H, W, seed, scene=False):
+  g = torch.Generator().manual_seed(seed)
+  depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g)
+  pose = torch.empty(B, 3).uniform_(-1, 1, generator=g)
+  pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)
+  return depth.numpy(), pose.numpy()
+
+
+def _oracle_kwargs(oracle, cfg):
+  return project_kwargs(cfg, oracle.camera_intrinsics)
+
+
+@pytest.mark.parametrize("B,H,W,mh,mw", [
+    (3, 48, 64, 64, 64),
+    (2, 51, 67, 33, 95),       # ragged: nothing divisible by 4
+    (1, 240, 320, 256, 256),   # BASELINE configs[0]
+    (4, 480, 640, 512, 512),   # BASELINE configs[1] geometry, small batch
+])
+def test_random_depth_vs_oracle(dmap, oracle, B, H, W, mh, mw):
+  depth, pose = _synthetic(B, H, W, seed=1234 + B)
+  cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+             cam_height=0.88, width_offset=mw / 2., height_offset=mh / 2., map_res=0.03,
+             map_width=mw, map_height=mh, trunc_depth_min=0.15, trunc_depth_max=5.05,
+             to_global=True, fill_value=-np.inf)
+  outs = _run(dmap, cfg, depth, cam_pose=pose)
+  want = oracle.orth_project(depth, **dict(_oracle_kwargs(oracle, cfg), cam_pose=pose),
+                             nthreads=8)
+  np.testing.assert_array_equal(outs[1], want[1])
+  np.testing.assert_array_equal(outs[0], want[0])
+
+
+def test_semantic_40_classes_vs_oracle(dmap, oracle):
+  """BASELINE configs[2] geometry at a small batch: 40-class one-hot, fill 0."""
+  B, H, W, C = 2, 120, 160, 40
+  depth, pose = _synthetic(B, H, W, seed=99)
+  g = torch.Generator().manual_seed(5)
+  labels = torch.randint(0, C, (B, H, W), generator=g)
+  value = torch.nn.functional.one_hot(labels, C).permute(0, 3, 1, 2).float().contiguous().numpy()
+  cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+             cam_height=0.88, width_offset=64., height_offset=64., map_res=0.06,
+             map_width=128, map_height=128, trunc_depth_min=0.15, trunc_depth_max=5.05,
+             to_global=True, fill_value=0.0)
+  outs = _run(dmap, cfg, depth, value=value, get_height_map=True, cam_pose=pose)
+  want = oracle.orth_project(depth, value_map=value, get_height_map=True,
+                             **dict(_oracle_kwargs(oracle, cfg), cam_pose=pose))
+  np.testing.assert_array_equal(outs[1], want[1])
+  np.testing.assert_array_equal(outs[0], want[0])
+  np.testing.assert_array_equal(outs[2], np.ascontiguousarray(want[2]))
+
+
+def test_empty_and_degenerate_inputs(dmap, oracle):
+  cfg = dict(width=8, height=4, hfov=np.radians(70.), cam_pitch=0.0, cam_height=1.0,
+             width_offset=4., height_offset=4., map_res=0.5, map_width=8, map_height=8,
+             to_global=False, fill_value=-np.inf)
+  # all pixels invalid: map stays at fill, mask all False
+  depth = np.full((1, 1, 4, 8), np.nan, dtype=np.float32)
+  top, mask = _run(dmap, cfg, depth)
+  assert not mask.any() and np.isneginf(top).all()
+  # 2-D and 3-D inputs are promoted like the reference's to_4D_image
+  d2 = np.full((4, 8), 2.0, dtype=np.float32)
+  top2, mask2 = _run(dmap, cfg, d2)
+  assert top2.shape == (1, 1, 8, 8)
+  want = oracle.orth_project(d2, **_oracle_kwargs(oracle, cfg))
+  np.testing.assert_array_equal(top2, want[0])
+  np.testing.assert_array_equal(mask2, want[1])
+
+
+def test_cpu_tensors_round_trip_through_gpu(dmap, oracle):
+  depth, pose = _synthetic(1, 48, 64, seed=3)
+  cfg = dict(width=64, height=48, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+             cam_height=0.88, width_offset=32., height_offset=32., map_res=0.1,
+             map_width=64, map_height=64, to_global=True, fill_value=-np.inf)
+  proj = dmap.MapProjector(**cfg)
+  top, mask = proj.orth_project(depth, cam_pose=pose)     # numpy in
+  assert top.device.type == "cpu" and mask.dtype == torch.bool
+  want = oracle.orth_project(depth, **dict(_oracle_kwargs(oracle, cfg), cam_pose=pose))
+  np.testing.assert_array_equal(top.numpy(), want[0])
+
+
+def test_fused_equals_max_over_frames(dmap, oracle):
+  B, H, W = 6, 96, 128
+  depth, pose = _synthetic(B, H, W, seed=77)
+  cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+             cam_height=0.88, width_offset=128., height_offset=128., map_res=0.05,
+             map_width=256, map_height=256, trunc_depth_min=0.15, trunc_depth_max=5.05,
+             to_global=True, fill_value=-np.inf)
+  proj = dmap.MapProjector(**cfg)
+  d = torch.from_numpy(depth).cuda()
+  fused, fmask = proj.orth_project_fused(d, cam_pose=pose)
+  per_frame, pmask = proj.orth_project(d, cam_pose=pose)
+  torch.cuda.synchronize()
+  assert torch.equal(fused, per_frame.amax(dim=0))
+  assert torch.equal(fmask, pmask.any(dim=0))
+  want = oracle.orth_project(depth, fused=True,
+                             **dict(_oracle_kwargs(oracle, cfg), cam_pose=pose))
+  np.testing.assert_array_equal(fused.cpu().numpy(), want[0])
+  np.testing.assert_array_equal(fmask.cpu().numpy(), want[1])
+  # running world map: fusing two halves one after the other == fusing all
+  acc, _ = proj.orth_project_fused(d[:3], cam_pose=pose[:3])
+  acc, amask = proj.orth_project_fused(d[3:], cam_pose=pose[3:], out=acc)
+  assert torch.equal(acc, fused) and torch.equal(amask, fmask)
+  assert torch.equal(dmap.mask_from_map(fused, -np.inf), fmask)
+
+
+def test_full_size_properties(dmap):
+  """BASELINE configs[1] at full size (B=64, 640x480 -> 512x512): properties
+  that do not need the oracle -- permutation invariance of the frame order,
+  B-stack == loop of B=1, mask == f(map, fill), determinism."""
+  B, H, W = 64, 480, 640
+  depth, pose = _synthetic(B, H, W, seed=1234)
+  proj = dmap.MapProjector(
+      width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
+      width_offset=256., height_offset=256., map_res=0.03, map_width=512, map_height=512,
+      trunc_depth_min=0.15, trunc_depth_max=5.05, to_global=True, fill_value=-np.inf)
+  d = torch.from_numpy(depth).cuda()
+  p = torch.from_numpy(pose)
+  top, mask = proj.orth_project(d, cam_pose=p)
+  top2, mask2 = proj.orth_project(d, cam_pose=p)
+  assert torch.equal(top, top2) and torch.equal(mask, mask2)          # deterministic
+  perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
+  topp, maskp = proj.orth_project(d[perm.cuda()], cam_pose=p[perm])
+  assert torch.equal(topp, top[perm.cuda()]) and torch.equal(maskp, mask[perm.cuda()])
+  for b in (0, 17, 63):
+    t1, m1 = proj.orth_project(d[b:b + 1], cam_pose=p[b:b + 1])
+    assert torch.equal(t1[0], top[b]) and torch.equal(m1[0], mask[b])
+  assert torch.equal(mask, torch.isfinite(top))                        # F9
+  assert mask.any(dim=-1).any(dim=-1).all()                            # every frame hit

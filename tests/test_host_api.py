@@ -1,0 +1,102 @@
+"""Host-side logic of the drop-in API on CPU: projector defaults/clone,
+Rodrigues matrices and intrinsics against the reference-generated fixture,
+frame-table packing, coordinate queries (golden g9), enums."""
+import numpy as np
+import pytest
+import torch
+
+import dungeon_maps_amd as dmap
+from dungeon_maps_amd import frames, utils
+from conftest import load_golden
+
+
+def test_enums_and_known_answers():
+  g, _ = load_golden("g10_known_answers")
+  assert dmap.Reduction(None) is dmap.Reduction.max
+  assert dmap.CenterMode(None) is dmap.CenterMode.none
+  got = utils.ravel_index(torch.from_numpy(g["ravel_in"]), (6, 5, 4))
+  assert got.tolist() == g["ravel_out"].tolist() == [71, 9]
+  assert dmap.get(None, None, 3, 4) == 3 and dmap.get(None, None) is None
+
+
+def test_rotation_matrices_match_reference():
+  g, _ = load_golden("g10_known_answers")
+  ang = torch.from_numpy(g["angles"])
+  Rx = utils.rotation_matrix([1., 0., 0.], ang).numpy()
+  Ry = utils.rotation_matrix([0., 1., 0.], ang).numpy()
+  np.testing.assert_array_equal(Rx, g["Rx"])
+  np.testing.assert_array_equal(Ry, g["Ry"])
+  # rotate() applies out_i = sum_j R[j,i] p_j
+  eye = torch.eye(3).view(1, 3, 3).expand(len(ang), 3, 3)
+  np.testing.assert_array_equal(utils.rotate(eye, [1., 0., 0.], ang).numpy(), g["Rx"])
+
+
+def test_intrinsics_match_reference():
+  g, _ = load_golden("g10_known_answers")
+  for w, h, hf, vf, cx, cy, fx, fy in g["intrinsics"]:
+    ci = utils.get_camera_intrinsics(int(w), int(h), np.radians(hf),
+                                     None if vf < 0 else np.radians(vf))
+    assert (ci.cx, ci.cy, ci.fx, ci.fy) == (cx, cy, fx, fy)
+
+
+def test_frame_table_layout_and_broadcast():
+  pose = np.array([[0.1, 0.2, 0.3], [0.4, 0.5, -0.6]], dtype=np.float32)
+  t = frames.build_frame_table(2, pose, -0.35, [0.8, 0.9], 10.0, [1.0, 2.0])
+  assert t.shape == (2, 32) and t.dtype == torch.float32
+  Rp = utils.rotation_matrix([1., 0., 0.], torch.tensor([-0.35])).reshape(9)
+  assert torch.equal(t[0, 0:9], Rp) and torch.equal(t[1, 0:9], Rp)
+  assert t[:, 9].tolist() == pytest.approx([0.8, 0.9])
+  Ry = utils.rotation_matrix([0., 1., 0.], torch.tensor([0.3, -0.6])).reshape(2, 9)
+  assert torch.equal(t[:, 10:19], Ry)
+  assert torch.equal(t[:, 19:21], torch.from_numpy(pose[:, :2]))
+  assert t[:, 21].tolist() == [10.0, 10.0] and t[:, 22].tolist() == [1.0, 2.0]
+  assert (t[:, 23:] == 0).all()
+  with pytest.raises(ValueError):
+    frames.build_frame_table(3, pose, 0., 0., 0., 0.)
+
+
+def test_projector_defaults_clone_and_forwarding():
+  p = dmap.MapProjector(width=64, height=48, hfov=1.2)
+  assert p.fill_value == dmap.NINF and p.flip_h is True and p.to_global is False
+  q = p.clone(map_res=0.05, map_width=10, map_height=12, to_global=True)
+  assert (q.map_res, q.map_width, q.map_height, q.to_global) == (0.05, 10, 12, True)
+  assert q.width == 64 and q.cam_params == p.cam_params
+  with pytest.raises(TypeError):
+    p.clone(focal_x=1.0)
+  q = q.clone(width_offset=5., height_offset=6.)
+  col, row = q.map_quantize([0.1, 0.2], [0.3, 0.4])
+  assert col.tolist() == [[7, 9]] and row.tolist() == [[-1, -3]]
+  x, z = q.map_dequantize(col, row)
+  np.testing.assert_allclose(x.numpy(), [[0.1, 0.2]], atol=0.025)
+
+
+def test_coordinate_queries_match_reference():
+  g, cfg = load_golden("g9_topdownmap_queries")
+  proj = dmap.MapProjector(**cfg)
+  pose = np.array(cfg["cam_pose"], dtype=np.float32)
+  build = dmap.MapBuilder(proj)
+  pts = torch.tensor([[0.5, 0.0, 1.0], [-1.2, 0.3, 2.2], [0.0, 0.0, 0.0]])
+  cds = torch.tensor([[0, 0], [10, 20], [63, 63]], dtype=torch.int64)
+  for mode in ("none", "origin", "camera"):
+    woff, hoff = build._compute_offsets(cam_pose=pose, center_mode=mode)
+    np.testing.assert_array_equal(np.asarray(woff, dtype=np.float32).reshape(-1),
+                                  g[f"{mode}_woff"].reshape(-1))
+    np.testing.assert_array_equal(np.asarray(hoff, dtype=np.float32).reshape(-1),
+                                  g[f"{mode}_hoff"].reshape(-1))
+    tm = dmap.TopdownMap(map_projector=proj.clone(cam_pose=pose, width_offset=woff,
+                                                  height_offset=hoff))
+    np.testing.assert_array_equal(tm.get_camera().numpy(), g[f"{mode}_camera"])
+    np.testing.assert_array_equal(tm.get_origin().numpy(), g[f"{mode}_origin"])
+    np.testing.assert_array_equal(tm.get_coords(pts, True).numpy(), g[f"{mode}_coords_global"])
+    np.testing.assert_array_equal(tm.get_coords(pts, False).numpy(), g[f"{mode}_coords_local"])
+    np.testing.assert_array_equal(tm.get_points(cds).numpy(), g[f"{mode}_points"])
+
+
+def test_topdownmap_container_semantics():
+  a = torch.zeros(1, 1, 4, 4)
+  tm = dmap.TopdownMap(a, torch.ones_like(a, dtype=torch.bool), a)
+  assert tm.is_height_map and tm.height_map is a and tm.map is a and not tm.is_empty
+  b = torch.ones(1, 1, 4, 4)
+  tm = dmap.TopdownMap(a, None, b)
+  assert not tm.is_height_map and tm.height_map is b
+  assert dmap.TopdownMap().is_empty

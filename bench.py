@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: depth frames/s projected + fused on MI355X.
+
+One step = one pass of the hot path over one batch of synthetic frames per GPU:
+
+  1. orth_project  B=64 x (640x480) depth -> (64, 1, 512, 512) height maps+masks
+     (BASELINE.json configs[1]; the kernel sequence the roofline is quoted on)
+  2. fuse          per-rank partial global map = max over the rank's frames
+  3. all-reduce    element-wise max of the partial maps over RCCL (N > 1 only)
+  4. mask          of the fused map
+
+N ranks each process their own 64 frames (weak scaling); `value` is the
+whole-job rate = N*B*K / max-over-ranks elapsed.  Inputs are synthetic,
+seeded, and resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
+objects: "roofline" (HBM, algorithmic bytes of step 1 / its HIP-event time on
+the launch stream) and "cpu_baseline" (the oracle timed on this box's host
+cores on a bounded sample; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (B, H, W, mh, mw, value channels)
+    "cfg1": (1, 240, 320, 256, 256, 0),
+    "cfg2": (64, 480, 640, 512, 512, 0),
+    "cfg3": (64, 480, 640, 512, 512, 40),
+}
+
+
+def algorithmic_bytes(B, H, W, mh, mw, C):
+  """read every input once, write every output once."""
+  depth = B * H * W * 4
+  if C == 0:
+    return depth + B * mh * mw * (4 + 1)
+  return depth + B * C * H * W * 4 + B * C * mh * mw * (4 + 1) + B * mh * mw * 4
+
+
+def synthetic_inputs(B, H, W, C, seed, device, scene):
+  g = torch.Generator().manual_seed(seed)
+  if scene:
+    depth = scene_depth(B, H, W, g)
+  else:
+    depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g)
+  pose = torch.empty(B, 3).uniform_(-1, 1, generator=g)
+  pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)
+  value = None
+  if C:
+    labels = torch.randint(0, C, (B, H, W), generator=g)
+    value = torch.nn.functional.one_hot(labels, C).permute(0, 3, 1, 2).float().contiguous()
+  return depth, pose, value
+
+
+def scene_depth(B, H, W, g, hfov=np.radians(70.), pitch=np.radians(-20.), cam_h=0.88):
+  """Floor plane + box walls (SURVEY 8d 'scene-like' variant)."""
+  cx, cy = W / 2., H / 2.
+  fx = cx / np.tan(hfov / 2.)
+  r = torch.arange(H, dtype=torch.float64).view(1, H, 1)
+  yn = ((H - 1) - r - cy) / fx
+  ky = np.cos(pitch) * yn + np.sin(pitch)
+  floor = torch.where(ky < -1e-6, -cam_h / ky, torch.full_like(ky, 10.0)).expand(B, H, W)
+  walls = torch.empty(B, 1, 8).uniform_(1.5, 6.0, generator=g).double()
+  walls = walls.repeat_interleave(W // 8, dim=2).expand(B, H, W)
+  d = torch.minimum(floor, walls).clamp(0.1, 10.0)
+  return d.float().unsqueeze(1).contiguous()
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=200)
+  ap.add_argument("--warmup", type=int, default=20)
+  ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+  ap.add_argument("--depth", default="uniform", choices=["uniform", "scene"])
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--cpu-seconds", type=float, default=12.0)
+  args = ap.parse_args()
+
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+  torch.cuda.set_device(local_rank)
+  dev = torch.device("cuda", local_rank)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+  import dungeon_maps_amd as dmap
+  from dungeon_maps_amd import _native
+  _native.lib()   # the HIP library must be present: no fallback
+
+  B, H, W, mh, mw, C = WORKLOADS[args.workload]
+  fill = 0.0 if C else -np.inf
+  depth, pose, value = synthetic_inputs(B, H, W, C, 1234 + rank, dev, args.depth == "scene")
+  depth_d = depth.to(dev)
+  value_d = None if value is None else value.to(dev)
+  proj = dmap.MapProjector(
+      width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
+      width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
+      trunc_depth_min=0.15, trunc_depth_max=5.05, clip_border=0, to_global=True,
+      fill_value=fill, reduction="max")
+
+  ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+  ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+  def step(i=None):
+    if i is not None:
+      ev_a[i].record()
+    top, mask = proj.orth_project(depth_d, value_map=value_d, cam_pose=pose)
+    if i is not None:
+      ev_b[i].record()
+    fused = dmap.fuse_batch(top, "max")
+    if dist is not None:
+      dist.all_reduce(fused, op=dist.ReduceOp.MAX)
+    fmask = dmap.mask_from_map(fused, fill)
+    return top, mask, fused, fmask
+
+  def barrier():
+    if dist is not None:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    step()
+  barrier()
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    out = step(i)
+  torch.cuda.synchronize()
+  barrier()
+  elapsed = time.perf_counter() - t0
+  if dist is not None:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  proj_ms = np.array([a.elapsed_time(b) for a, b in zip(ev_a, ev_b)])
+  kernel_s = float(np.mean(proj_ms)) * 1e-3
+  alg = algorithmic_bytes(B, H, W, mh, mw, C)
+  achieved = alg / kernel_s / 1e9
+
+  result = {
+      "metric": "depth frames/sec projected+fused, B=64 640x480->512x512",
+      "value": world * B * args.steps / elapsed,
+      "unit": "frames/s",
+      "n_gpus": world,
+      "steps": args.steps,
+      "warmup": args.warmup,
+      "ms_per_step": elapsed / args.steps * 1e3,
+      "higher_is_better": True,
+      "scaling": "weak",
+      "vs_baseline": None,
+      "dtype": "f32",
+      "data": "synthetic",
+      "config": {
+          "workload": f"{args.workload}: B={B}/GPU, {W}x{H} depth -> {mw}x{mh} "
+                      f"{'height map' if not C else f'{C}-class object map + height map'}, "
+                      f"depth={args.depth}, project + fuse(max over frames)"
+                      f"{' + RCCL all-reduce(max)' if world > 1 else ''} + mask",
+          "frames_per_gpu": B, "global_frames": world * B,
+      },
+      "roofline": {
+          "bound": "hbm",
+          "achieved": achieved,
+          "peak": HBM_PEAK_GBS,
+          "unit": "GB/s",
+          "frac": achieved / HBM_PEAK_GBS,
+          "traffic": None,
+          "kernel": "orth_project launch sequence (dm_orth_project_f32)",
+          "algorithmic_bytes_per_launch": alg,
+          "launch_us": kernel_s * 1e6,
+          "launch_us_min": float(proj_ms.min()) * 1e3,
+      },
+  }
+
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    result["cpu_baseline"] = cpu_baseline(depth, pose, value, H, W, mh, mw, fill,
+                                          args.cpu_seconds, out)
+  if rank == 0:
+    print(json.dumps(result))
+  if dist is not None:
+    dist.destroy_process_group()
+
+
+def cpu_baseline(depth, pose, value, H, W, mh, mw, fill, budget_s, gpu_out):
+  """The CPU oracle (port of the reference's algorithm, oracle/dm_oracle.c,
+  OpenMP over frames) on a bounded sample of the same workload, on this box's
+  host cores; also used as a last check of the GPU result."""
+  from oracle import oracle
+  cores = min(oracle.max_threads(), os.cpu_count() or 1)
+  n = min(depth.shape[0], max(cores, 16))
+  d = depth[:n].numpy()
+  v = None if value is None else value[:n].numpy()
+  cx, cy, fx, fy = oracle.camera_intrinsics(W, H, np.radians(70.))
+  kw = dict(cam_pose=pose[:n].numpy(), width_offset=mw / 2., height_offset=mh / 2.,
+            cam_pitch=np.radians(-20.), cam_height=0.88, map_res=0.03, map_width=mw,
+            map_height=mh, focal_x=fx, focal_y=fy, center_x=cx, center_y=cy,
+            trunc_depth_min=0.15, trunc_depth_max=5.05, to_global=True, fill_value=fill,
+            nthreads=cores)
+  want = oracle.orth_project(d, value_map=v, **kw)     # warm-up + parity check
+  same = bool(np.array_equal(gpu_out[0][:n].cpu().numpy(), want[0])
+              and np.array_equal(gpu_out[1][:n].cpu().numpy(), want[1]))
+  times = []
+  t_end = time.perf_counter() + budget_s
+  while time.perf_counter() < t_end or len(times) < 3:
+    t0 = time.perf_counter()
+    oracle.orth_project(d, value_map=v, **kw)
+    times.append(time.perf_counter() - t0)
+  return {
+      "value": n / float(np.median(times)),
+      "unit": "frames/s",
+      "cores": cores,
+      "kind": "port",
+      "sample": f"{n} frames of the same workload, median of {len(times)} runs "
+                f"(~{sum(times):.0f} s), OpenMP over frames",
+      "gpu_matches_cpu_on_sample": same,
+  }
+
+
+if __name__ == "__main__":
+  main()

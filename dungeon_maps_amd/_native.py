@@ -43,6 +43,9 @@ _SIGNATURES = {
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "dm_fuse_batch_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_int, ctypes.c_void_p]),
     "dm_mask_from_map_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
         ctypes.c_void_p]),

@@ -96,6 +96,20 @@ int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames_dev,
   return DM_OK;
 }
 
+int dm_fuse_batch_f32(const float* maps_dev, int64_t B, size_t n, float* out_dev, int reduction,
+                      int accumulate, void* stream) {
+  if (reduction != DM_REDUCE_MAX && reduction != DM_REDUCE_MIN)
+    return fail(DM_ERR_UNSUPPORTED, "fuse supports max/min only (got %d)", reduction);
+  if (B < 0 || B > 0x7fffffff) return fail(DM_ERR_INVALID_ARGUMENT, "bad batch %lld", (long long)B);
+  if (n == 0 || (B == 0 && accumulate)) return DM_OK;
+  if (B == 0) return fail(DM_ERR_INVALID_ARGUMENT, "cannot fuse an empty batch without accumulate");
+  if (!maps_dev || !out_dev) return fail(DM_ERR_INVALID_ARGUMENT, "maps/out must not be NULL");
+  hipError_t e = dm::run_fuse_batch(maps_dev, (int)B, n, out_dev, reduction == DM_REDUCE_MAX,
+                                    accumulate, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
 int dm_mask_from_map_f32(const float* map_dev, float fill, uint8_t* mask_dev, size_t n,
                          void* stream) {
   if (n == 0) return DM_OK;

@@ -177,6 +177,57 @@ hipError_t run_generic_fused(const dm_params& p, const dm_frame* frames, const f
   return hipGetLastError();
 }
 
+// out[i] = max/min over b of maps[b][i]; 4 cells per thread, 16-byte accesses.
+template <bool IS_MAX>
+__global__ void __launch_bounds__(256)
+k_fuse_batch(const float* __restrict__ maps, int B, size_t n, size_t nvec,
+             float* __restrict__ out, int accumulate) {
+  const size_t n4 = nvec / 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 acc = reinterpret_cast<const float4*>(maps)[i];
+    if (accumulate) {
+      const float4 o = reinterpret_cast<const float4*>(out)[i];
+      acc.x = IS_MAX ? fmaxf(acc.x, o.x) : fminf(acc.x, o.x);
+      acc.y = IS_MAX ? fmaxf(acc.y, o.y) : fminf(acc.y, o.y);
+      acc.z = IS_MAX ? fmaxf(acc.z, o.z) : fminf(acc.z, o.z);
+      acc.w = IS_MAX ? fmaxf(acc.w, o.w) : fminf(acc.w, o.w);
+    }
+    for (int b = 1; b < B; ++b) {
+      const float4 v = reinterpret_cast<const float4*>(maps + (size_t)b * n)[i];
+      acc.x = IS_MAX ? fmaxf(acc.x, v.x) : fminf(acc.x, v.x);
+      acc.y = IS_MAX ? fmaxf(acc.y, v.y) : fminf(acc.y, v.y);
+      acc.z = IS_MAX ? fmaxf(acc.z, v.z) : fminf(acc.z, v.z);
+      acc.w = IS_MAX ? fmaxf(acc.w, v.w) : fminf(acc.w, v.w);
+    }
+    reinterpret_cast<float4*>(out)[i] = acc;
+  }
+  // scalar remainder (everything when rows are not 16-byte aligned)
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float acc = maps[i];
+    if (accumulate) acc = IS_MAX ? fmaxf(acc, out[i]) : fminf(acc, out[i]);
+    for (int b = 1; b < B; ++b)
+      acc = IS_MAX ? fmaxf(acc, maps[(size_t)b * n + i]) : fminf(acc, maps[(size_t)b * n + i]);
+    out[i] = acc;
+  }
+}
+
+hipError_t run_fuse_batch(const float* maps, int B, size_t n, float* out, bool is_max,
+                          int accumulate, hipStream_t s) {
+  // float4 path needs every row 16-byte aligned: n % 4 == 0 and aligned bases
+  const bool aligned = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(maps) |
+                                        reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+  const size_t nvec = aligned ? n : 0;
+  const int blocks = blocks_for(aligned ? n / 4 : n, 256, 8192);
+  if (is_max)
+    hipLaunchKernelGGL(k_fuse_batch<true>, dim3(blocks), dim3(256), 0, s, maps, B, n, nvec, out,
+                       accumulate);
+  else
+    hipLaunchKernelGGL(k_fuse_batch<false>, dim3(blocks), dim3(256), 0, s, maps, B, n, nvec, out,
+                       accumulate);
+  return hipGetLastError();
+}
+
 hipError_t run_mask_from_map(const float* map, float fill, uint8_t* mask, size_t n,
                              hipStream_t s) {
   hipLaunchKernelGGL(k_finalize, dim3(blocks_for(n, 1024, 4096)), dim3(256), 0, s,

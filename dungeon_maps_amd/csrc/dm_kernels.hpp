@@ -15,6 +15,8 @@ hipError_t run_generic(const dm_params& p, const dm_frame* frames, const float* 
 hipError_t run_generic_fused(const dm_params& p, const dm_frame* frames, const float* depth,
                              const float* value, const uint8_t* valid, float* out,
                              uint8_t* mask, int accumulate, hipStream_t s);
+hipError_t run_fuse_batch(const float* maps, int B, size_t n, float* out, bool is_max,
+                          int accumulate, hipStream_t s);
 hipError_t run_mask_from_map(const float* map, float fill, uint8_t* mask, size_t n,
                              hipStream_t s);
 

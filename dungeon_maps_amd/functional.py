@@ -20,7 +20,7 @@ from . import _native, frames, utils
 from .utils import NINF, Reduction
 
 __all__ = [
-    "CenterMode", "get", "orth_project", "orth_project_fused", "camera_affine_grid",
+    "CenterMode", "get", "orth_project", "orth_project_fused", "fuse_batch", "mask_from_map", "camera_affine_grid",
     "depth_map_to_point_cloud", "height_map_to_point_cloud", "image_to_camera_space",
     "camera_to_image_space", "camera_to_local_space", "local_to_camera_space",
     "local_to_global_space", "global_to_local_space", "map_quantize",
@@ -240,6 +240,30 @@ def orth_project_fused(
         _ptr(call.valid), _ptr(out), _ptr(mask), int(accumulate), _ptr(ws), ws_bytes,
         _stream_ptr(call.dev)))
   return out, mask
+
+
+def fuse_batch(maps: torch.Tensor, reduction=None, out: Optional[torch.Tensor] = None
+               ) -> torch.Tensor:
+  """Fuse maps (B, C, mh, mw) that share one frame into one (C, mh, mw) map:
+  element-wise max (or min) over the batch axis on the GPU (dm_fuse_batch_f32).
+  ``out``, if given, is a running world map whose content takes part."""
+  if maps.device.type != "cuda" or maps.dtype != torch.float32:
+    raise RuntimeError("fuse_batch expects a float32 GPU tensor")
+  maps = maps.contiguous()
+  shape = tuple(maps.shape[1:])
+  accumulate = out is not None
+  if accumulate:
+    if tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() \
+        or out.device != maps.device:
+      raise ValueError(f"`out` must be a contiguous float32 {shape} tensor on {maps.device}")
+  else:
+    out = torch.empty(shape, dtype=torch.float32, device=maps.device)
+  n = int(np.prod(shape)) if shape else 1
+  with torch.cuda.device(maps.device):
+    _native.check(_native.lib().dm_fuse_batch_f32(
+        _ptr(maps), maps.shape[0], n, _ptr(out), _reduction_code(reduction), int(accumulate),
+        _stream_ptr(maps.device)))
+  return out
 
 
 def mask_from_map(topdown: torch.Tensor, fill_value: Optional[float]) -> torch.Tensor:

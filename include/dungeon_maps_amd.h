@@ -133,6 +133,17 @@ int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames_dev,
                               void* stream);
 
 /*
+ * Fuse B maps that share one frame (same res/offsets/size) into one:
+ * out[i] = reduce_b maps[b, i], reduce = max or min.  This is what
+ * MapBuilder.merge -> fuse_topdown_maps (maps.py:2181-2287, 2471-2508) computes
+ * for such maps (element-wise max in a shared frame), applied
+ * across the batch axis.  maps_dev (B, n) f32, out_dev (n) f32; if
+ * `accumulate` is non-zero out_dev's current content takes part.
+ */
+int dm_fuse_batch_f32(const float* maps_dev, int64_t B, size_t n, float* out_dev,
+                      int reduction, int accumulate, void* stream);
+
+/*
  * mask = (map - fill != 0) with NaN -> 0: utils.py:489-491 as a function of
  * the finished map (used after the cross-rank max all-reduce).  n elements.
  */

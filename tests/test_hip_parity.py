@@ -200,6 +200,12 @@ def test_fused_equals_max_over_frames(dmap, oracle):
   acc, amask = proj.orth_project_fused(d[3:], cam_pose=pose[3:], out=acc)
   assert torch.equal(acc, fused) and torch.equal(amask, fmask)
   assert torch.equal(dmap.mask_from_map(fused, -np.inf), fmask)
+  # fuse of finished per-frame maps (dm_fuse_batch_f32), incl. odd sizes / running map
+  assert torch.equal(dmap.fuse_batch(per_frame, "max"), fused)
+  assert torch.equal(dmap.fuse_batch(per_frame[3:], "max", out=dmap.fuse_batch(per_frame[:3])),
+                     fused)
+  odd = torch.randn(5, 3, 7, 11, device="cuda")
+  assert torch.equal(dmap.fuse_batch(odd, "min"), odd.amin(dim=0))
 
 
 def test_full_size_properties(dmap):

@@ -43,6 +43,7 @@ _SIGNATURES = {
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "dm_debug_force_generic_path": (ctypes.c_int, [ctypes.c_int]),
     "dm_fuse_batch_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_int, ctypes.c_void_p]),

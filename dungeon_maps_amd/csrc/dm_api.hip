@@ -8,6 +8,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
+thread_local int g_force_generic = 0;   // dm_debug_force_generic_path (tests)
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -46,17 +47,22 @@ const char* dm_last_error(void) { return g_err; }
 
 size_t dm_orth_project_workspace_bytes(const dm_params* p) {
   if (check_params(p) != DM_OK) return 0;
-  return dm::generic_workspace_bytes(*p);
+  size_t n = dm::generic_workspace_bytes(*p);
+  if (dm::window_path_supported(*p)) {
+    const size_t w = dm::window_workspace_bytes(*p);
+    if (w > n) n = w;
+  }
+  return n;
 }
 
-int dm_orth_project_f32(const dm_params* p, const dm_frame* frames_dev, const float* depth_dev,
+int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float* depth_dev,
                         const float* value_dev, const uint8_t* valid_dev, float* out_dev,
                         uint8_t* mask_dev, float* height_dev, void* workspace_dev,
                         size_t workspace_bytes, void* stream) {
   int rc = check_params(p);
   if (rc != DM_OK) return rc;
   if (p->B == 0) return DM_OK;
-  if (!frames_dev || !depth_dev || !out_dev || !mask_dev)
+  if (!frames || !depth_dev || !out_dev || !mask_dev)
     return fail(DM_ERR_INVALID_ARGUMENT, "frames/depth/out/mask must not be NULL");
   if ((p->vc > 0) != (value_dev != nullptr))
     return fail(DM_ERR_INVALID_ARGUMENT, "value pointer and vc=%d disagree", p->vc);
@@ -66,34 +72,48 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames_dev, const fl
   if (need > workspace_bytes || (need && !workspace_dev))
     return fail(DM_ERR_WORKSPACE_TOO_SMALL, "workspace %zu B < required %zu B", workspace_bytes,
                 need);
-  hipError_t e = dm::run_generic(*p, frames_dev, depth_dev, value_dev, valid_dev, out_dev,
-                                 mask_dev, p->vc ? height_dev : nullptr, workspace_dev,
-                                 static_cast<hipStream_t>(stream));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipErrorNotSupported;
+  if (dm::window_path_supported(*p) && !g_force_generic)
+    e = dm::run_window(*p, frames, depth_dev, valid_dev, out_dev, mask_dev, workspace_dev, s);
+  if (e == hipErrorNotSupported)   // nothing enqueued: a window exceeds LDS, odd alignment, ...
+    e = dm::run_generic(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
+                        p->vc ? height_dev : nullptr, workspace_dev, s);
   if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
   return DM_OK;
 }
 
-int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames_dev,
+int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames,
                               const float* depth_dev, const float* value_dev,
                               const uint8_t* valid_dev, float* out_dev, uint8_t* mask_dev,
                               int accumulate, void* workspace_dev, size_t workspace_bytes,
                               void* stream) {
-  (void)workspace_dev; (void)workspace_bytes;
   int rc = check_params(p);
   if (rc != DM_OK) return rc;
   if (p->reduction != DM_REDUCE_MAX && p->reduction != DM_REDUCE_MIN)
     return fail(DM_ERR_UNSUPPORTED, "fused projection supports max/min only (got %d)",
                 p->reduction);
-  if (!out_dev || !mask_dev || (p->B > 0 && (!frames_dev || !depth_dev)))
+  if (!out_dev || !mask_dev || (p->B > 0 && (!frames || !depth_dev)))
     return fail(DM_ERR_INVALID_ARGUMENT, "frames/depth/out/mask must not be NULL");
+  const size_t need = dm::generic_workspace_bytes(*p);
+  if (need > workspace_bytes || !workspace_dev)
+    return fail(DM_ERR_WORKSPACE_TOO_SMALL, "workspace %zu B < required %zu B", workspace_bytes,
+                need);
   if ((p->vc > 0) != (value_dev != nullptr) && p->B > 0)
     return fail(DM_ERR_INVALID_ARGUMENT, "value pointer and vc=%d disagree", p->vc);
   if ((p->valid_c > 0) != (valid_dev != nullptr) && p->B > 0)
     return fail(DM_ERR_INVALID_ARGUMENT, "valid pointer and valid_c=%d disagree", p->valid_c);
-  hipError_t e = dm::run_generic_fused(*p, frames_dev, depth_dev, value_dev, valid_dev, out_dev,
-                                       mask_dev, accumulate, static_cast<hipStream_t>(stream));
+  hipError_t e = dm::run_generic_fused(*p, frames, depth_dev, value_dev, valid_dev, out_dev,
+                                       mask_dev, accumulate, workspace_dev,
+                                       static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
   return DM_OK;
+}
+
+int dm_debug_force_generic_path(int on) {
+  const int old = g_force_generic;
+  g_force_generic = on != 0;
+  return old;
 }
 
 int dm_fuse_batch_f32(const float* maps_dev, int64_t B, size_t n, float* out_dev, int reduction,

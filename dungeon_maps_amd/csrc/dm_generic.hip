@@ -129,20 +129,38 @@ static hipError_t launch_scatter(const dm_params& p, const View& v, dim3 grid,
   return hipGetLastError();
 }
 
-size_t generic_workspace_bytes(const dm_params& p) {
-  if (p.reduction != DM_REDUCE_MEAN) return 0;
-  const size_t oc = p.vc ? p.vc : p.dc;
-  return (size_t)p.B * oc * p.mh * p.mw * sizeof(float);
+static inline size_t frames_bytes(const dm_params& p) {
+  return ((size_t)p.B * sizeof(dm_frame) + 255) / 256 * 256;
 }
 
-hipError_t run_generic(const dm_params& p, const dm_frame* frames, const float* depth,
+// workspace: frame table | per-cell counts (mean only)
+size_t generic_workspace_bytes(const dm_params& p) {
+  size_t n = frames_bytes(p);
+  if (p.reduction == DM_REDUCE_MEAN) {
+    const size_t oc = p.vc ? p.vc : p.dc;
+    n += (size_t)p.B * oc * p.mh * p.mw * sizeof(float);
+  }
+  return n;
+}
+
+// pageable -> device: the bytes have left the host buffer when this returns
+static hipError_t upload_frames(const dm_params& p, const dm_frame* frames_host, void* ws,
+                                hipStream_t s) {
+  return hipMemcpyAsync(ws, frames_host, (size_t)p.B * sizeof(dm_frame), hipMemcpyHostToDevice, s);
+}
+
+hipError_t run_generic(const dm_params& p, const dm_frame* frames_host, const float* depth,
                        const float* value, const uint8_t* valid, float* out,
                        uint8_t* mask, float* height, void* ws, hipStream_t s) {
+  hipError_t ue = upload_frames(p, frames_host, ws, s);
+  if (ue != hipSuccess) return ue;
+  const dm_frame* frames = static_cast<const dm_frame*>(ws);
   const View v = make_view(p);
   const size_t M = (size_t)p.mh * p.mw, oc = p.vc ? p.vc : p.dc;
   const size_t n_out = (size_t)p.B * oc * M;
   const size_t n_h = height ? (size_t)p.B * p.dc * M : 0;
-  float* count = p.reduction == DM_REDUCE_MEAN ? static_cast<float*>(ws) : nullptr;
+  float* count = p.reduction == DM_REDUCE_MEAN
+      ? reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + frames_bytes(p)) : nullptr;
   hipLaunchKernelGGL(k_fill, dim3(blocks_for(n_out > n_h ? n_out : n_h, 1024, 4096)), dim3(256),
                      0, s, out, p.fill, n_out, height, -__builtin_inff(), n_h);
   if (count)
@@ -158,9 +176,12 @@ hipError_t run_generic(const dm_params& p, const dm_frame* frames, const float* 
   return hipGetLastError();
 }
 
-hipError_t run_generic_fused(const dm_params& p, const dm_frame* frames, const float* depth,
+hipError_t run_generic_fused(const dm_params& p, const dm_frame* frames_host, const float* depth,
                              const float* value, const uint8_t* valid, float* out,
-                             uint8_t* mask, int accumulate, hipStream_t s) {
+                             uint8_t* mask, int accumulate, void* ws, hipStream_t s) {
+  hipError_t ue = upload_frames(p, frames_host, ws, s);
+  if (ue != hipSuccess) return ue;
+  const dm_frame* frames = static_cast<const dm_frame*>(ws);
   const View v = make_view(p);
   const size_t M = (size_t)p.mh * p.mw, oc = p.vc ? p.vc : p.dc;
   const size_t n_out = oc * M;

@@ -112,6 +112,89 @@ __device__ inline bool border_ok(const View& v, int r, int q) {
 }
 
 // ---------------------------------------------------------------------------
+// Fast-path geometry (dm_window.hip).  Same results as project_pixel, fewer
+// instructions:
+//  * a/b with y = RN(1/b) precomputed on the host:  q0 = a*y,
+//    q = fma(fma(-b, q0, a), y, q0) is the correctly rounded IEEE quotient for
+//    1e-25 <= |a| <= 1e25 (Markstein; brute-forced by tools/check_fma_division.c).
+//  * the rotations built by rotate([1,0,0],.) / rotate([0,1,0],.) have exact
+//    0/1 entries; their zero terms do not change a finite FMA chain (x*0 = +-0,
+//    fma(a,b,+-0) = RN(a*b)), and a non-finite chain is non-finite either way
+//    and lands outside the map.  The host checks the pattern for every frame
+//    of the call (axis_aligned) and otherwise the full chain is used.
+struct FastView {
+  View v;
+  float res_inv, fx_inv, fy_inv;   // RN(1/res), RN(1/fx), RN(1/fy)
+};
+
+// Correctly rounded a / b from y = RN(1/b) (3 instructions, no branch).
+// Exact for 1e-25 <= |a| <= 1e25.  Outside that range the result can differ
+// from IEEE division, but never in a way the projector can see, PROVIDED
+// 1e-6 <= b <= 1e6 (checked on the host, else FAST_DIV is off): a huge |a|
+// gives a huge or non-finite quotient either way (outside every map); a tiny
+// |a| gives a quotient below 1e-19 either way, which vanishes when the offset
+// and the 0.5 are added; NaN/inf stay non-finite.
+__device__ inline float div_markstein(float a, float b, float y) {
+  const float q0 = a * y;
+  return __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
+}
+
+template <bool FAST_DIV>
+__device__ inline float div_f(float a, float b, float y) {
+  return FAST_DIV ? div_markstein(a, b, y) : a / b;
+}
+
+template <bool FAST_DIV>
+__device__ inline float fray_x(const FastView& fv, int q) {
+  return div_f<FAST_DIV>((float)q - fv.v.cx, fv.v.fx, fv.fx_inv);
+}
+template <bool FAST_DIV>
+__device__ inline float fray_y(const FastView& fv, int r) {
+  float yr = (float)r;
+  if (fv.v.flip_h) yr = fv.v.Hm1 - yr;
+  return div_f<FAST_DIV>(yr - fv.v.cy, fv.v.fy, fv.fy_inv);
+}
+
+// Floored cell coordinates (as floats) + height of one pixel.  `z` must
+// already be NaN for pixels rejected by the depth range / valid map / border
+// (NaN propagates to xf, zf); the height truncation is returned in `low`.
+template <bool AXIS_ALIGNED, bool FAST_DIV>
+__device__ inline void project_point(const FastView& fv, const Cam& c, float z, float ax,
+                                     float ay, float& xf, float& zf, float& y2, bool& low) {
+  const View& v = fv.v;
+  const float X = ax * z;
+  const float Y = ay * z;
+  float x1, y1, z1;
+  if (AXIS_ALIGNED) {
+    x1 = X;
+    y1 = __builtin_fmaf(z, c.p[7], Y * c.p[4]) + c.h;
+    z1 = __builtin_fmaf(z, c.p[8], Y * c.p[5]);
+  } else {
+    x1 = __builtin_fmaf(z, c.p[6], __builtin_fmaf(Y, c.p[3], X * c.p[0])) + 0.0f;
+    y1 = __builtin_fmaf(z, c.p[7], __builtin_fmaf(Y, c.p[4], X * c.p[1])) + c.h;
+    z1 = __builtin_fmaf(z, c.p[8], __builtin_fmaf(Y, c.p[5], X * c.p[2])) + 0.0f;
+  }
+  low = !v.has_hmax || (y1 <= v.hmax);
+  float x2 = x1, z2 = z1;
+  y2 = y1;
+  if (v.to_global) {
+    if (AXIS_ALIGNED) {
+      x2 = __builtin_fmaf(z1, c.y[6], x1 * c.y[0]) + c.tx;
+      z2 = __builtin_fmaf(z1, c.y[8], x1 * c.y[2]) + c.tz;
+    } else {
+      x2 = __builtin_fmaf(z1, c.y[6], __builtin_fmaf(y1, c.y[3], x1 * c.y[0])) + c.tx;
+      y2 = __builtin_fmaf(z1, c.y[7], __builtin_fmaf(y1, c.y[4], x1 * c.y[1])) + 0.0f;
+      z2 = __builtin_fmaf(z1, c.y[8], __builtin_fmaf(y1, c.y[5], x1 * c.y[2])) + c.tz;
+    }
+  }
+  xf = div_f<FAST_DIV>(x2, v.res, fv.res_inv) + c.wo;
+  zf = div_f<FAST_DIV>(z2, v.res, fv.res_inv) + c.ho;
+  if (v.flip_h) zf = v.mhm1 - zf;
+  xf = __builtin_floorf(xf + 0.5f);
+  zf = __builtin_floorf(zf + 0.5f);
+}
+
+// ---------------------------------------------------------------------------
 // order-preserving float <-> uint key: k(a) < k(b)  <=>  a < b (with -0 < +0)
 __device__ inline uint32_t f2key(float f) {
   uint32_t u = __float_as_uint(f);

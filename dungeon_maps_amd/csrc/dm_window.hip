@@ -1,0 +1,525 @@
+// LDS-windowed fast path of orth_project (max / min, one value per pixel).
+//
+// Why: the scatter has no locality the memory system can exploit -- global
+// atomics run at ~27 G/s on MI355X whatever their scope (profiles/r01_microbench.log),
+// LDS atomics at ~5300 G/s.  So every reduction happens in LDS and each output
+// byte is written exactly once, by plain coalesced stores.
+//
+//   k_window_scatter  one workgroup per (frame, channel, image part).  A part
+//       is a column strip (x row band) of the depth image.  The host bounds the
+//       part's footprint in the map -- the frustum slab of its pixel rectangle
+//       between trunc_depth_min and trunc_depth_max is a convex polytope whose
+//       extreme cells are reached at its 8 corners -- and the workgroup
+//       accumulates into an LDS image of exactly that window with ds_max_u32 on
+//       order-preserving keys, then flushes the window as a "slab" (plain
+//       16-byte stores; it stays in L2 / Infinity Cache for the next kernel).
+//   k_window_merge    one thread per 16 output cells: combines the <= P slabs
+//       covering them (windows of neighbouring strips overlap), writes the map
+//       and the mask once, 64 + 16 bytes per thread, fill value elsewhere.
+//
+// Everything a workgroup needs is wave-uniform (frame record, window) and read
+// through scalar loads; depth is read with 16-byte loads, one row segment per
+// group of lanes, several rows in flight per thread.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "dm_kernels.hpp"
+
+namespace dm {
+
+namespace {
+
+constexpr int kScatterThreads = 1024;
+constexpr int kRowsInFlight = 4;
+constexpr int kMaxLdsBytes = 160 * 1024;
+
+
+struct Parts {
+  int pc, pr;          // column strips x row bands
+  int wp, hp;          // part width (multiple of 4) / height in pixels
+};
+
+// Window of one part in map cells; w == 0: the part cannot hit the map.
+struct Window {
+  int x0, z0, w, h;
+};
+
+__host__ Parts choose_parts(const dm_params& p) {
+  // enough workgroups to fill 256 CUs, parts not smaller than 32 columns,
+  // strip boundaries on 128-byte lines (32 floats) when W allows it
+  const long frames = (long)p.B * p.dc;
+  int want = (int)((256 + frames - 1) / frames);
+  if (want < 1) want = 1;
+  Parts s;
+  s.pc = 1; s.pr = 1;
+  const int unit = (p.W % 32 == 0) ? 32 : 4;
+  const int units = (p.W + unit - 1) / unit;
+  int pc = want < units ? want : units;
+  if (pc > 16) pc = 16;
+  // prefer a divisor of the unit count (equal strips)
+  while (pc > 1 && units % pc != 0) --pc;
+  s.pc = pc;
+  s.wp = ((units + pc - 1) / pc) * unit;
+  int pr = (want + pc - 1) / pc;
+  if (pr > 8) pr = 8;
+  if (pr > p.H / 16) pr = p.H / 16 > 0 ? p.H / 16 : 1;
+  s.pr = pr;
+  s.hp = (p.H + pr - 1) / pr;
+  return s;
+}
+
+// y = RN(1/b) in float32, exactly: pick the neighbour minimising |b*y - 1|
+// (b*y is exact in double).
+__host__ bool exact_reciprocal(float b, float* y_out) {
+  if (!(b > 0.0f) || !isfinite(b)) return false;
+  float y = (float)(1.0 / (double)b);
+  if (!isfinite(y) || y < 1e-30f || y > 1e30f) return false;
+  // the Markstein step needs b's reciprocal rounded to nearest
+  float best = y;
+  double err = fabs(fma((double)b, (double)y, -1.0));
+  const float cand[2] = {nextafterf(y, 0.0f), nextafterf(y, INFINITY)};
+  for (float c : cand) {
+    const double e = fabs(fma((double)b, (double)c, -1.0));
+    if (e < err) { err = e; best = c; }
+  }
+  *y_out = best;
+  return true;
+}
+
+__host__ bool axis_aligned(const dm_frame* f, int B) {
+  for (int b = 0; b < B; ++b) {
+    const float* p = f[b].Rp; const float* y = f[b].Ry;
+    if (!(p[0] == 1.0f && p[1] == 0.0f && p[2] == 0.0f && p[3] == 0.0f && p[6] == 0.0f))
+      return false;
+    if (!(y[1] == 0.0f && y[3] == 0.0f && y[4] == 1.0f && y[5] == 0.0f && y[7] == 0.0f))
+      return false;
+  }
+  return true;
+}
+
+// Footprint of the pixel rectangle [q0,q1) x [r0,r1) of frame f in map cells,
+// padded by 2 cells and aligned to 4 columns, clipped to the map.
+__host__ Window part_window(const dm_params& p, const dm_frame& f, int q0, int q1, int r0,
+                            int r1) {
+  Window full = {0, 0, p.mw, p.mh};
+  if (p.clip_border > 0) {
+    const int c = p.clip_border;
+    if (q0 < c) q0 = c;
+    if (r0 < c) r0 = c;
+    if (q1 > p.W - c) q1 = p.W - c;
+    if (r1 > p.H - c) r1 = p.H - c;
+  }
+  if (q0 >= q1 || r0 >= r1) return Window{0, 0, 0, 0};
+  if (!p.has_dmin || !p.has_dmax || !(p.dmin >= 0.0f) || !(p.dmax >= p.dmin) ||
+      !isfinite(p.dmax))
+    return full;
+  double lo_x = INFINITY, hi_x = -INFINITY, lo_z = INFINITY, hi_z = -INFINITY;
+  const int qs[2] = {q0, q1 - 1}, rs[2] = {r0, r1 - 1};
+  const double zs[2] = {p.dmin, p.dmax};
+  for (int qi = 0; qi < 2; ++qi)
+    for (int ri = 0; ri < 2; ++ri)
+      for (int zi = 0; zi < 2; ++zi) {
+        const double ax = ((double)qs[qi] - p.cx) / p.fx;
+        double yr = rs[ri];
+        if (p.flip_h) yr = (double)(p.H - 1) - yr;
+        const double ay = (yr - p.cy) / p.fy;
+        const double z = zs[zi];
+        const double X = ax * z, Y = ay * z, Z = z;
+        const double x1 = X * f.Rp[0] + Y * f.Rp[3] + Z * f.Rp[6];
+        const double y1 = X * f.Rp[1] + Y * f.Rp[4] + Z * f.Rp[7] + f.cam_height;
+        const double z1 = X * f.Rp[2] + Y * f.Rp[5] + Z * f.Rp[8];
+        double x2 = x1, z2 = z1;
+        if (p.to_global) {
+          x2 = x1 * f.Ry[0] + y1 * f.Ry[3] + z1 * f.Ry[6] + f.tx;
+          z2 = x1 * f.Ry[2] + y1 * f.Ry[5] + z1 * f.Ry[8] + f.tz;
+        }
+        double xf = x2 / p.res + f.width_offset;
+        double zf = z2 / p.res + f.height_offset;
+        if (p.flip_h) zf = (double)(p.mh - 1) - zf;
+        if (!isfinite(xf) || !isfinite(zf)) return full;
+        lo_x = fmin(lo_x, xf); hi_x = fmax(hi_x, xf);
+        lo_z = fmin(lo_z, zf); hi_z = fmax(hi_z, zf);
+      }
+  // cells are floor(v + 0.5); 2 cells of slack cover the float32 rounding of
+  // the device arithmetic (observed error < 1e-3 cell)
+  double x0 = floor(lo_x + 0.5) - 2, x1 = floor(hi_x + 0.5) + 3;
+  double z0 = floor(lo_z + 0.5) - 2, z1 = floor(hi_z + 0.5) + 3;
+  if (x0 < 0) x0 = 0;
+  if (z0 < 0) z0 = 0;
+  if (x1 > p.mw) x1 = p.mw;
+  if (z1 > p.mh) z1 = p.mh;
+  if (x0 >= x1 || z0 >= z1) return Window{0, 0, 0, 0};
+  Window w;
+  w.x0 = ((int)x0) & ~3;
+  const int xe = ((int)x1 + 3) & ~3;           // mw % 4 == 0 is a precondition
+  w.w = (xe > p.mw ? p.mw : xe) - w.x0;
+  w.z0 = (int)z0;
+  w.h = (int)z1 - w.z0;
+  return w;
+}
+
+// ---------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------
+// Scalars of the scatter kernel, slimmed down to what it reads (SGPR budget).
+// Disabled tests are encoded as always-true bounds (dmin = -inf, dmax = hmax =
+// +inf: they then only reject NaN, which never reaches the map anyway) and a
+// local-space projection as an identity yaw with zero translation, so the
+// pixel loop has no flag to branch on.
+struct ScatterArgs {
+  int W, H;
+  int clip;                   // border pixels to drop (0 = none)
+  int flip_h;
+  float cx, cy, fx, fy, res;
+  float fx_inv, fy_inv, res_inv;
+  float dmin, dmax, hmax;
+  float Hm1, mhm1;
+  Parts parts;
+  int dc, valid_c;
+  int slab_stride;            // cells per slab
+  float fill;
+  const dm_frame* frames;     // device copy (yaw already neutralised if !to_global)
+  const Window* windows;      // (B, pr, pc): the same for every channel of a frame
+  const float* depth;
+  const uint8_t* valid;
+  float* slabs;
+};
+
+// ds_max_f32 / ds_min_f32: "store if new > old" -- torch_scatter's rule; a NaN
+// operand never replaces a number.
+template <bool IS_MAX>
+__device__ inline void lds_reduce(float* cell, float v) {
+  if (IS_MAX) __hip_atomic_fetch_max(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_fetch_min(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// FAST: every frame's rotations have the exact 0/1 pattern of rotate([1,0,0],.)
+//       and rotate([0,1,0],.) AND the Markstein reciprocals are usable
+//       (dm_pixel.hpp).  !FAST: full FMA chains and IEEE division.
+// VEC = 4: 16-byte depth loads (W % 4 == 0, 16-byte aligned base); VEC = 1: any shape.
+template <bool IS_MAX, bool FAST, bool HAS_VALID, int VEC>
+__global__ void __launch_bounds__(kScatterThreads)
+k_window_scatter(ScatterArgs a) {
+  extern __shared__ float lds[];
+  const int part = blockIdx.x;                 // pr-major, pc-minor
+  const int ch = blockIdx.y, b = blockIdx.z;
+  const int nparts = a.parts.pc * a.parts.pr;
+  const int pcx = part % a.parts.pc, pry = part / a.parts.pc;
+  const Window w = a.windows[(size_t)b * nparts + part];
+  if (w.w == 0) return;                        // wave-uniform: nothing can land
+  const int area = w.w * w.h;
+  for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
+    *reinterpret_cast<float4*>(lds + i) = make_float4(a.fill, a.fill, a.fill, a.fill);
+  __syncthreads();
+
+  const dm_frame* f = a.frames + b;
+  // pitch: rows 1,2 of R; yaw: rows 0,2 (the rest is 0/1 when FAST)
+  const float p0 = f->Rp[0], p1 = f->Rp[1], p2 = f->Rp[2], p3 = f->Rp[3], p4 = f->Rp[4],
+              p5 = f->Rp[5], p6 = f->Rp[6], p7 = f->Rp[7], p8 = f->Rp[8];
+  const float y0 = f->Ry[0], y1r = f->Ry[1], y2r = f->Ry[2], y3 = f->Ry[3], y4 = f->Ry[4],
+              y5 = f->Ry[5], y6 = f->Ry[6], y7 = f->Ry[7], y8 = f->Ry[8];
+  const float cam_h = f->cam_height, tx = f->tx, tz = f->tz;
+  const float wo = f->width_offset, ho = f->height_offset;
+
+  const int q0 = pcx * a.parts.wp;
+  int q1 = q0 + a.parts.wp; if (q1 > a.W) q1 = a.W;
+  const int r0 = pry * a.parts.hp;
+  int r1 = r0 + a.parts.hp; if (r1 > a.H) r1 = a.H;
+  const int nx = (q1 - q0 + VEC - 1) / VEC;    // lane groups per row
+  const int ntx = nx < kScatterThreads ? nx : kScatterThreads;
+  const int rows_per_iter = kScatterThreads / ntx;
+  const int gx = threadIdx.x % ntx, gy = threadIdx.x / ntx;
+  const size_t N = (size_t)a.H * a.W;
+  const float* dimg = a.depth + ((size_t)b * a.dc + ch) * N;
+  const uint8_t* vimg = HAS_VALID
+      ? a.valid + ((size_t)b * a.valid_c + (a.valid_c == 1 ? 0 : ch)) * N : nullptr;
+  const float qnan = __builtin_nanf("");
+
+  if (gy < rows_per_iter) {
+    for (int g = gx; g < nx; g += ntx) {       // one trip unless the strip is wider than the block
+      const int q = q0 + g * VEC;
+      // ray slope of each column (maps.py:677); border columns are poisoned with
+      // NaN, which flows through X to the cell coordinates (maps.py:48-70)
+      float ax[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float d = (float)(q + k) - a.cx;
+        ax[k] = FAST ? div_markstein(d, a.fx, a.fx_inv) : d / a.fx;
+        if (q + k < a.clip || q + k >= a.W - a.clip) ax[k] = qnan;
+      }
+      for (int r = r0 + gy; r < r1; r += rows_per_iter * kRowsInFlight) {
+        float z[kRowsInFlight][VEC];
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u) {
+          const int rr = r + u * rows_per_iter;
+          if (rr < r1) {
+            if (VEC == 4) {
+              const float4 t = *reinterpret_cast<const float4*>(dimg + (size_t)rr * a.W + q);
+              z[u][0] = t.x; z[u][1 % VEC] = t.y; z[u][2 % VEC] = t.z; z[u][3 % VEC] = t.w;
+            } else {
+              z[u][0] = dimg[(size_t)rr * a.W + q];
+            }
+            if (HAS_VALID) {
+#pragma unroll
+              for (int k = 0; k < VEC; ++k)
+                if (vimg[(size_t)rr * a.W + q + k] == 0) z[u][k] = qnan;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u) {
+          const int rr = r + u * rows_per_iter;
+          if (rr >= r1) break;
+          float yr = (float)rr;
+          yr = a.flip_h ? a.Hm1 - yr : yr;                       // maps.py:670-671
+          const float dy = yr - a.cy;
+          float ay = FAST ? div_markstein(dy, a.fy, a.fy_inv) : dy / a.fy;
+          if (rr < a.clip || rr >= a.H - a.clip) ay = qnan;
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const float zz = z[u][k];
+            const float X = ax[k] * zz, Y = ay * zz;             // maps.py:677-678
+            float x1, h1, z1, x2, h2, z2;
+            if (FAST) {
+              x1 = X;
+              h1 = __builtin_fmaf(zz, p7, Y * p4) + cam_h;       // maps.py:790-797
+              z1 = __builtin_fmaf(zz, p8, Y * p5);
+              x2 = __builtin_fmaf(z1, y6, x1 * y0) + tx;         // maps.py:884-892
+              z2 = __builtin_fmaf(z1, y8, x1 * y2r) + tz;
+              h2 = h1;
+            } else {
+              x1 = __builtin_fmaf(zz, p6, __builtin_fmaf(Y, p3, X * p0)) + 0.0f;
+              h1 = __builtin_fmaf(zz, p7, __builtin_fmaf(Y, p4, X * p1)) + cam_h;
+              z1 = __builtin_fmaf(zz, p8, __builtin_fmaf(Y, p5, X * p2)) + 0.0f;
+              x2 = __builtin_fmaf(z1, y6, __builtin_fmaf(h1, y3, x1 * y0)) + tx;
+              h2 = __builtin_fmaf(z1, y7, __builtin_fmaf(h1, y4, x1 * y1r)) + 0.0f;
+              z2 = __builtin_fmaf(z1, y8, __builtin_fmaf(h1, y5, x1 * y2r)) + tz;
+            }
+            float xf = (FAST ? div_markstein(x2, a.res, a.res_inv) : x2 / a.res) + wo;
+            float zf = (FAST ? div_markstein(z2, a.res, a.res_inv) : z2 / a.res) + ho;
+            zf = a.flip_h ? a.mhm1 - zf : zf;                    // maps.py:1006-1009
+            xf = __builtin_floorf(xf + 0.5f);                    // maps.py:1012-1013
+            zf = __builtin_floorf(zf + 0.5f);
+            // window test in integers (the window lies inside the map).
+            // v_cvt_i32_f32 saturates and maps NaN to 0, so NaN is excluded by
+            // the ordered compare.  maps.py:537-544, 286-288, 1150-1158
+            const unsigned ux = (unsigned)((int)xf - w.x0), uz = (unsigned)((int)zf - w.z0);
+            bool ok = !__builtin_isunordered(xf, zf) && ux < (unsigned)w.w &&
+                      uz < (unsigned)w.h && zz <= a.dmax && zz >= a.dmin && h1 <= a.hmax;
+            if (!FAST) ok = ok && (h2 == h2);
+            if (ok) lds_reduce<IS_MAX>(lds + (__umul24(uz, (unsigned)w.w) + ux), h2);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int pid = (b * a.dc + ch) * nparts + part;
+  float* slab = a.slabs + (size_t)pid * a.slab_stride;
+  for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
+    *reinterpret_cast<float4*>(slab + i) = *reinterpret_cast<const float4*>(lds + i);
+}
+
+struct MergeArgs {
+  int B, dc, mh, mw;
+  int nparts;                 // pc * pr
+  int slab_stride;
+  float fill;
+  const Window* windows;
+  const float* slabs;
+  float* out;
+  uint8_t* mask;
+};
+
+constexpr int kMergeThreads = 256;
+constexpr int kMergeGroups = 4;     // float4 groups per thread, kMergeThreads*4 cells apart
+
+// Each block owns kMergeThreads*4*kMergeGroups consecutive cells of one map;
+// every store instruction of a wave covers 1 KiB (map) / 256 B (mask) contiguously.
+template <bool IS_MAX>
+__global__ void __launch_bounds__(kMergeThreads)
+k_window_merge(MergeArgs a) {
+  const int fc = blockIdx.y;                   // frame * dc + channel
+  const int b = fc / a.dc;
+  const size_t M = (size_t)a.mh * a.mw;
+  const size_t base = (size_t)blockIdx.x * (kMergeThreads * 4 * kMergeGroups) + threadIdx.x * 4;
+  float4 acc[kMergeGroups];
+  int zb[kMergeGroups], x[kMergeGroups];
+#pragma unroll
+  for (int j = 0; j < kMergeGroups; ++j) {
+    acc[j] = make_float4(a.fill, a.fill, a.fill, a.fill);
+    const size_t cell = base + (size_t)j * kMergeThreads * 4;
+    zb[j] = (int)(cell / a.mw);
+    x[j] = (int)(cell - (size_t)zb[j] * a.mw);
+  }
+  for (int p = 0; p < a.nparts; ++p) {
+    const Window w = a.windows[(size_t)b * a.nparts + p];
+    if (w.w == 0) continue;
+    const float* slab = a.slabs + ((size_t)fc * a.nparts + p) * a.slab_stride;
+#pragma unroll
+    for (int j = 0; j < kMergeGroups; ++j) {
+      const unsigned ux = (unsigned)(x[j] - w.x0), uz = (unsigned)(zb[j] - w.z0);
+      if (ux < (unsigned)w.w && uz < (unsigned)w.h) {
+        const float4 s = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
+        acc[j].x = IS_MAX ? fmaxf(acc[j].x, s.x) : fminf(acc[j].x, s.x);
+        acc[j].y = IS_MAX ? fmaxf(acc[j].y, s.y) : fminf(acc[j].y, s.y);
+        acc[j].z = IS_MAX ? fmaxf(acc[j].z, s.z) : fminf(acc[j].z, s.z);
+        acc[j].w = IS_MAX ? fmaxf(acc[j].w, s.w) : fminf(acc[j].w, s.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kMergeGroups; ++j) {
+    const size_t cell = base + (size_t)j * kMergeThreads * 4;
+    if (cell >= M) break;
+    *reinterpret_cast<float4*>(a.out + (size_t)fc * M + cell) = acc[j];
+    const uint32_t mk = (uint32_t)mask_of(acc[j].x, a.fill) |
+                        ((uint32_t)mask_of(acc[j].y, a.fill) << 8) |
+                        ((uint32_t)mask_of(acc[j].z, a.fill) << 16) |
+                        ((uint32_t)mask_of(acc[j].w, a.fill) << 24);
+    *reinterpret_cast<uint32_t*>(a.mask + (size_t)fc * M + cell) = mk;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+bool window_path_supported(const dm_params& p) {
+  if (p.vc != 0) return false;
+  if (p.reduction != DM_REDUCE_MAX && p.reduction != DM_REDUCE_MIN) return false;
+  if (p.mw % 4 != 0) return false;
+  if (!(p.fill == p.fill)) return false;       // NaN fill has no order
+  return true;
+}
+
+size_t window_workspace_bytes(const dm_params& p) {
+  // frames | windows | slabs (worst case: every window as large as LDS allows)
+  const Parts s = choose_parts(p);
+  const size_t nparts = (size_t)s.pc * s.pr;
+  size_t cap = (size_t)p.mh * p.mw;
+  if (cap > kMaxLdsBytes / 4) cap = kMaxLdsBytes / 4;
+  return align_up((size_t)p.B * sizeof(dm_frame), 256) +
+         align_up((size_t)p.B * nparts * sizeof(Window), 256) +
+         (size_t)p.B * p.dc * nparts * align_up(cap, 4) * 4;
+}
+
+// Returns hipErrorNotSupported when some window does not fit in LDS (the caller
+// then takes the generic path); nothing has been enqueued in that case.
+hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const float* depth,
+                      const uint8_t* valid, float* out, uint8_t* mask, void* ws,
+                      hipStream_t s) {
+  const Parts parts = choose_parts(p);
+  const int nparts = parts.pc * parts.pr;
+  if ((long)p.B * p.dc > 65535) return hipErrorNotSupported;
+  if (reinterpret_cast<uintptr_t>(out) % 16 != 0 || reinterpret_cast<uintptr_t>(mask) % 4 != 0 ||
+      reinterpret_cast<uintptr_t>(ws) % 256 != 0)
+    return hipErrorNotSupported;
+  // host staging (thread-local: hipMemcpyAsync from pageable memory has copied
+  // the bytes out by the time it returns)
+  thread_local std::vector<unsigned char> staging;
+  const size_t frames_bytes = align_up((size_t)p.B * sizeof(dm_frame), 256);
+  const size_t win_bytes = align_up((size_t)p.B * nparts * sizeof(Window), 256);
+  staging.resize(frames_bytes + win_bytes);
+  memcpy(staging.data(), frames_host, (size_t)p.B * sizeof(dm_frame));
+  if (!p.to_global) {     // local map: neutral yaw, no translation (exact: x*1 + z*0 + 0)
+    dm_frame* fr = reinterpret_cast<dm_frame*>(staging.data());
+    static const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int b = 0; b < p.B; ++b) {
+      memcpy(fr[b].Ry, eye, sizeof(eye));
+      fr[b].tx = 0.0f; fr[b].tz = 0.0f;
+    }
+  }
+  Window* wins = reinterpret_cast<Window*>(staging.data() + frames_bytes);
+  int max_area = 0;
+  for (int b = 0; b < p.B; ++b)
+    for (int pr = 0; pr < parts.pr; ++pr)
+      for (int pc = 0; pc < parts.pc; ++pc) {
+        const int q0 = pc * parts.wp, r0 = pr * parts.hp;
+        const int q1 = q0 + parts.wp < p.W ? q0 + parts.wp : p.W;
+        const int r1 = r0 + parts.hp < p.H ? r0 + parts.hp : p.H;
+        const Window w = part_window(p, frames_host[b], q0, q1, r0, r1);
+        wins[(size_t)b * nparts + pr * parts.pc + pc] = w;
+        if (w.w * w.h > max_area) max_area = w.w * w.h;
+      }
+  if ((size_t)max_area * 4 > (size_t)kMaxLdsBytes) return hipErrorNotSupported;
+  const int slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 4);
+  hipError_t e;
+
+  unsigned char* base = static_cast<unsigned char*>(ws);
+  e = hipMemcpyAsync(base, staging.data(), frames_bytes + win_bytes,
+                                hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+
+  ScatterArgs sa;
+  sa.W = p.W; sa.H = p.H;
+  sa.clip = p.clip_border > 0 ? p.clip_border : 0;
+  sa.flip_h = p.flip_h != 0;
+  sa.cx = p.cx; sa.cy = p.cy; sa.fx = p.fx; sa.fy = p.fy; sa.res = p.res;
+  // branch-free exact division needs exactly rounded reciprocals and sane magnitudes
+  const bool fast_div = exact_reciprocal(p.res, &sa.res_inv) &&
+                        exact_reciprocal(p.fx, &sa.fx_inv) &&
+                        exact_reciprocal(p.fy, &sa.fy_inv) &&
+                        p.res >= 1e-6f && p.res <= 1e6f && p.fx >= 1e-6f && p.fx <= 1e6f &&
+                        p.fy >= 1e-6f && p.fy <= 1e6f;
+  if (!fast_div) sa.res_inv = sa.fx_inv = sa.fy_inv = 0.0f;
+  sa.dmin = p.has_dmin ? p.dmin : -INFINITY;
+  sa.dmax = p.has_dmax ? p.dmax : INFINITY;
+  sa.hmax = p.has_hmax ? p.hmax : INFINITY;
+  sa.Hm1 = (float)(p.H - 1); sa.mhm1 = (float)(p.mh - 1);
+  sa.parts = parts;
+  sa.dc = p.dc; sa.valid_c = p.valid_c;
+  sa.slab_stride = slab_stride;
+  sa.fill = p.fill;
+  sa.frames = reinterpret_cast<const dm_frame*>(base);
+  sa.windows = reinterpret_cast<const Window*>(base + frames_bytes);
+  sa.depth = depth; sa.valid = valid;
+  sa.slabs = reinterpret_cast<float*>(base + frames_bytes + win_bytes);
+
+  const bool is_max = p.reduction == DM_REDUCE_MAX;
+  const bool fast = fast_div && axis_aligned(reinterpret_cast<const dm_frame*>(staging.data()), p.B);
+  const bool has_valid = valid != nullptr;
+  const bool vec4 = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(depth) % 16 == 0) &&
+                    (parts.wp % 4 == 0);
+  const size_t lds_bytes = align_up((size_t)slab_stride * 4, 16);
+  dim3 grid(nparts, p.dc, p.B);
+
+  if (max_area > 0) {
+    using Kernel = void (*)(ScatterArgs);
+    // [is_max][fast][has_valid][vec4]
+    static const Kernel table[2][2][2][2] = {
+        {{{k_window_scatter<false, false, false, 1>, k_window_scatter<false, false, false, 4>},
+          {k_window_scatter<false, false, true, 1>, k_window_scatter<false, false, true, 4>}},
+         {{k_window_scatter<false, true, false, 1>, k_window_scatter<false, true, false, 4>},
+          {k_window_scatter<false, true, true, 1>, k_window_scatter<false, true, true, 4>}}},
+        {{{k_window_scatter<true, false, false, 1>, k_window_scatter<true, false, false, 4>},
+          {k_window_scatter<true, false, true, 1>, k_window_scatter<true, false, true, 4>}},
+         {{k_window_scatter<true, true, false, 1>, k_window_scatter<true, true, false, 4>},
+          {k_window_scatter<true, true, true, 1>, k_window_scatter<true, true, true, 4>}}}};
+    const Kernel kfn = table[is_max][fast][has_valid][vec4];
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kfn, grid, dim3(kScatterThreads), lds_bytes, s, sa);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+
+  MergeArgs ma;
+  ma.B = p.B; ma.dc = p.dc; ma.mh = p.mh; ma.mw = p.mw;
+  ma.nparts = nparts; ma.slab_stride = slab_stride; ma.fill = p.fill;
+  ma.windows = sa.windows; ma.slabs = sa.slabs; ma.out = out; ma.mask = mask;
+  const size_t M = (size_t)p.mh * p.mw;
+  const int per_block = kMergeThreads * 4 * kMergeGroups;
+  dim3 g((unsigned)((M + per_block - 1) / per_block), p.B * p.dc);
+  if (is_max) hipLaunchKernelGGL(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma);
+  else hipLaunchKernelGGL(k_window_merge<false>, g, dim3(kMergeThreads), 0, s, ma);
+  return hipGetLastError();
+}
+
+}  // namespace dm

@@ -3,7 +3,8 @@
 The HIP kernels never evaluate sin/cos: the two Rodrigues matrices of every
 frame are built here, on the CPU, in float32 with the reference's op order
 (reference utils.py:303-327 via ``utils.rotation_matrix``) and shipped to the
-GPU as one (B, 32) float32 table (``dm_frame`` in include/dungeon_maps_amd.h).
+library as one (B, 32) float32 host table (``dm_frame`` in
+include/dungeon_maps_amd.h), which stages it to the GPU on the call's stream.
 That is what makes the integer cell indices reproduce the reference's CPU path
 bit for bit regardless of the device's libm.
 """
@@ -44,10 +45,3 @@ def build_frame_table(batch: int, cam_pose, cam_pitch, cam_height, width_offset,
   table[:, 21] = _column(width_offset, batch)
   table[:, 22] = _column(height_offset, batch)
   return table
-
-
-def upload(table: torch.Tensor, device: torch.device) -> torch.Tensor:
-  """Async H2D of the table through pinned memory (stream-ordered)."""
-  if device.type != "cuda":
-    raise RuntimeError("frame tables live on the GPU")
-  return table.pin_memory().to(device, non_blocking=True)

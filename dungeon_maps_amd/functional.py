@@ -136,9 +136,9 @@ class _Call:
     p.hmax = float(trunc_height_max) if trunc_height_max is not None else 0.0
     self.params = p
     self.oc = vc if vc else dc
-    table = frames.build_frame_table(B, cam_pose, cam_pitch, cam_height, width_offset,
-                                     height_offset)
-    self.frames = frames.upload(table, self.dev)
+    # host-side dm_frame table; the library stages it to the GPU inside the call
+    self.frames = frames.build_frame_table(B, cam_pose, cam_pitch, cam_height, width_offset,
+                                           height_offset)
 
   def workspace(self) -> Tuple[Optional[torch.Tensor], int]:
     import ctypes

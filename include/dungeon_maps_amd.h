@@ -10,11 +10,13 @@
  * Conventions
  *  - plain pointers and sizes only; every pointer named *_dev is DEVICE memory
  *    (hipMalloc / PyTorch caching allocator), contiguous, float32 unless said
- *    otherwise.  The library never allocates or frees device memory: scratch is
- *    a caller-provided workspace (size from dm_*_workspace_bytes).
+ *    otherwise.  `frames` is a HOST array (pageable is fine): it is staged to
+ *    the device with a stream-ordered copy inside the call and may be reused as
+ *    soon as the call returns.  The library never allocates or frees device
+ *    memory: scratch is a caller-provided workspace (dm_*_workspace_bytes,
+ *    256-byte aligned).
  *  - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
- *    the default stream).  No host synchronisation inside; safe to capture in
- *    a hipGraph.
+ *    the default stream).  No host synchronisation inside.
  *  - return 0 on success, a negative dm_status otherwise; dm_last_error()
  *    returns a thread-local message.  No exceptions cross the ABI.
  *  - re-entrant; no global state besides the thread-local error string.
@@ -49,7 +51,7 @@ typedef enum dm_reduction {
 } dm_reduction;
 
 /*
- * Per-frame camera state, one 128-byte record per frame b (device table).
+ * Per-frame camera state, one 128-byte record per frame b (host array).
  * Built on the host with the reference's float32 op order so that no device
  * sin/cos is involved:
  *   Rp  = rotate([1,0,0], cam_pitch[b])   utils.py:303-327 via maps.py:790
@@ -108,7 +110,7 @@ size_t dm_orth_project_workspace_bytes(const dm_params* p);
  *              the height map IS out, maps.py:333-334)
  * Outputs are fully written (no pre-initialisation needed).
  */
-int dm_orth_project_f32(const dm_params* p, const dm_frame* frames_dev,
+int dm_orth_project_f32(const dm_params* p, const dm_frame* frames,
                         const float* depth_dev, const float* value_dev,
                         const uint8_t* valid_dev, float* out_dev,
                         uint8_t* mask_dev, float* height_dev,
@@ -125,12 +127,19 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames_dev,
  * If `accumulate` is non-zero, out_dev's current content takes part in the
  * reduction (running world map); otherwise it starts from p->fill.
  */
-int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames_dev,
+int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames,
                               const float* depth_dev, const float* value_dev,
                               const uint8_t* valid_dev, float* out_dev,
                               uint8_t* mask_dev, int accumulate,
                               void* workspace_dev, size_t workspace_bytes,
                               void* stream);
+
+/*
+ * Test hook: non-zero forces dm_orth_project_f32 onto the generic
+ * (global-atomic) path on the calling thread; returns the previous setting.
+ * The LDS-windowed fast path is checked against it on the device.
+ */
+int dm_debug_force_generic_path(int on);
 
 /*
  * Fuse B maps that share one frame (same res/offsets/size) into one:

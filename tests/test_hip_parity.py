@@ -231,3 +231,53 @@ def test_full_size_properties(dmap):
     assert torch.equal(t1[0], top[b]) and torch.equal(m1[0], mask[b])
   assert torch.equal(mask, torch.isfinite(top))                        # F9
   assert mask.any(dim=-1).any(dim=-1).all()                            # every frame hit
+
+
+# --------------------------------------------------------------------------
+# LDS-windowed fast path vs the generic global-atomic path (same device)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [
+    dict(B=5, H=96, W=128, mh=128, mw=128),                       # strips x bands
+    dict(B=3, H=50, W=66, mh=64, mw=64),                          # W % 4 != 0 -> scalar loads
+    dict(B=2, H=96, W=128, mh=128, mw=128, flip_h=False, to_global=False),
+    dict(B=2, H=96, W=128, mh=128, mw=128, clip_border=7, trunc_height_max=0.6),
+    dict(B=2, H=96, W=128, mh=128, mw=128, reduction="min", fill_value=np.inf),
+    dict(B=2, H=96, W=128, mh=128, mw=128, fill_value=0.25),      # finite fill takes part
+    dict(B=2, H=96, W=128, mh=96, mw=160, trunc_depth_max=None),  # unbounded: window = map
+    dict(B=1, H=96, W=128, mh=512, mw=512, trunc_depth_min=None), # window > LDS -> fallback
+    dict(B=2, H=96, W=128, mh=128, mw=128, valid=True),
+    dict(B=300, H=24, W=32, mh=64, mw=64),                        # more frames than CUs
+    dict(B=2, H=96, W=128, mh=128, mw=128, res=1.0 / 3),
+    dict(B=2, H=96, W=128, mh=128, mw=128, woff=1000.0),          # frustum misses the map
+])
+def test_window_path_equals_generic_path(dmap, oracle, case):
+  from dungeon_maps_amd import _native
+  c = dict(case)
+  B, H, W, mh, mw = (c.pop(k) for k in ("B", "H", "W", "mh", "mw"))
+  use_valid = c.pop("valid", False)
+  res = c.pop("res", 0.05)
+  woff = c.pop("woff", mw / 2.)
+  depth, pose = _synthetic(B, H, W, seed=4321)
+  depth[:, :, 0, :3] = [np.nan, np.inf, -1.0]
+  valid = None
+  if use_valid:
+    valid = (np.random.default_rng(1).uniform(size=(B, 1, H, W)) > 0.4)
+  cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+             cam_height=0.88, width_offset=woff, height_offset=mh / 2., map_res=res,
+             map_width=mw, map_height=mh, trunc_depth_min=0.15, trunc_depth_max=5.05,
+             to_global=True, fill_value=-np.inf)
+  cfg.update(c)
+  lib = _native.lib()
+  fast = _run(dmap, cfg, depth, valid=valid, cam_pose=pose)
+  lib.dm_debug_force_generic_path(1)
+  try:
+    slow = _run(dmap, cfg, depth, valid=valid, cam_pose=pose)
+  finally:
+    lib.dm_debug_force_generic_path(0)
+  np.testing.assert_array_equal(fast[1], slow[1])
+  np.testing.assert_array_equal(fast[0], slow[0])
+  if B <= 8:
+    want = oracle.orth_project(depth, valid_map=valid,
+                               **dict(_oracle_kwargs(oracle, cfg), cam_pose=pose))
+    np.testing.assert_array_equal(fast[1], want[1])
+    np.testing.assert_array_equal(fast[0], want[0])

@@ -247,36 +247,44 @@ k_window_scatter(ScatterArgs a) {
       for (int k = 0; k < VEC; ++k) {
         const float d = (float)(q + k) - a.cx;
         ax[k] = FAST ? div_markstein(d, a.fx, a.fx_inv) : d / a.fx;
-        if (q + k < a.clip || q + k >= a.W - a.clip) ax[k] = qnan;
+        ax[k] = (q + k < a.clip || q + k >= a.W - a.clip) ? qnan : ax[k];
       }
-      for (int r = r0 + gy; r < r1; r += rows_per_iter * kRowsInFlight) {
-        float z[kRowsInFlight][VEC];
+      // Software pipeline over groups of kRowsInFlight rows: the loads of group
+      // i+1 are in flight while group i is projected (all waves of a workgroup
+      // run in phase, so latency has to be hidden inside each wave).
+      const int step = rows_per_iter * kRowsInFlight;
+      float za[kRowsInFlight][VEC], zb_[kRowsInFlight][VEC];
+      auto load_rows = [&](float (&z)[kRowsInFlight][VEC], int r) {
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u) {
-          const int rr = r + u * rows_per_iter;
-          if (rr < r1) {
-            if (VEC == 4) {
-              const float4 t = *reinterpret_cast<const float4*>(dimg + (size_t)rr * a.W + q);
-              z[u][0] = t.x; z[u][1 % VEC] = t.y; z[u][2 % VEC] = t.z; z[u][3 % VEC] = t.w;
-            } else {
-              z[u][0] = dimg[(size_t)rr * a.W + q];
-            }
-            if (HAS_VALID) {
+          // rows past the part are clamped to its last row (a legal address);
+          // project_rows() ignores them.  No per-lane branch: the loads stay in
+          // one basic block and the compiler can wait on them individually.
+          int rr = r + u * rows_per_iter;
+          rr = rr < r1 ? rr : r1 - 1;
+          if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(dimg + (size_t)rr * a.W + q);
+            z[u][0] = t.x; z[u][1 % VEC] = t.y; z[u][2 % VEC] = t.z; z[u][3 % VEC] = t.w;
+          } else {
+            z[u][0] = dimg[(size_t)rr * a.W + q];
+          }
+          if (HAS_VALID) {
 #pragma unroll
-              for (int k = 0; k < VEC; ++k)
-                if (vimg[(size_t)rr * a.W + q + k] == 0) z[u][k] = qnan;
-            }
+            for (int k = 0; k < VEC; ++k)
+              z[u][k] = vimg[(size_t)rr * a.W + q + k] ? z[u][k] : qnan;
           }
         }
+      };
+      auto project_rows = [&](const float (&z)[kRowsInFlight][VEC], int r) {
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u) {
           const int rr = r + u * rows_per_iter;
-          if (rr >= r1) break;
           float yr = (float)rr;
           yr = a.flip_h ? a.Hm1 - yr : yr;                       // maps.py:670-671
           const float dy = yr - a.cy;
           float ay = FAST ? div_markstein(dy, a.fy, a.fy_inv) : dy / a.fy;
-          if (rr < a.clip || rr >= a.H - a.clip) ay = qnan;
+          // rows outside the part (pipeline tail) or in the clipped border: poison
+          ay = (rr >= r1 || rr < a.clip || rr >= a.H - a.clip) ? qnan : ay;
 #pragma unroll
           for (int k = 0; k < VEC; ++k) {
             const float zz = z[u][k];
@@ -312,6 +320,18 @@ k_window_scatter(ScatterArgs a) {
             if (ok) lds_reduce<IS_MAX>(lds + (__umul24(uz, (unsigned)w.w) + ux), h2);
           }
         }
+      };
+      const int niter = (r1 - r0 + step - 1) / step;             // wave-uniform
+      int r = r0 + gy;
+      load_rows(za, r);
+      for (int it = 0; it < niter; it += 2) {
+        load_rows(zb_, r + step);
+        project_rows(za, r);
+        if (it + 1 < niter) {
+          load_rows(za, r + 2 * step);
+          project_rows(zb_, r + step);
+        }
+        r += 2 * step;
       }
     }
   }

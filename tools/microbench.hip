@@ -46,6 +46,46 @@ __global__ void __launch_bounds__(256) k_write(float4* __restrict__ out, size_t 
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
     out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
 }
+__global__ void __launch_bounds__(256) k_write_nt(float4* __restrict__ out, size_t n4) {
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    { float* o = reinterpret_cast<float*>(&out[i]);
+      __builtin_nontemporal_store(1.f, o); __builtin_nontemporal_store(2.f, o + 1);
+      __builtin_nontemporal_store(3.f, o + 2); __builtin_nontemporal_store(4.f, o + 3); }
+}
+// each block owns a contiguous chunk of `per_block` float4
+__global__ void __launch_bounds__(256) k_write_chunk(float4* __restrict__ out, size_t n4, int per_block) {
+  size_t base = (size_t)blockIdx.x * per_block;
+  for (int i = threadIdx.x; i < per_block; i += 256) if (base + i < n4) out[base + i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+__global__ void __launch_bounds__(256) k_copy(const float4* __restrict__ in, float4* __restrict__ out, size_t n4) {
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) out[i] = in[i];
+}
+__global__ void __launch_bounds__(256) k_copy_chunk(const float4* __restrict__ in, float4* __restrict__ out, size_t n4, int per_block) {
+  size_t base = (size_t)blockIdx.x * per_block;
+  for (int i = threadIdx.x; i < per_block; i += 256) if (base + i < n4) out[base + i] = in[base + i];
+}
+typedef float v2f __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(1024) k_valu_fma(float* out, int iters, float a, float b) {
+  float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+  for (int i = 0; i < iters; ++i) {
+    x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b);
+    x4 = __builtin_fmaf(x4, a, b); x5 = __builtin_fmaf(x5, a, b); x6 = __builtin_fmaf(x6, a, b); x7 = __builtin_fmaf(x7, a, b);
+  }
+  float r = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+  if (r == 123.456f) out[0] = r;
+}
+__global__ void __launch_bounds__(1024) k_valu_pkfma(float* out, int iters, float a, float b) {
+  v2f x0 = {(float)threadIdx.x, 1.f}, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f;
+  v2f va = {a, a}, vb = {b, b};
+  for (int i = 0; i < iters; ++i) {
+    x0 = __builtin_elementwise_fma(x0, va, vb); x1 = __builtin_elementwise_fma(x1, va, vb);
+    x2 = __builtin_elementwise_fma(x2, va, vb); x3 = __builtin_elementwise_fma(x3, va, vb);
+  }
+  v2f r = x0 + x1 + x2 + x3;
+  if (r.x + r.y == 123.456f) out[0] = r.x;
+}
 __global__ void k_empty() {}
 
 template <class F> float time_ms(F f, int reps = 5) {
@@ -63,6 +103,17 @@ int main() {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device %s CUs %d clock %d kHz L2 %d\n", prop.name, prop.multiProcessorCount, prop.clockRate, prop.l2CacheSize);
   unsigned* dout; CK(hipMalloc(&dout, 1 << 20));
+  {
+    const int iters = 4096;
+    for (int threads : {256, 512, 1024}) {
+      float ms = time_ms([&] { hipLaunchKernelGGL(k_valu_fma, dim3(256), dim3(threads), 0, 0, (float*)dout, iters, 1.0001f, 0.5f); });
+      double n = 256.0 * threads * iters * 8;
+      printf("v_fma_f32     %4d thr/CU: %.3f ms  %.1f Tlane-instr/s  (%.1f lanes/clk/CU @2.4GHz)\n", threads, ms, n / ms / 1e9, n / ms / 1e-3 / 256 / 2.4e9);
+      ms = time_ms([&] { hipLaunchKernelGGL(k_valu_pkfma, dim3(256), dim3(threads), 0, 0, (float*)dout, iters, 1.0001f, 0.5f); });
+      n = 256.0 * threads * iters * 4;
+      printf("v_pk_fma_f32  %4d thr/CU: %.3f ms  %.1f Tlane-instr/s  (%.1f lanes/clk/CU; x2 flops)\n", threads, ms, n / ms / 1e9, n / ms / 1e-3 / 256 / 2.4e9);
+    }
+  }
   // LDS atomics: 32K cells (128 KB), 1 block per CU
   {
     const int iters = 2000;
@@ -97,6 +148,32 @@ int main() {
       printf("read  1GiB blocks=%d: %.3f ms  %.2f TB/s\n", blocks, ms, bytes / ms / 1e9);
       ms = time_ms([&] { hipLaunchKernelGGL(k_write, dim3(blocks), dim3(256), 0, 0, buf, bytes / 16); });
       printf("write 1GiB blocks=%d: %.3f ms  %.2f TB/s\n", blocks, ms, bytes / ms / 1e9);
+    }
+    {
+      size_t half = bytes / 2; float4* dst = buf + half / 16;
+      for (int blocks : {2048, 8192, 32768}) {
+        float ms = time_ms([&] { hipLaunchKernelGGL(k_write_nt, dim3(blocks), dim3(256), 0, 0, buf, bytes / 16); });
+        printf("write_nt 1GiB blocks=%d: %.3f ms  %.2f TB/s\n", blocks, ms, bytes / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(256), 0, 0, buf, dst, half / 16); });
+        printf("copy 512MiB->512MiB blocks=%d: %.3f ms  %.2f TB/s (read+write)\n", blocks, ms, bytes / ms / 1e9);
+      }
+      for (int per_block : {1024, 4096, 16384}) {   // 16 KB, 64 KB, 256 KB chunks
+        int blocks = (int)((bytes / 16 + per_block - 1) / per_block);
+        float ms = time_ms([&] { hipLaunchKernelGGL(k_write_chunk, dim3(blocks), dim3(256), 0, 0, buf, bytes / 16, per_block); });
+        printf("write_chunk 1GiB chunk=%d KB blocks=%d: %.3f ms  %.2f TB/s\n", per_block * 16 / 1024, blocks, ms, bytes / ms / 1e9);
+        blocks = (int)((half / 16 + per_block - 1) / per_block);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_copy_chunk, dim3(blocks), dim3(256), 0, 0, buf, dst, half / 16, per_block); });
+        printf("copy_chunk 512MiB chunk=%d KB blocks=%d: %.3f ms  %.2f TB/s (read+write)\n", per_block * 16 / 1024, blocks, ms, bytes / ms / 1e9);
+      }
+      // cfg2-sized: write 84 MB
+      size_t w84 = (size_t)84 << 20;
+      for (int per_block : {1024, 4096}) {
+        int blocks = (int)((w84 / 16 + per_block - 1) / per_block);
+        float ms = time_ms([&] { hipLaunchKernelGGL(k_write_chunk, dim3(blocks), dim3(256), 0, 0, buf, w84 / 16, per_block); }, 10);
+        printf("write_chunk 84MiB chunk=%d KB: %.3f ms  %.2f TB/s\n", per_block * 16 / 1024, ms, w84 / ms / 1e9);
+      }
+      float ms = time_ms([&] { hipLaunchKernelGGL(k_write_nt, dim3(8192), dim3(256), 0, 0, buf, w84 / 16); }, 10);
+      printf("write_nt 84MiB: %.3f ms  %.2f TB/s\n", ms, w84 / ms / 1e9);
     }
     // L3-resident size: 160 MB (cfg2 working set)
     size_t small = (size_t)80 << 20;

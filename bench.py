@@ -124,13 +124,14 @@ def main():
   def step(i=None):
     if i is not None:
       ev_a[i].record()
-    top, mask = proj.orth_project(depth_d, value_map=value_d, cam_pose=pose)
+    # per-frame maps + masks and this rank's partial global map, one launch sequence
+    top, mask, fused, fmask = proj.orth_project_and_fuse(depth_d, value_map=value_d,
+                                                         cam_pose=pose)
     if i is not None:
       ev_b[i].record()
-    fused = dmap.fuse_batch(top, "max")
     if dist is not None:
-      dist.all_reduce(fused, op=dist.ReduceOp.MAX)
-    fmask = dmap.mask_from_map(fused, fill)
+      dist.all_reduce(fused, op=dist.ReduceOp.MAX)      # RCCL, element-wise max
+      fmask = dmap.mask_from_map(fused, fill)
     return top, mask, fused, fmask
 
   def barrier():

@@ -8,9 +8,11 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libdungeon_maps_amd.so")
+# DUNGEON_MAPS_AMD_LIB: load another build of the same ABI (instrumented builds)
+LIB_PATH = os.environ.get("DUNGEON_MAPS_AMD_LIB") or os.path.join(
+    HERE, "csrc", "libdungeon_maps_amd.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # dm_reduction
 REDUCE_MAX, REDUCE_MIN, REDUCE_SUM, REDUCE_MEAN, REDUCE_PROD = range(5)
@@ -38,7 +40,7 @@ _SIGNATURES = {
     "dm_orth_project_f32": (ctypes.c_int, [
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dm_orth_project_fused_f32": (ctypes.c_int, [
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,

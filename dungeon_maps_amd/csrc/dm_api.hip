@@ -57,8 +57,9 @@ size_t dm_orth_project_workspace_bytes(const dm_params* p) {
 
 int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float* depth_dev,
                         const float* value_dev, const uint8_t* valid_dev, float* out_dev,
-                        uint8_t* mask_dev, float* height_dev, void* workspace_dev,
-                        size_t workspace_bytes, void* stream) {
+                        uint8_t* mask_dev, float* height_dev, float* fused_dev,
+                        uint8_t* fused_mask_dev, void* workspace_dev, size_t workspace_bytes,
+                        void* stream) {
   int rc = check_params(p);
   if (rc != DM_OK) return rc;
   if (p->B == 0) return DM_OK;
@@ -68,6 +69,11 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
     return fail(DM_ERR_INVALID_ARGUMENT, "value pointer and vc=%d disagree", p->vc);
   if ((p->valid_c > 0) != (valid_dev != nullptr))
     return fail(DM_ERR_INVALID_ARGUMENT, "valid pointer and valid_c=%d disagree", p->valid_c);
+  if ((fused_dev != nullptr) != (fused_mask_dev != nullptr))
+    return fail(DM_ERR_INVALID_ARGUMENT, "fused map and fused mask must be given together");
+  if (fused_dev && p->reduction != DM_REDUCE_MAX && p->reduction != DM_REDUCE_MIN)
+    return fail(DM_ERR_UNSUPPORTED, "the batch-fused map supports max/min only (got %d)",
+                p->reduction);
   const size_t need = dm_orth_project_workspace_bytes(p);
   if (need > workspace_bytes || (need && !workspace_dev))
     return fail(DM_ERR_WORKSPACE_TOO_SMALL, "workspace %zu B < required %zu B", workspace_bytes,
@@ -75,10 +81,17 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipErrorNotSupported;
   if (dm::window_path_supported(*p) && !g_force_generic)
-    e = dm::run_window(*p, frames, depth_dev, valid_dev, out_dev, mask_dev, workspace_dev, s);
-  if (e == hipErrorNotSupported)   // nothing enqueued: a window exceeds LDS, odd alignment, ...
+    e = dm::run_window(*p, frames, depth_dev, valid_dev, out_dev, mask_dev, fused_dev,
+                       fused_mask_dev, workspace_dev, s);
+  if (e == hipErrorNotSupported) { // nothing enqueued: a window exceeds LDS, odd alignment, ...
     e = dm::run_generic(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
                         p->vc ? height_dev : nullptr, workspace_dev, s);
+    if (e == hipSuccess && fused_dev) {
+      const size_t n = (size_t)(p->vc ? p->vc : p->dc) * p->mh * p->mw;
+      e = dm::run_fuse_batch(out_dev, p->B, n, fused_dev, p->reduction == DM_REDUCE_MAX, 0, s);
+      if (e == hipSuccess) e = dm::run_mask_from_map(fused_dev, p->fill, fused_mask_dev, n, s);
+    }
+  }
   if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
   return DM_OK;
 }

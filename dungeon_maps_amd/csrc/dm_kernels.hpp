@@ -20,8 +20,8 @@ hipError_t run_generic_fused(const dm_params& p, const dm_frame* frames_host, co
 bool window_path_supported(const dm_params& p);
 size_t window_workspace_bytes(const dm_params& p);
 hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const float* depth,
-                      const uint8_t* valid, float* out, uint8_t* mask, void* ws,
-                      hipStream_t s);
+                      const uint8_t* valid, float* out, uint8_t* mask, float* fused,
+                      uint8_t* fused_mask, void* ws, hipStream_t s);
 hipError_t run_fuse_batch(const float* maps, int B, size_t n, float* out, bool is_max,
                           int accumulate, hipStream_t s);
 hipError_t run_mask_from_map(const float* map, float fill, uint8_t* mask, size_t n,

@@ -185,7 +185,19 @@ struct ScatterArgs {
   const float* depth;
   const uint8_t* valid;
   float* slabs;
+  // fill duty: the part of every output map outside its frame's union window
+  const Window* unions;       // (B): bounding box of the frame's windows, x aligned to 4
+  float* out;
+  uint8_t* mask;
+  int mh, mw;
 };
+
+// (int)floorf(x) in one instruction; NaN -> 0, saturating (like v_cvt_i32_f32)
+__device__ inline int floor_to_int(float x) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 
 // ds_max_f32 / ds_min_f32: "store if new > old" -- torch_scatter's rule; a NaN
 // operand never replaces a number.
@@ -208,8 +220,38 @@ k_window_scatter(ScatterArgs a) {
   const int nparts = a.parts.pc * a.parts.pr;
   const int pcx = part % a.parts.pc, pry = part / a.parts.pc;
   const Window w = a.windows[(size_t)b * nparts + part];
-  if (w.w == 0) return;                        // wave-uniform: nothing can land
-  const int area = w.w * w.h;
+  const int area = w.w * w.h;                  // 0: nothing of this part can land
+
+  // Fill duty, interleaved with the scatter so that these stores ride under the
+  // VALU-bound projection: map rows part, part + nparts, ... of (b, ch), minus
+  // the frame's union window U (k_window_merge writes U).  One float4 (+ 4 mask
+  // bytes) per thread and step.
+  const Window U = a.unions[b];
+  const int g4 = a.mw >> 2;
+  const int g4_shift = (g4 & (g4 - 1)) == 0 ? __builtin_ctz(g4) : -1;   // wave-uniform
+  const int fill_total = ((a.mh - part + nparts - 1) / nparts) * g4;
+  const int fill_steps = (fill_total + kScatterThreads - 1) / kScatterThreads;
+  const size_t map_base = ((size_t)b * a.dc + ch) * (size_t)a.mh * a.mw;
+  int fs = 0;
+  auto fill_step = [&]() {
+    const int i = fs * kScatterThreads + (int)threadIdx.x;
+    ++fs;
+    if (i < fill_total) {
+      const int k = g4_shift >= 0 ? (i >> g4_shift) : i / g4;
+      const int g = i - k * g4;
+      const int r = part + k * nparts, x = g << 2;
+      const bool inside = (unsigned)(r - U.z0) < (unsigned)U.h && (unsigned)(x - U.x0) < (unsigned)U.w;
+      if (!inside) {
+        const size_t cell = map_base + (size_t)r * a.mw + x;
+        *reinterpret_cast<float4*>(a.out + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
+        *reinterpret_cast<uint32_t*>(a.mask + cell) = 0u;
+      }
+    }
+  };
+  if (area == 0) {                             // wave-uniform
+    while (fs < fill_steps) fill_step();
+    return;
+  }
   for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
     *reinterpret_cast<float4*>(lds + i) = make_float4(a.fill, a.fill, a.fill, a.fill);
   __syncthreads();
@@ -236,8 +278,11 @@ k_window_scatter(ScatterArgs a) {
   const uint8_t* vimg = HAS_VALID
       ? a.valid + ((size_t)b * a.valid_c + (a.valid_c == 1 ? 0 : ch)) * N : nullptr;
   const float qnan = __builtin_nanf("");
+  const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
+  const unsigned dummy = (unsigned)area + (threadIdx.x & 63u);   // 64 scratch cells after the window
 
-  if (gy < rows_per_iter) {
+  const bool idle = gy >= rows_per_iter;       // block size not a multiple of the strip width
+  {
     for (int g = gx; g < nx; g += ntx) {       // one trip unless the strip is wider than the block
       const int q = q0 + g * VEC;
       // ray slope of each column (maps.py:677); border columns are poisoned with
@@ -247,7 +292,7 @@ k_window_scatter(ScatterArgs a) {
       for (int k = 0; k < VEC; ++k) {
         const float d = (float)(q + k) - a.cx;
         ax[k] = FAST ? div_markstein(d, a.fx, a.fx_inv) : d / a.fx;
-        ax[k] = (q + k < a.clip || q + k >= a.W - a.clip) ? qnan : ax[k];
+        ax[k] = (idle || q + k < a.clip || q + k >= a.W - a.clip) ? qnan : ax[k];
       }
       // Software pipeline over groups of kRowsInFlight rows: the loads of group
       // i+1 are in flight while group i is projected (all waves of a workgroup
@@ -285,6 +330,12 @@ k_window_scatter(ScatterArgs a) {
           float ay = FAST ? div_markstein(dy, a.fy, a.fy_inv) : dy / a.fy;
           // rows outside the part (pipeline tail) or in the clipped border: poison
           ay = (rr >= r1 || rr < a.clip || rr >= a.H - a.clip) ? qnan : ay;
+          // the VEC pixels of a row are projected side by side (independent
+          // chains for the scheduler); their LDS atomics come last so that no
+          // branch separates the arithmetic of neighbouring pixels
+          unsigned li[VEC];
+          float hv[VEC];
+          bool ok[VEC];
 #pragma unroll
           for (int k = 0; k < VEC; ++k) {
             const float zz = z[u][k];
@@ -307,34 +358,50 @@ k_window_scatter(ScatterArgs a) {
             }
             float xf = (FAST ? div_markstein(x2, a.res, a.res_inv) : x2 / a.res) + wo;
             float zf = (FAST ? div_markstein(z2, a.res, a.res_inv) : z2 / a.res) + ho;
-            zf = a.flip_h ? a.mhm1 - zf : zf;                    // maps.py:1006-1009
-            xf = __builtin_floorf(xf + 0.5f);                    // maps.py:1012-1013
-            zf = __builtin_floorf(zf + 0.5f);
-            // window test in integers (the window lies inside the map).
-            // v_cvt_i32_f32 saturates and maps NaN to 0, so NaN is excluded by
-            // the ordered compare.  maps.py:537-544, 286-288, 1150-1158
-            const unsigned ux = (unsigned)((int)xf - w.x0), uz = (unsigned)((int)zf - w.z0);
-            bool ok = !__builtin_isunordered(xf, zf) && ux < (unsigned)w.w &&
-                      uz < (unsigned)w.h && zz <= a.dmax && zz >= a.dmin && h1 <= a.hmax;
-            if (!FAST) ok = ok && (h2 == h2);
-            if (ok) lds_reduce<IS_MAX>(lds + (__umul24(uz, (unsigned)w.w) + ux), h2);
+            // flip: (mh-1) - zf as fma(zf, -1, mh-1); no flip: fma(zf, 1, 0) -- both exact
+            zf = __builtin_fmaf(zf, flip_s, flip_c);             // maps.py:1006-1009
+            xf = xf + 0.5f;                                      // maps.py:1012-1013
+            zf = zf + 0.5f;
+            // floor + convert in one instruction; window test in integers (the
+            // window lies inside the map).  The conversion saturates and maps
+            // NaN to 0, so NaN is excluded by the ordered compare.
+            // maps.py:537-544, 286-288, 1150-1158
+            const unsigned ux = (unsigned)(floor_to_int(xf) - w.x0);
+            const unsigned uz = (unsigned)(floor_to_int(zf) - w.z0);
+            ok[k] = !__builtin_isunordered(xf, zf) && ux < (unsigned)w.w &&
+                    uz < (unsigned)w.h && zz <= a.dmax && zz >= a.dmin && h1 <= a.hmax;
+            if (!FAST) ok[k] = ok[k] && (h2 == h2);
+            // rejected pixels are redirected to a per-lane dummy cell behind the
+            // window instead of being branched around: the whole row group stays
+            // one basic block the scheduler can interleave
+            unsigned cell = __umul24(uz, (unsigned)w.w) + ux;
+            asm("" : "+v"(cell));   // keep the select below a v_cndmask, not a branch
+            li[k] = ok[k] ? cell : dummy;
+            hv[k] = h2;
           }
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) lds_reduce<IS_MAX>(lds + li[k], hv[k]);
         }
       };
       const int niter = (r1 - r0 + step - 1) / step;             // wave-uniform
+      const int fill_per_iter = (fill_steps + niter - 1) / niter;
       int r = r0 + gy;
       load_rows(za, r);
       for (int it = 0; it < niter; it += 2) {
         load_rows(zb_, r + step);
+        // fill stores are issued after the loads, so no load ever waits on them
+        for (int t = 0; t < fill_per_iter && fs < fill_steps; ++t) fill_step();
         project_rows(za, r);
         if (it + 1 < niter) {
           load_rows(za, r + 2 * step);
+          for (int t = 0; t < fill_per_iter && fs < fill_steps; ++t) fill_step();
           project_rows(zb_, r + step);
         }
         r += 2 * step;
       }
     }
   }
+  while (fs < fill_steps) fill_step();
   __syncthreads();
   const int pid = (b * a.dc + ch) * nparts + part;
   float* slab = a.slabs + (size_t)pid * a.slab_stride;
@@ -348,31 +415,39 @@ struct MergeArgs {
   int slab_stride;
   float fill;
   const Window* windows;
+  const Window* unions;
   const float* slabs;
   float* out;
   uint8_t* mask;
 };
 
 constexpr int kMergeThreads = 256;
-constexpr int kMergeGroups = 4;     // float4 groups per thread, kMergeThreads*4 cells apart
+constexpr int kMergeGroups = 1;     // float4 groups per thread (more waves hide the 2-level latency)
 
-// Each block owns kMergeThreads*4*kMergeGroups consecutive cells of one map;
-// every store instruction of a wave covers 1 KiB (map) / 256 B (mask) contiguously.
+// Writes the union window U of every (frame, channel): max/min over the slabs
+// covering each cell, fill where none does.  A block owns kMergeThreads *
+// kMergeGroups consecutive float4 groups of U (row-major inside U), so a wave's
+// store covers up to 1 KiB (map) / 256 B (mask) contiguously.
 template <bool IS_MAX>
 __global__ void __launch_bounds__(kMergeThreads)
 k_window_merge(MergeArgs a) {
   const int fc = blockIdx.y;                   // frame * dc + channel
   const int b = fc / a.dc;
+  const Window U = a.unions[b];
+  const int ug4 = U.w >> 2;                    // float4 groups per U row
+  const int total = ug4 * U.h;
+  const int first = blockIdx.x * (kMergeThreads * kMergeGroups) + threadIdx.x;
+  if (blockIdx.x * (kMergeThreads * kMergeGroups) >= total) return;
   const size_t M = (size_t)a.mh * a.mw;
-  const size_t base = (size_t)blockIdx.x * (kMergeThreads * 4 * kMergeGroups) + threadIdx.x * 4;
   float4 acc[kMergeGroups];
   int zb[kMergeGroups], x[kMergeGroups];
 #pragma unroll
   for (int j = 0; j < kMergeGroups; ++j) {
     acc[j] = make_float4(a.fill, a.fill, a.fill, a.fill);
-    const size_t cell = base + (size_t)j * kMergeThreads * 4;
-    zb[j] = (int)(cell / a.mw);
-    x[j] = (int)(cell - (size_t)zb[j] * a.mw);
+    const int i = first + j * kMergeThreads;
+    const int row = i / ug4;
+    zb[j] = U.z0 + row;
+    x[j] = U.x0 + ((i - row * ug4) << 2);
   }
   for (int p = 0; p < a.nparts; ++p) {
     const Window w = a.windows[(size_t)b * a.nparts + p];
@@ -381,7 +456,7 @@ k_window_merge(MergeArgs a) {
 #pragma unroll
     for (int j = 0; j < kMergeGroups; ++j) {
       const unsigned ux = (unsigned)(x[j] - w.x0), uz = (unsigned)(zb[j] - w.z0);
-      if (ux < (unsigned)w.w && uz < (unsigned)w.h) {
+      if (ux < (unsigned)w.w && uz < (unsigned)w.h && first + j * kMergeThreads < total) {
         const float4 s = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
         acc[j].x = IS_MAX ? fmaxf(acc[j].x, s.x) : fminf(acc[j].x, s.x);
         acc[j].y = IS_MAX ? fmaxf(acc[j].y, s.y) : fminf(acc[j].y, s.y);
@@ -392,14 +467,84 @@ k_window_merge(MergeArgs a) {
   }
 #pragma unroll
   for (int j = 0; j < kMergeGroups; ++j) {
-    const size_t cell = base + (size_t)j * kMergeThreads * 4;
-    if (cell >= M) break;
-    *reinterpret_cast<float4*>(a.out + (size_t)fc * M + cell) = acc[j];
+    if (first + j * kMergeThreads >= total) break;
+    const size_t cell = (size_t)fc * M + (size_t)zb[j] * a.mw + x[j];
+    *reinterpret_cast<float4*>(a.out + cell) = acc[j];
     const uint32_t mk = (uint32_t)mask_of(acc[j].x, a.fill) |
                         ((uint32_t)mask_of(acc[j].y, a.fill) << 8) |
                         ((uint32_t)mask_of(acc[j].z, a.fill) << 16) |
                         ((uint32_t)mask_of(acc[j].w, a.fill) << 24);
-    *reinterpret_cast<uint32_t*>(a.mask + (size_t)fc * M + cell) = mk;
+    *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+  }
+}
+
+// Batch fuse (north_star "projected+fused"): fused[c] = max/min over the frames
+// whose union window covers c of out[b][c]; frames that do not cover c hold the
+// fill value there, so they cannot change the result and are never read.
+struct FuseArgs {
+  int B, dc, mh, mw;
+  float fill;
+  const Window* unions;
+  const float* maps;          // (B, dc, mh, mw)
+  float* fused;               // (dc, mh, mw)
+  uint8_t* fused_mask;
+};
+
+constexpr int kFuseGroups = 32;     // float4 groups of the fused map per block
+constexpr int kFuseLanes = 8;       // threads sharing one group, frames b = lane (mod 8)
+
+// Block = 32 groups x 8 frame lanes.  Each thread tests the unions of its frames
+// (lane, lane + 8, ...) eight at a time, loads the covered maps (independent
+// 16-byte loads), and the 8 partial results of a group are combined through LDS.
+template <bool IS_MAX>
+__global__ void __launch_bounds__(kFuseGroups * kFuseLanes)
+k_fuse_unions(FuseArgs a) {
+  __shared__ float4 part[kFuseLanes][kFuseGroups];
+  const int ch = blockIdx.y;
+  const int g4 = a.mw >> 2;
+  const int gi = threadIdx.x & (kFuseGroups - 1), lane = threadIdx.x / kFuseGroups;
+  const int g = blockIdx.x * kFuseGroups + gi;
+  const bool live = g < g4 * a.mh;
+  const int z = live ? g / g4 : 0, x = live ? (g - z * g4) << 2 : 0;
+  const size_t M = (size_t)a.mh * a.mw;
+  const size_t cell = (size_t)z * a.mw + x;
+  float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+  for (int b0 = lane; b0 < a.B; b0 += 8 * kFuseLanes) {
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int bb = b0 + k * kFuseLanes;
+      v[k] = acc;
+      if (bb < a.B) {
+        const Window U = a.unions[bb];
+        if ((unsigned)(z - U.z0) < (unsigned)U.h && (unsigned)(x - U.x0) < (unsigned)U.w)
+          v[k] = *reinterpret_cast<const float4*>(a.maps + ((size_t)bb * a.dc + ch) * M + cell);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc.x = IS_MAX ? fmaxf(acc.x, v[k].x) : fminf(acc.x, v[k].x);
+      acc.y = IS_MAX ? fmaxf(acc.y, v[k].y) : fminf(acc.y, v[k].y);
+      acc.z = IS_MAX ? fmaxf(acc.z, v[k].z) : fminf(acc.z, v[k].z);
+      acc.w = IS_MAX ? fmaxf(acc.w, v[k].w) : fminf(acc.w, v[k].w);
+    }
+  }
+  part[lane][gi] = acc;
+  __syncthreads();
+  if (lane == 0 && live) {
+#pragma unroll
+    for (int k = 1; k < kFuseLanes; ++k) {
+      const float4 o = part[k][gi];
+      acc.x = IS_MAX ? fmaxf(acc.x, o.x) : fminf(acc.x, o.x);
+      acc.y = IS_MAX ? fmaxf(acc.y, o.y) : fminf(acc.y, o.y);
+      acc.z = IS_MAX ? fmaxf(acc.z, o.z) : fminf(acc.z, o.z);
+      acc.w = IS_MAX ? fmaxf(acc.w, o.w) : fminf(acc.w, o.w);
+    }
+    *reinterpret_cast<float4*>(a.fused + (size_t)ch * M + cell) = acc;
+    const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+                        ((uint32_t)mask_of(acc.z, a.fill) << 16) |
+                        ((uint32_t)mask_of(acc.w, a.fill) << 24);
+    *reinterpret_cast<uint32_t*>(a.fused_mask + (size_t)ch * M + cell) = mk;
   }
 }
 
@@ -425,26 +570,27 @@ size_t window_workspace_bytes(const dm_params& p) {
   size_t cap = (size_t)p.mh * p.mw;
   if (cap > kMaxLdsBytes / 4) cap = kMaxLdsBytes / 4;
   return align_up((size_t)p.B * sizeof(dm_frame), 256) +
-         align_up((size_t)p.B * nparts * sizeof(Window), 256) +
+         align_up((size_t)p.B * (nparts + 1) * sizeof(Window), 256) +
          (size_t)p.B * p.dc * nparts * align_up(cap, 4) * 4;
 }
 
 // Returns hipErrorNotSupported when some window does not fit in LDS (the caller
 // then takes the generic path); nothing has been enqueued in that case.
 hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const float* depth,
-                      const uint8_t* valid, float* out, uint8_t* mask, void* ws,
-                      hipStream_t s) {
+                      const uint8_t* valid, float* out, uint8_t* mask, float* fused,
+                      uint8_t* fused_mask, void* ws, hipStream_t s) {
   const Parts parts = choose_parts(p);
   const int nparts = parts.pc * parts.pr;
   if ((long)p.B * p.dc > 65535) return hipErrorNotSupported;
   if (reinterpret_cast<uintptr_t>(out) % 16 != 0 || reinterpret_cast<uintptr_t>(mask) % 4 != 0 ||
-      reinterpret_cast<uintptr_t>(ws) % 256 != 0)
+      reinterpret_cast<uintptr_t>(ws) % 256 != 0 || reinterpret_cast<uintptr_t>(fused) % 16 != 0 ||
+      reinterpret_cast<uintptr_t>(fused_mask) % 4 != 0)
     return hipErrorNotSupported;
   // host staging (thread-local: hipMemcpyAsync from pageable memory has copied
   // the bytes out by the time it returns)
   thread_local std::vector<unsigned char> staging;
   const size_t frames_bytes = align_up((size_t)p.B * sizeof(dm_frame), 256);
-  const size_t win_bytes = align_up((size_t)p.B * nparts * sizeof(Window), 256);
+  const size_t win_bytes = align_up((size_t)p.B * (nparts + 1) * sizeof(Window), 256);
   staging.resize(frames_bytes + win_bytes);
   memcpy(staging.data(), frames_host, (size_t)p.B * sizeof(dm_frame));
   if (!p.to_global) {     // local map: neutral yaw, no translation (exact: x*1 + z*0 + 0)
@@ -456,8 +602,10 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     }
   }
   Window* wins = reinterpret_cast<Window*>(staging.data() + frames_bytes);
-  int max_area = 0;
-  for (int b = 0; b < p.B; ++b)
+  Window* unions = wins + (size_t)p.B * nparts;       // (B): bounding box of a frame's windows
+  int max_area = 0, max_union = 0;
+  for (int b = 0; b < p.B; ++b) {
+    int ux0 = p.mw, ux1 = 0, uz0 = p.mh, uz1 = 0;
     for (int pr = 0; pr < parts.pr; ++pr)
       for (int pc = 0; pc < parts.pc; ++pc) {
         const int q0 = pc * parts.wp, r0 = pr * parts.hp;
@@ -466,8 +614,17 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
         const Window w = part_window(p, frames_host[b], q0, q1, r0, r1);
         wins[(size_t)b * nparts + pr * parts.pc + pc] = w;
         if (w.w * w.h > max_area) max_area = w.w * w.h;
+        if (w.w > 0) {
+          if (w.x0 < ux0) ux0 = w.x0;
+          if (w.x0 + w.w > ux1) ux1 = w.x0 + w.w;
+          if (w.z0 < uz0) uz0 = w.z0;
+          if (w.z0 + w.h > uz1) uz1 = w.z0 + w.h;
+        }
       }
-  if ((size_t)max_area * 4 > (size_t)kMaxLdsBytes) return hipErrorNotSupported;
+    unions[b] = ux1 > ux0 ? Window{ux0, uz0, ux1 - ux0, uz1 - uz0} : Window{0, 0, 0, 0};
+    if (unions[b].w * unions[b].h > max_union) max_union = unions[b].w * unions[b].h;
+  }
+  if ((size_t)max_area * 4 + 64 * 4 + 16 > (size_t)kMaxLdsBytes) return hipErrorNotSupported;
   const int slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 4);
   hipError_t e;
 
@@ -500,16 +657,18 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
   sa.windows = reinterpret_cast<const Window*>(base + frames_bytes);
   sa.depth = depth; sa.valid = valid;
   sa.slabs = reinterpret_cast<float*>(base + frames_bytes + win_bytes);
+  sa.unions = sa.windows + (size_t)p.B * nparts;
+  sa.out = out; sa.mask = mask; sa.mh = p.mh; sa.mw = p.mw;
 
   const bool is_max = p.reduction == DM_REDUCE_MAX;
   const bool fast = fast_div && axis_aligned(reinterpret_cast<const dm_frame*>(staging.data()), p.B);
   const bool has_valid = valid != nullptr;
   const bool vec4 = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(depth) % 16 == 0) &&
                     (parts.wp % 4 == 0);
-  const size_t lds_bytes = align_up((size_t)slab_stride * 4, 16);
+  const size_t lds_bytes = align_up((size_t)slab_stride * 4, 16) + 64 * 4;   // + dummy cells
   dim3 grid(nparts, p.dc, p.B);
 
-  if (max_area > 0) {
+  {
     using Kernel = void (*)(ScatterArgs);
     // [is_max][fast][has_valid][vec4]
     static const Kernel table[2][2][2][2] = {
@@ -530,15 +689,26 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     if (e != hipSuccess) return e;
   }
 
-  MergeArgs ma;
-  ma.B = p.B; ma.dc = p.dc; ma.mh = p.mh; ma.mw = p.mw;
-  ma.nparts = nparts; ma.slab_stride = slab_stride; ma.fill = p.fill;
-  ma.windows = sa.windows; ma.slabs = sa.slabs; ma.out = out; ma.mask = mask;
-  const size_t M = (size_t)p.mh * p.mw;
-  const int per_block = kMergeThreads * 4 * kMergeGroups;
-  dim3 g((unsigned)((M + per_block - 1) / per_block), p.B * p.dc);
-  if (is_max) hipLaunchKernelGGL(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma);
-  else hipLaunchKernelGGL(k_window_merge<false>, g, dim3(kMergeThreads), 0, s, ma);
+  if (max_union > 0) {
+    MergeArgs ma;
+    ma.B = p.B; ma.dc = p.dc; ma.mh = p.mh; ma.mw = p.mw;
+    ma.nparts = nparts; ma.slab_stride = slab_stride; ma.fill = p.fill;
+    ma.windows = sa.windows; ma.unions = sa.unions; ma.slabs = sa.slabs;
+    ma.out = out; ma.mask = mask;
+    const int per_block = kMergeThreads * kMergeGroups;          // float4 groups
+    dim3 g((unsigned)((max_union / 4 + per_block - 1) / per_block), p.B * p.dc);
+    if (is_max) hipLaunchKernelGGL(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma);
+    else hipLaunchKernelGGL(k_window_merge<false>, g, dim3(kMergeThreads), 0, s, ma);
+  }
+  if (fused) {
+    FuseArgs fa;
+    fa.B = p.B; fa.dc = p.dc; fa.mh = p.mh; fa.mw = p.mw; fa.fill = p.fill;
+    fa.unions = sa.unions; fa.maps = out; fa.fused = fused; fa.fused_mask = fused_mask;
+    dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kFuseGroups - 1) / kFuseGroups), p.dc);
+    const dim3 blk(kFuseGroups * kFuseLanes);
+    if (is_max) hipLaunchKernelGGL(k_fuse_unions<true>, g, blk, 0, s, fa);
+    else hipLaunchKernelGGL(k_fuse_unions<false>, g, blk, 0, s, fa);
+  }
   return hipGetLastError();
 }
 

@@ -1,47 +1,104 @@
-"""Host-side camera state -> device ``dm_frame`` table.
+"""Host-side camera state -> ``dm_frame`` table.
 
 The HIP kernels never evaluate sin/cos: the two Rodrigues matrices of every
-frame are built here, on the CPU, in float32 with the reference's op order
-(reference utils.py:303-327 via ``utils.rotation_matrix``) and shipped to the
-library as one (B, 32) float32 host table (``dm_frame`` in
-include/dungeon_maps_amd.h), which stages it to the GPU on the call's stream.
-That is what makes the integer cell indices reproduce the reference's CPU path
-bit for bit regardless of the device's libm.
+frame are built here, on the CPU, in float32, and handed to the library as one
+(B, 32) float32 host table (``dm_frame`` in include/dungeon_maps_amd.h), which
+stages it to the GPU on the call's stream.  That is what makes the integer cell
+indices reproduce the reference's CPU path bit for bit regardless of the
+device's libm.
+
+The matrices are those of reference utils.py:303-327,
+``R = (I + sin(a) S) + (1 - cos(a)) S^2`` evaluated element-wise in float32,
+specialised to the two axes the projector uses (maps.py:790, 885):
+
+  about X (pitch):  [[1, 0, 0], [0, d, -s], [0, s, d]]
+  about Y (yaw):    [[d, 0, s], [0, 1, 0], [-s, 0, d]]      d = 1 - (1 - cos a)
+
+with ``a`` clamped to 0 when |a| <= 1e-3 and sin/cos taken from torch's CPU
+kernels (the libm the reference itself calls).  tests/test_host_api.py checks
+this closed form against ``utils.rotation_matrix`` (the generic op-for-op
+version) and against the reference-generated fixture.
 """
 from typing import Optional
 
+import numpy as np
 import torch
 
-from . import utils
 from ._native import FRAME_FLOATS
 
-_AXIS_X = torch.tensor([[1., 0., 0.]])
-_AXIS_Y = torch.tensor([[0., 1., 0.]])
+_F32 = np.float32
+_ONE = np.float32(1.0)
+_ANGLE_EPS = np.float32(0.001)   # reference utils.py:47
 
 
-def _column(value, batch: int, width: Optional[int] = None) -> torch.Tensor:
-  """CPU float32 (batch,) or (batch, width) column from a scalar / list /
+def _is_scalar(v) -> bool:
+  return isinstance(v, (int, float, np.floating, np.integer))
+
+
+def _column(value, batch: int, width: Optional[int] = None) -> np.ndarray:
+  """float32 (batch,) or (batch, width) array from a scalar / list / array /
   tensor that has either 1 or ``batch`` rows."""
-  t = utils.to_tensor(value).detach().to(device="cpu", dtype=torch.float32)
-  t = t.reshape(-1) if width is None else t.reshape(-1, width)
-  if t.shape[0] == 1 and batch != 1:
-    t = t.expand(batch, *t.shape[1:])
-  if t.shape[0] != batch:
-    raise ValueError(f"per-frame argument has {t.shape[0]} rows, expected 1 or {batch}")
-  return t
+  if torch.is_tensor(value):
+    value = value.detach().to(device="cpu", dtype=torch.float32).numpy()
+  a = np.asarray(value, dtype=_F32)
+  a = a.reshape(-1) if width is None else a.reshape(-1, width)
+  if a.shape[0] == 1 and batch != 1:
+    a = np.broadcast_to(a, (batch,) + a.shape[1:])
+  if a.shape[0] != batch:
+    raise ValueError(f"per-frame argument has {a.shape[0]} rows, expected 1 or {batch}")
+  return a
+
+
+def _sin_cos(angles: np.ndarray):
+  """float32 sin/cos with torch's CPU kernels; |a| <= eps clamps to 0."""
+  a = np.array(angles, dtype=_F32)            # private, contiguous copy
+  a[np.abs(a) <= _ANGLE_EPS] = 0.0
+  t = torch.from_numpy(a)
+  return torch.sin(t).numpy(), torch.cos(t).numpy()
+
+
+_scalar_terms = {}   # angle (python float) -> (sin, 1 - (1 - cos)) as float32
+
+
+def _terms(angle, batch: int):
+  """(s, d) of reference utils.py:326 for a scalar or per-frame angle."""
+  if _is_scalar(angle):
+    key = float(angle)
+    hit = _scalar_terms.get(key)
+    if hit is None:
+      s, c = _sin_cos(np.array([key], dtype=_F32))
+      hit = (s[0], _ONE - (_ONE - c[0]))
+      if len(_scalar_terms) < 4096:
+        _scalar_terms[key] = hit
+    return hit
+  s, c = _sin_cos(_column(angle, batch))
+  return s, _ONE - (_ONE - c)            # (1 + sin*0) + (1 - cos) * (-1), float32
 
 
 def build_frame_table(batch: int, cam_pose, cam_pitch, cam_height, width_offset,
                       height_offset) -> torch.Tensor:
   """(batch, 32) float32 CPU tensor laid out as ``dm_frame``:
   [0:9] Rp, [9] cam_height, [10:19] Ry, [19] tx, [20] tz, [21] woff, [22] hoff."""
-  pose = _column([0., 0., 0.] if cam_pose is None else cam_pose, batch, 3)
-  table = torch.zeros((batch, FRAME_FLOATS), dtype=torch.float32)
-  table[:, 0:9] = utils.rotation_matrix(_AXIS_X, _column(cam_pitch, batch)).reshape(batch, 9)
-  table[:, 9] = _column(cam_height, batch)
-  table[:, 10:19] = utils.rotation_matrix(_AXIS_Y, pose[:, 2]).reshape(batch, 9)
-  table[:, 19] = pose[:, 0]
-  table[:, 20] = pose[:, 1]
-  table[:, 21] = _column(width_offset, batch)
-  table[:, 22] = _column(height_offset, batch)
-  return table
+  table = np.zeros((batch, FRAME_FLOATS), dtype=_F32)
+  sp, dp = _terms(cam_pitch, batch)
+  table[:, 0] = _ONE
+  table[:, 4] = dp
+  table[:, 5] = -sp
+  table[:, 7] = sp
+  table[:, 8] = dp
+  table[:, 9] = cam_height if _is_scalar(cam_height) else _column(cam_height, batch)
+  if cam_pose is None:
+    table[:, 10] = _ONE
+    table[:, 18] = _ONE
+  else:
+    pose = _column(cam_pose, batch, 3)
+    sy, dy = _terms(pose[:, 2], batch)
+    table[:, 10] = dy
+    table[:, 12] = sy
+    table[:, 16] = -sy
+    table[:, 18] = dy
+    table[:, 19:21] = pose[:, 0:2]
+  table[:, 14] = _ONE
+  table[:, 21] = width_offset if _is_scalar(width_offset) else _column(width_offset, batch)
+  table[:, 22] = height_offset if _is_scalar(height_offset) else _column(height_offset, batch)
+  return torch.from_numpy(table)

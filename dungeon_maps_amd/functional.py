@@ -20,7 +20,7 @@ from . import _native, frames, utils
 from .utils import NINF, Reduction
 
 __all__ = [
-    "CenterMode", "get", "orth_project", "orth_project_fused", "fuse_batch", "mask_from_map", "camera_affine_grid",
+    "CenterMode", "get", "orth_project", "orth_project_and_fuse", "orth_project_fused", "fuse_batch", "mask_from_map", "camera_affine_grid",
     "depth_map_to_point_cloud", "height_map_to_point_cloud", "image_to_camera_space",
     "camera_to_image_space", "camera_to_local_space", "local_to_camera_space",
     "local_to_global_space", "global_to_local_space", "map_quantize",
@@ -80,8 +80,12 @@ def _stream_ptr(device: torch.device) -> int:
 
 
 def _image(x, device, dtype) -> torch.Tensor:
-  t = utils.to_4D_image(utils.to_tensor(x))
-  return t.to(device=device, dtype=dtype).contiguous()
+  t = x if torch.is_tensor(x) else utils.to_tensor(x)
+  if t.dim() != 4:
+    t = utils.to_4D_image(t)
+  if t.device != device or t.dtype != dtype:
+    t = t.to(device=device, dtype=dtype)
+  return t if t.is_contiguous() else t.contiguous()
 
 
 class _Call:
@@ -92,7 +96,7 @@ class _Call:
                focal_x, focal_y, center_x, center_y, trunc_depth_min, trunc_depth_max,
                trunc_height_max, clip_border, to_global, flip_h, fill_value, reduction,
                device):
-    first = utils.to_tensor(depth_map)
+    first = depth_map if torch.is_tensor(depth_map) else utils.to_tensor(depth_map)
     self.target = torch.device(device) if device is not None else first.device
     self.dev = _compute_device(self.target)
     self.depth = _image(first, self.dev, torch.float32)
@@ -116,36 +120,55 @@ class _Call:
       if self.valid.shape[0] != B:
         self.valid = self.valid.expand(B, -1, -1, -1).contiguous()
       valid_c = self.valid.shape[1]
-    p = _native.Params()
-    p.B, p.dc, p.vc, p.H, p.W = B, dc, vc, H, W
-    p.mh, p.mw = int(map_height), int(map_width)
-    p.clip_border = int(clip_border) if clip_border is not None else 0
-    p.flip_h = int(bool(flip_h))
-    p.to_global = int(bool(to_global))
-    p.reduction = _reduction_code(reduction)
-    p.has_dmin = int(trunc_depth_min is not None)
-    p.has_dmax = int(trunc_depth_max is not None)
-    p.has_hmax = int(trunc_height_max is not None)
-    p.valid_c = valid_c
-    p.cx, p.cy, p.fx, p.fy = float(center_x), float(center_y), float(focal_x), float(focal_y)
-    p.res = float(map_res)
-    # fill_value None: the reference scatters into an all-zero canvas (maps.py:320)
-    p.fill = 0.0 if fill_value is None else float(fill_value)
-    p.dmin = float(trunc_depth_min) if trunc_depth_min is not None else 0.0
-    p.dmax = float(trunc_depth_max) if trunc_depth_max is not None else 0.0
-    p.hmax = float(trunc_height_max) if trunc_height_max is not None else 0.0
-    self.params = p
+    key = (B, dc, vc, H, W, int(map_height), int(map_width),
+           int(clip_border) if clip_border is not None else 0, bool(flip_h), bool(to_global),
+           _reduction_code(reduction), trunc_depth_min, trunc_depth_max, trunc_height_max,
+           valid_c, float(center_x), float(center_y), float(focal_x), float(focal_y),
+           float(map_res), fill_value)
+    cached = _PARAMS_CACHE.get(key)
+    if cached is None:
+      cached = _make_params(key)
+      if len(_PARAMS_CACHE) < 256:
+        _PARAMS_CACHE[key] = cached
+    self.params, self.ws_bytes = cached
     self.oc = vc if vc else dc
     # host-side dm_frame table; the library stages it to the GPU inside the call
     self.frames = frames.build_frame_table(B, cam_pose, cam_pitch, cam_height, width_offset,
                                            height_offset)
 
   def workspace(self) -> Tuple[Optional[torch.Tensor], int]:
-    import ctypes
-    need = _native.lib().dm_orth_project_workspace_bytes(ctypes.byref(self.params))
-    if need == 0:
+    if self.ws_bytes == 0:
       return None, 0
-    return torch.empty(need, dtype=torch.uint8, device=self.dev), need
+    return torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev), self.ws_bytes
+
+
+_PARAMS_CACHE = {}   # call signature -> (dm_params, workspace bytes); both immutable afterwards
+
+
+def _make_params(key):
+  import ctypes
+  (B, dc, vc, H, W, mh, mw, clip, flip_h, to_global, red, dmin, dmax, hmax, valid_c, cx, cy,
+   fx, fy, res, fill) = key
+  p = _native.Params()
+  p.B, p.dc, p.vc, p.H, p.W = B, dc, vc, H, W
+  p.mh, p.mw = mh, mw
+  p.clip_border = clip
+  p.flip_h = int(flip_h)
+  p.to_global = int(to_global)
+  p.reduction = red
+  p.has_dmin = int(dmin is not None)
+  p.has_dmax = int(dmax is not None)
+  p.has_hmax = int(hmax is not None)
+  p.valid_c = valid_c
+  p.cx, p.cy, p.fx, p.fy = cx, cy, fx, fy
+  p.res = res
+  # fill_value None: the reference scatters into an all-zero canvas (maps.py:320)
+  p.fill = 0.0 if fill is None else float(fill)
+  p.dmin = float(dmin) if dmin is not None else 0.0
+  p.dmax = float(dmax) if dmax is not None else 0.0
+  p.hmax = float(hmax) if hmax is not None else 0.0
+  need = _native.lib().dm_orth_project_workspace_bytes(ctypes.byref(p))
+  return p, int(need)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -160,7 +183,7 @@ def orth_project(
     clip_border: Optional[int], to_global: bool, flip_h: bool = True,
     fill_value: Optional[float] = None, reduction: Optional[Reduction] = None,
     get_height_map: bool = False, device: Optional[torch.device] = None,
-    _validate_args: bool = True
+    _validate_args: bool = True, _fuse: bool = False
 ) -> Union[Tuple[torch.Tensor, torch.Tensor],
            Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
   """Orthographic projection of depth maps (b, c, h, w) to top-down maps.
@@ -187,20 +210,47 @@ def orth_project(
   height = None
   if get_height_map and p.vc:
     height = torch.empty((p.B, p.dc, p.mh, p.mw), dtype=torch.float32, device=call.dev)
+  fused = fmask = None
+  if _fuse:
+    fused = torch.empty(shape[1:], dtype=torch.float32, device=call.dev)
+    fmask = torch.empty(shape[1:], dtype=torch.bool, device=call.dev)
   ws, ws_bytes = call.workspace()
   with torch.cuda.device(call.dev):
     _native.check(_native.lib().dm_orth_project_f32(
         ctypes.byref(p), _ptr(call.frames), _ptr(call.depth), _ptr(call.value),
-        _ptr(call.valid), _ptr(topdown), _ptr(mask), _ptr(height), _ptr(ws), ws_bytes,
-        _stream_ptr(call.dev)))
+        _ptr(call.valid), _ptr(topdown), _ptr(mask), _ptr(height), _ptr(fused), _ptr(fmask),
+        _ptr(ws), ws_bytes, _stream_ptr(call.dev)))
   if call.target != call.dev:
     topdown, mask = topdown.to(call.target), mask.to(call.target)
     height = None if height is None else height.to(call.target)
+    if _fuse:
+      fused, fmask = fused.to(call.target), fmask.to(call.target)
+  if _fuse:
+    return topdown, mask, fused, fmask
   if not get_height_map:
     return topdown, mask
   if height is None:
     return topdown, mask, topdown
   return topdown, mask, torch.broadcast_to(height, topdown.shape)
+
+
+def orth_project_and_fuse(depth_map, value_map, valid_map, cam_pose, width_offset,
+                          height_offset, cam_pitch, cam_height, map_res, map_width, map_height,
+                          focal_x, focal_y, center_x, center_y, trunc_depth_min,
+                          trunc_depth_max, trunc_height_max, clip_border, to_global=True,
+                          flip_h=True, fill_value=NINF, reduction=None, device=None
+                          ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+  """``orth_project`` plus the batch-fused map in the same launch sequence:
+  returns ``(topdown (b,C,mh,mw), mask, fused (C,mh,mw), fused_mask)`` with
+  ``fused = max (or min) over the batch axis of topdown`` -- what the
+  reference's MapBuilder.merge computes for maps that share one frame
+  (element-wise max).  The fused map of each rank is what a
+  multi-GPU job all-reduces (``parallel.all_reduce_fused``)."""
+  return orth_project(depth_map, value_map, valid_map, cam_pose, width_offset, height_offset,
+                      cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
+                      center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
+                      clip_border, to_global, flip_h, fill_value, reduction, False, device,
+                      True, _fuse=True)
 
 
 def orth_project_fused(

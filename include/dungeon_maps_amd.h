@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 1
+#define DM_ABI_VERSION 2
 
 typedef enum dm_status {
   DM_OK = 0,
@@ -108,12 +108,18 @@ size_t dm_orth_project_workspace_bytes(const dm_params* p);
  *   height_dev (B, dc, mh, mw) f32 or NULL: the second, NINF/max projection
  *              of maps.py:332-350 (only meaningful when vc > 0; with vc == 0
  *              the height map IS out, maps.py:333-334)
+ *   fused_dev / fused_mask_dev (oc, mh, mw) f32 / u8, or both NULL: the maps
+ *              of the B frames fused into one (max or min over the batch axis
+ *              -- MapBuilder.merge / fuse_topdown_maps, maps.py:2181-2287,
+ *              2471-2508, for maps sharing one frame) and its mask.
+ *              The per-rank partial of the "projected+fused" metric.
  * Outputs are fully written (no pre-initialisation needed).
  */
 int dm_orth_project_f32(const dm_params* p, const dm_frame* frames,
                         const float* depth_dev, const float* value_dev,
                         const uint8_t* valid_dev, float* out_dev,
                         uint8_t* mask_dev, float* height_dev,
+                        float* fused_dev, uint8_t* fused_mask_dev,
                         void* workspace_dev, size_t workspace_bytes,
                         void* stream);
 

@@ -204,6 +204,16 @@ def test_fused_equals_max_over_frames(dmap, oracle):
   assert torch.equal(dmap.fuse_batch(per_frame, "max"), fused)
   assert torch.equal(dmap.fuse_batch(per_frame[3:], "max", out=dmap.fuse_batch(per_frame[:3])),
                      fused)
+  # per-frame maps + fused map from one launch sequence (fast path and generic path)
+  from dungeon_maps_amd import _native
+  for force in (0, 1):
+    _native.lib().dm_debug_force_generic_path(force)
+    try:
+      t2, m2, f2, fm2 = proj.orth_project_and_fuse(d, cam_pose=pose)
+    finally:
+      _native.lib().dm_debug_force_generic_path(0)
+    assert torch.equal(t2, per_frame) and torch.equal(m2, pmask)
+    assert torch.equal(f2, fused) and torch.equal(fm2, fmask)
   odd = torch.randn(5, 3, 7, 11, device="cuda")
   assert torch.equal(dmap.fuse_batch(odd, "min"), odd.amin(dim=0))
 
@@ -231,6 +241,13 @@ def test_full_size_properties(dmap):
     assert torch.equal(t1[0], top[b]) and torch.equal(m1[0], mask[b])
   assert torch.equal(mask, torch.isfinite(top))                        # F9
   assert mask.any(dim=-1).any(dim=-1).all()                            # every frame hit
+  t2, m2, fused, fmask = proj.orth_project_and_fuse(d, cam_pose=p)
+  assert torch.equal(t2, top) and torch.equal(m2, mask)
+  assert torch.equal(fused, top.amax(dim=0)) and torch.equal(fmask, mask.any(dim=0))
+  # more than 64 frames: the fuse walks the union table in chunks of 64
+  d3 = torch.cat([d, d[:13]]); p3 = torch.cat([p, p[:13]])
+  t3, _, f3, _ = proj.orth_project_and_fuse(d3, cam_pose=p3)
+  assert torch.equal(f3, t3.amax(dim=0))
 
 
 # --------------------------------------------------------------------------

@@ -39,6 +39,25 @@ def test_intrinsics_match_reference():
     assert (ci.cx, ci.cy, ci.fx, ci.fy) == (cx, cy, fx, fy)
 
 
+def test_frame_table_closed_form_equals_generic_rodrigues():
+  """frames.build_frame_table's closed form == utils.rotation_matrix (the
+  op-for-op restatement of reference utils.py:303-327), incl. the clamp."""
+  g, _ = load_golden("g10_known_answers")
+  rng = np.random.default_rng(0)
+  ang = np.concatenate([g["angles"], rng.uniform(-7, 7, 5000).astype(np.float32),
+                        np.float32([0.001, -0.001, 0.0010001, 1e-4, 0.0, np.pi / 2, -np.pi / 2])])
+  n = len(ang)
+  pose = np.zeros((n, 3), dtype=np.float32)
+  pose[:, 2] = ang[::-1]
+  t = frames.build_frame_table(n, pose, ang, 0.5, 0.0, 0.0)
+  Rx = utils.rotation_matrix([1., 0., 0.], torch.from_numpy(ang)).reshape(n, 9)
+  Ry = utils.rotation_matrix([0., 1., 0.], torch.from_numpy(ang[::-1].copy())).reshape(n, 9)
+  np.testing.assert_array_equal(t[:, 0:9].numpy(), Rx.numpy())
+  np.testing.assert_array_equal(t[:, 10:19].numpy(), Ry.numpy())
+  k = len(g["angles"])
+  np.testing.assert_array_equal(t[:k, 0:9].numpy().reshape(k, 3, 3), g["Rx"])
+
+
 def test_frame_table_layout_and_broadcast():
   pose = np.array([[0.1, 0.2, 0.3], [0.4, 0.5, -0.6]], dtype=np.float32)
   t = frames.build_frame_table(2, pose, -0.35, [0.8, 0.9], 10.0, [1.0, 2.0])

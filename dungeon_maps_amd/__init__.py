@@ -9,6 +9,7 @@ hand-written HIP kernels for gfx950 behind a C ABI
 from . import utils
 from . import functional
 from . import maps
+from . import parallel
 
 from .maps import *  # noqa: F401,F403
 from .maps import MapProjector, TopdownMap, MapBuilder, crop_topdown_map, fuse_topdown_maps

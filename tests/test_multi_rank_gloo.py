@@ -1,0 +1,82 @@
+"""The N > 1 path on CPU: world_size-2 gloo processes shard a batch, build their
+partial global maps, fuse them with parallel.all_reduce_fused and must end up
+with exactly the single-process result (max is exact, so bit-identical).
+
+No GPU here: each rank's partial map comes from the CPU oracle (the checker),
+the collective and the sharding logic are the product's."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(oracle):
+  H, W, mh, mw = 48, 64, 96, 96
+  cx, cy, fx, fy = oracle.camera_intrinsics(W, H, np.radians(70.))
+  return dict(width_offset=mw / 2., height_offset=mh / 2., cam_pitch=np.radians(-20.),
+              cam_height=0.88, map_res=0.1, map_width=mw, map_height=mh, focal_x=fx,
+              focal_y=fy, center_x=cx, center_y=cy, trunc_depth_min=0.15,
+              trunc_depth_max=5.05, to_global=True, fill_value=-np.inf)
+
+
+def _inputs(B=7, H=48, W=64):
+  g = torch.Generator().manual_seed(42)
+  depth = torch.empty(B, 1, H, W).uniform_(0.1, 8.0, generator=g).numpy()
+  pose = torch.empty(B, 3).uniform_(-1, 1, generator=g).numpy()
+  return depth, pose
+
+
+def _worker(rank, world, port, out_dir):
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  from oracle import oracle
+  from dungeon_maps_amd import parallel
+  depth, pose = _inputs()
+  lo, hi = parallel.shard_range(len(depth), rank, world)
+  part, _ = oracle.orth_project(depth[lo:hi], cam_pose=pose[lo:hi], fused=True, **_cfg(oracle))
+  fused = torch.from_numpy(part.copy())
+  parallel.all_reduce_fused(fused, "max")
+  np.save(os.path.join(out_dir, f"fused_{rank}.npy"), fused.numpy())
+  with pytest.raises(ValueError):
+    parallel.all_reduce_fused(fused, "sum")
+  dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank(oracle, tmp_path):
+  world = 2
+  port = 29500 + os.getpid() % 2000
+  mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+  depth, pose = _inputs()
+  want, wmask = oracle.orth_project(depth, cam_pose=pose, fused=True, **_cfg(oracle))
+  for r in range(world):
+    got = np.load(tmp_path / f"fused_{r}.npy")
+    np.testing.assert_array_equal(got, want)
+    # mask = f(map, fill): recomputed locally after the all-reduce
+    np.testing.assert_array_equal(np.isfinite(got), wmask)
+
+
+def test_shard_range_partitions_the_batch():
+  from dungeon_maps_amd import parallel
+  for n in (0, 1, 7, 64, 513):
+    for world in (1, 2, 3, 8):
+      spans = [parallel.shard_range(n, r, world) for r in range(world)]
+      assert spans[0][0] == 0 and spans[-1][1] == n
+      assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+      sizes = [b - a for a, b in spans]
+      assert max(sizes) - min(sizes) <= 1
+  with pytest.raises(ValueError):
+    parallel.shard_range(4, 2, 2)
+
+
+def test_single_process_all_reduce_is_identity():
+  from dungeon_maps_amd import parallel
+  t = torch.randn(1, 4, 4)
+  assert parallel.all_reduce_fused(t.clone(), None).equal(t)

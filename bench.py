@@ -118,17 +118,23 @@ def main():
       trunc_depth_min=0.15, trunc_depth_max=5.05, clip_border=0, to_global=True,
       fill_value=fill, reduction="max")
 
+  # HIP events on the launch stream (torch's current stream): before the call and,
+  # through the library's measurement hook, right after the kernels that produce the
+  # per-frame maps + masks (i.e. before the batch fuse).
   ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
   ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+  for e in ev_b:
+    e.record()                 # materialise the hipEvent_t handles
+  torch.cuda.synchronize()
+  lib = _native.lib()
 
   def step(i=None):
     if i is not None:
       ev_a[i].record()
+      lib.dm_debug_record_after_projection(ev_b[i].cuda_event)
     # per-frame maps + masks and this rank's partial global map, one launch sequence
     top, mask, fused, fmask = proj.orth_project_and_fuse(depth_d, value_map=value_d,
                                                          cam_pose=pose)
-    if i is not None:
-      ev_b[i].record()
     if dist is not None:
       dist.all_reduce(fused, op=dist.ReduceOp.MAX)      # RCCL, element-wise max
       fmask = dmap.mask_from_map(fused, fill)
@@ -185,7 +191,9 @@ def main():
           "unit": "GB/s",
           "frac": achieved / HBM_PEAK_GBS,
           "traffic": None,
-          "kernel": "orth_project launch sequence (dm_orth_project_f32)",
+          "kernel": "orth_project launch sequence of dm_orth_project_f32: frame-table copy + "
+                    "k_window_scatter + k_window_merge (everything that produces the "
+                    "per-frame maps and masks; the batch fuse that follows is excluded)",
           "algorithmic_bytes_per_launch": alg,
           "launch_us": kernel_s * 1e6,
           "launch_us_min": float(proj_ms.min()) * 1e3,

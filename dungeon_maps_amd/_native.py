@@ -46,6 +46,23 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dm_debug_force_generic_path": (ctypes.c_int, [ctypes.c_int]),
+    "dm_debug_record_after_projection": (None, [ctypes.c_void_p]),
+    "dm_camera_affine_grid_f32": (ctypes.c_int, [
+        ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "dm_affine_points_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_size_t,
+        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "dm_map_quantize_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+        ctypes.c_size_t, ctypes.c_float, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p]),
+    "dm_scatter_workspace_bytes": (ctypes.c_size_t, [
+        ctypes.c_int64, ctypes.c_int32, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32]),
+    "dm_scatter_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+        ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_float,
+        ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dm_fuse_batch_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_int, ctypes.c_void_p]),

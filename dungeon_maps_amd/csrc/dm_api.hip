@@ -9,6 +9,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 thread_local int g_force_generic = 0;   // dm_debug_force_generic_path (tests)
+thread_local hipEvent_t g_mid_event = nullptr;   // dm_debug_record_after_projection (bench)
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -80,12 +81,15 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
                 need);
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipErrorNotSupported;
+  const hipEvent_t mid = g_mid_event;
+  g_mid_event = nullptr;
   if (dm::window_path_supported(*p) && !g_force_generic)
     e = dm::run_window(*p, frames, depth_dev, valid_dev, out_dev, mask_dev, fused_dev,
-                       fused_mask_dev, workspace_dev, s);
+                       fused_mask_dev, workspace_dev, mid, s);
   if (e == hipErrorNotSupported) { // nothing enqueued: a window exceeds LDS, odd alignment, ...
     e = dm::run_generic(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
                         p->vc ? height_dev : nullptr, workspace_dev, s);
+    if (e == hipSuccess && mid) e = hipEventRecord(mid, s);
     if (e == hipSuccess && fused_dev) {
       const size_t n = (size_t)(p->vc ? p->vc : p->dc) * p->mh * p->mw;
       e = dm::run_fuse_batch(out_dev, p->B, n, fused_dev, p->reduction == DM_REDUCE_MAX, 0, s);
@@ -121,6 +125,85 @@ int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames,
                                        static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
   return DM_OK;
+}
+
+int dm_camera_affine_grid_f32(const dm_params* p, const dm_frame* frames, const float* depth_dev,
+                              float* grid_dev, void* workspace_dev, size_t workspace_bytes,
+                              void* stream) {
+  if (!p) return fail(DM_ERR_INVALID_ARGUMENT, "params is NULL");
+  if (p->B < 0 || p->dc < 1 || p->H < 1 || p->W < 1 || p->B > 65535 || p->dc > 65535 ||
+      (int64_t)p->H * p->W >= (1ll << 31))
+    return fail(DM_ERR_INVALID_ARGUMENT, "bad shape B=%d dc=%d H=%d W=%d", p->B, p->dc, p->H, p->W);
+  if (p->B == 0) return DM_OK;
+  if (!frames || !depth_dev || !grid_dev)
+    return fail(DM_ERR_INVALID_ARGUMENT, "frames/depth/grid must not be NULL");
+  if (!workspace_dev || workspace_bytes < (size_t)p->B * sizeof(dm_frame))
+    return fail(DM_ERR_WORKSPACE_TOO_SMALL, "workspace %zu B < required %zu B", workspace_bytes,
+                (size_t)p->B * sizeof(dm_frame));
+  hipError_t e = dm::run_camera_affine_grid(*p, frames, depth_dev, grid_dev, workspace_dev,
+                                            static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
+int dm_affine_points_f32(const float* pts_dev, const float* R_dev, const float* t_dev, int64_t B,
+                         size_t n, int translate_first, float* out_dev, void* stream) {
+  if (B < 0 || B > 65535) return fail(DM_ERR_INVALID_ARGUMENT, "bad batch %lld", (long long)B);
+  if (B == 0 || n == 0) return DM_OK;
+  if (!pts_dev || !R_dev || !t_dev || !out_dev)
+    return fail(DM_ERR_INVALID_ARGUMENT, "pts/R/t/out must not be NULL");
+  hipError_t e = dm::run_affine_points(pts_dev, R_dev, t_dev, (int)B, n, translate_first, out_dev,
+                                       static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
+int dm_map_quantize_f32(const float* x_dev, const float* z_dev, const float* woff_dev,
+                        const float* hoff_dev, int64_t B, size_t n, float res, int32_t map_height,
+                        int32_t flip_h, int64_t* xb_dev, int64_t* zb_dev, void* stream) {
+  if (B < 0 || B > 65535) return fail(DM_ERR_INVALID_ARGUMENT, "bad batch %lld", (long long)B);
+  if (B == 0 || n == 0) return DM_OK;
+  if (!x_dev || !z_dev || !woff_dev || !hoff_dev || !xb_dev || !zb_dev)
+    return fail(DM_ERR_INVALID_ARGUMENT, "x/z/offsets/outputs must not be NULL");
+  hipError_t e = dm::run_map_quantize(x_dev, z_dev, woff_dev, hoff_dev, (int)B, n, res, map_height,
+                                      flip_h != 0, reinterpret_cast<long long*>(xb_dev),
+                                      reinterpret_cast<long long*>(zb_dev),
+                                      static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
+size_t dm_scatter_workspace_bytes(int64_t R, int32_t C, size_t M, int32_t has_fill,
+                                  int32_t reduction) {
+  if (R <= 0 || C <= 0) return 0;
+  return dm::scatter_workspace_bytes((size_t)R * C, M, has_fill, reduction);
+}
+
+int dm_scatter_f32(const float* values_dev, const int64_t* index_dev, float* canvas_dev,
+                   uint8_t* mask_dev, int64_t R, int32_t C, int32_t Ci, size_t N, size_t M,
+                   float fill, int32_t has_fill, int32_t reduction, void* workspace_dev,
+                   size_t workspace_bytes, void* stream) {
+  if (R < 0 || C < 1 || !(Ci == 1 || Ci == C))
+    return fail(DM_ERR_INVALID_ARGUMENT, "bad shape R=%lld C=%d Ci=%d", (long long)R, C, Ci);
+  if (reduction < DM_REDUCE_MAX || reduction > DM_REDUCE_PROD)
+    return fail(DM_ERR_INVALID_ARGUMENT, "unknown reduction %d", reduction);
+  if ((int64_t)R * C > 65535) return fail(DM_ERR_UNSUPPORTED, "R*C is limited to 65535 rows");
+  if (R == 0 || M == 0) return DM_OK;
+  if (!canvas_dev || !mask_dev || (N > 0 && (!values_dev || !index_dev)))
+    return fail(DM_ERR_INVALID_ARGUMENT, "values/index/canvas/mask must not be NULL");
+  const size_t need = dm_scatter_workspace_bytes(R, C, M, has_fill, reduction);
+  if (need > workspace_bytes || (need && !workspace_dev))
+    return fail(DM_ERR_WORKSPACE_TOO_SMALL, "workspace %zu B < required %zu B", workspace_bytes,
+                need);
+  hipError_t e = dm::run_scatter(values_dev, reinterpret_cast<const long long*>(index_dev),
+                                 canvas_dev, mask_dev, (int)R, C, Ci, N, M, fill, has_fill != 0,
+                                 reduction, workspace_dev, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
+void dm_debug_record_after_projection(void* event) {
+  g_mid_event = static_cast<hipEvent_t>(event);
 }
 
 int dm_debug_force_generic_path(int on) {

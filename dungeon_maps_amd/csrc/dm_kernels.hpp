@@ -21,10 +21,23 @@ bool window_path_supported(const dm_params& p);
 size_t window_workspace_bytes(const dm_params& p);
 hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const float* depth,
                       const uint8_t* valid, float* out, uint8_t* mask, float* fused,
-                      uint8_t* fused_mask, void* ws, hipStream_t s);
+                      uint8_t* fused_mask, void* ws, hipEvent_t after_projection, hipStream_t s);
 hipError_t run_fuse_batch(const float* maps, int B, size_t n, float* out, bool is_max,
                           int accumulate, hipStream_t s);
 hipError_t run_mask_from_map(const float* map, float fill, uint8_t* mask, size_t n,
                              hipStream_t s);
+
+// dm_points.hip -- exact point-set primitives (affine, quantise, flat scatter)
+hipError_t run_affine_points(const float* pts, const float* R, const float* t, int B,
+                             size_t n_per_batch, int translate_first, float* out, hipStream_t s);
+hipError_t run_map_quantize(const float* x, const float* z, const float* woff, const float* hoff,
+                            int B, size_t n_per_batch, float res, int map_height, int flip,
+                            long long* xb, long long* zb, hipStream_t s);
+hipError_t run_camera_affine_grid(const dm_params& p, const dm_frame* frames_host,
+                                  const float* depth, float* grid, void* ws, hipStream_t s);
+size_t scatter_workspace_bytes(size_t rows, size_t M, int has_fill, int reduction);
+hipError_t run_scatter(const float* values, const long long* index, float* canvas, uint8_t* mask,
+                       int R, int C, int Ci, size_t N, size_t M, float fill, int has_fill,
+                       int reduction, void* ws, hipStream_t s);
 
 }  // namespace dm

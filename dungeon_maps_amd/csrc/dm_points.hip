@@ -1,0 +1,243 @@
+// Point-set primitives with the reference's exact float32 semantics, for callers
+// that work on materialised tensors instead of the fused projector: map fusion
+// (fuse_topdown_maps), the public project()/scatter_tensor(), map_quantize() and
+// the space transforms on GPU tensors.  Low volume, latency-insensitive: simple
+// one-thread-per-element kernels, global atomics for the scatter.
+//
+//   k_affine_points   utils.rotate + utils.translate (utils.py:229-330):
+//                     out_i = fma(p2,R[6+i], fma(p1,R[3+i], p0*R[i])) (+ t_i),
+//                     translate before or after the rotation
+//   k_map_quantize    maps.py:944-1019 (true division, round half up, int64)
+//   k_scatter_flat    utils.scatter_tensor incl. the torch_scatter call
+//                     (utils.py:389-492) on pre-ravelled indices
+#include "dm_kernels.hpp"
+
+namespace dm {
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+k_affine_points(const float* __restrict__ pts, const float* __restrict__ R,
+                const float* __restrict__ t, int translate_first, size_t n_per_batch,
+                float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_per_batch) return;
+  const float* r = R + 9 * b;
+  const float* tb = t + 3 * b;
+  const float* p = pts + ((size_t)b * n_per_batch + i) * 3;
+  float p0 = p[0], p1 = p[1], p2 = p[2];
+  if (translate_first) { p0 += tb[0]; p1 += tb[1]; p2 += tb[2]; }
+  float o0 = __builtin_fmaf(p2, r[6], __builtin_fmaf(p1, r[3], p0 * r[0]));
+  float o1 = __builtin_fmaf(p2, r[7], __builtin_fmaf(p1, r[4], p0 * r[1]));
+  float o2 = __builtin_fmaf(p2, r[8], __builtin_fmaf(p1, r[5], p0 * r[2]));
+  if (!translate_first) { o0 += tb[0]; o1 += tb[1]; o2 += tb[2]; }
+  float* o = out + ((size_t)b * n_per_batch + i) * 3;
+  o[0] = o0; o[1] = o1; o[2] = o2;
+}
+
+// float -> int64 the way x86 does it for the reference's `.to(torch.int64)`:
+// NaN and out-of-range become INT64_MIN
+__device__ inline long long to_i64_x86(float f) {
+  if (!(f >= -9.2233720368547758e18f && f < 9.2233720368547758e18f)) return (long long)0x8000000000000000ull;
+  return (long long)f;
+}
+
+__global__ void __launch_bounds__(256)
+k_map_quantize(const float* __restrict__ x, const float* __restrict__ z,
+               const float* __restrict__ woff, const float* __restrict__ hoff, float res,
+               float mhm1, int flip, size_t n_per_batch, long long* __restrict__ xb,
+               long long* __restrict__ zb) {
+  const int b = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_per_batch) return;
+  const size_t k = (size_t)b * n_per_batch + i;
+  float xf = x[k] / res + woff[b];
+  float zf = z[k] / res + hoff[b];
+  if (flip) zf = mhm1 - zf;
+  xb[k] = to_i64_x86(__builtin_floorf(xf + 0.5f));
+  zb[k] = to_i64_x86(__builtin_floorf(zf + 0.5f));
+}
+
+__device__ inline void atomic_max_f(float* addr, float v) {
+  if (!(v == v)) return;
+  v += 0.0f;
+  if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ inline void atomic_min_f(float* addr, float v) {
+  if (!(v == v)) return;
+  v += 0.0f;
+  if (v >= 0.0f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ inline void atomic_mul_f(float* addr, float v) {
+  unsigned int* a = reinterpret_cast<unsigned int*>(addr);
+  unsigned int old = *a, assumed;
+  do {
+    assumed = old;
+    old = atomicCAS(a, assumed, __float_as_uint(__uint_as_float(assumed) * v));
+  } while (old != assumed);
+}
+
+// values (R, C, N); index (R, Ci, N) int64, Ci in {1, C}; canvas (R, C, M)
+__global__ void __launch_bounds__(256)
+k_scatter_flat(const float* __restrict__ values, const long long* __restrict__ index,
+               float* __restrict__ canvas, float* __restrict__ count, int C, int Ci, size_t N,
+               size_t M, int reduction) {
+  const int rc = blockIdx.y;                 // r * C + c
+  const int r = rc / C, c = rc - r * C;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const long long cell = index[((size_t)r * Ci + (Ci == 1 ? 0 : c)) * N + i];
+  if (cell < 0 || (unsigned long long)cell >= M) return;
+  const float v = values[(size_t)rc * N + i];
+  float* dst = canvas + (size_t)rc * M + cell;
+  switch (reduction) {
+    case DM_REDUCE_MAX: atomic_max_f(dst, v); break;
+    case DM_REDUCE_MIN: atomic_min_f(dst, v); break;
+    case DM_REDUCE_PROD: atomic_mul_f(dst, v); break;
+    default: atomicAdd(dst, v); break;
+  }
+  if (count) atomicAdd(count + (size_t)rc * M + cell, 1.0f);
+}
+
+// mask = changed (vs the constant fill or vs the saved copy); mean division
+__global__ void __launch_bounds__(256)
+k_scatter_finalize(float* __restrict__ canvas, const float* __restrict__ before, float fill,
+                   const float* __restrict__ count, uint8_t* __restrict__ mask, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float o = canvas[i];
+    if (count) {
+      const float c = count[i];
+      o = o / (c < 1.0f ? 1.0f : c);
+      canvas[i] = o;
+    }
+    mask[i] = mask_of(o, before ? before[i] : fill);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_fill1(float* __restrict__ a, float v, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = v;
+}
+
+// camera_affine_grid (maps.py:353-460): where does every pixel of frame t land
+// in the image of frame t+1 after the camera moved by trans_pose?  Pure map
+// kernel: 4 bytes in, 8 bytes out per pixel.  Chain (all float32, reference op
+// order): image_to_camera_space (616-682) -> camera_to_local_space (753-800)
+// -> local_to_global_space(trans_pose) (850-895) -> local_to_camera_space
+// (802-848: translate by (0,-h,0), rotate by -pitch) -> camera_to_image_space
+// (684-751: z_eps = z + 1e-7, x/z_eps*fx + cx, flip).
+__global__ void __launch_bounds__(256)
+k_camera_affine_grid(View v, int dc, const dm_frame* __restrict__ frames,
+                     const float* __restrict__ depth, float* __restrict__ grid) {
+  const int b = blockIdx.z, ch = blockIdx.y;
+  const int N = v.H * v.W;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const dm_frame* f = frames + b;
+  const float* rp = f->Rp; const float* ry = f->Ry; const float* ri = f->reserved;  // R(-pitch)
+  const int r = i / v.W, q = i - r * v.W;
+  const size_t k = ((size_t)b * dc + ch) * N + i;
+  const float z = depth[k];
+  const float X = ray_x(v, q) * z, Y = ray_y(v, r) * z;
+  // camera -> local
+  const float x1 = __builtin_fmaf(z, rp[6], __builtin_fmaf(Y, rp[3], X * rp[0])) + 0.0f;
+  const float y1 = __builtin_fmaf(z, rp[7], __builtin_fmaf(Y, rp[4], X * rp[1])) + f->cam_height;
+  const float z1 = __builtin_fmaf(z, rp[8], __builtin_fmaf(Y, rp[5], X * rp[2])) + 0.0f;
+  // apply the pose transition
+  const float x2 = __builtin_fmaf(z1, ry[6], __builtin_fmaf(y1, ry[3], x1 * ry[0])) + f->tx;
+  const float y2 = __builtin_fmaf(z1, ry[7], __builtin_fmaf(y1, ry[4], x1 * ry[1])) + 0.0f;
+  const float z2 = __builtin_fmaf(z1, ry[8], __builtin_fmaf(y1, ry[5], x1 * ry[2])) + f->tz;
+  // local -> camera: translate first, then rotate by -pitch
+  const float x3 = x2 + 0.0f, y3 = y2 + (-f->cam_height), z3 = z2 + 0.0f;
+  const float xc = __builtin_fmaf(z3, ri[6], __builtin_fmaf(y3, ri[3], x3 * ri[0]));
+  const float yc = __builtin_fmaf(z3, ri[7], __builtin_fmaf(y3, ri[4], x3 * ri[1]));
+  const float zc = __builtin_fmaf(z3, ri[8], __builtin_fmaf(y3, ri[5], x3 * ri[2]));
+  // camera -> image
+  const float z_eps = zc + 1e-7f;
+  float u = xc / z_eps * v.fx + v.cx;
+  float w = yc / z_eps * v.fy + v.cy;
+  if (v.flip_h) w = v.Hm1 - w;
+  reinterpret_cast<float2*>(grid)[k] = make_float2(u, w);
+}
+
+inline int nblocks(size_t n, int cap = 8192) {
+  size_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
+}
+
+}  // namespace
+
+hipError_t run_affine_points(const float* pts, const float* R, const float* t, int B,
+                             size_t n_per_batch, int translate_first, float* out, hipStream_t s) {
+  if (B == 0 || n_per_batch == 0) return hipSuccess;
+  dim3 g((unsigned)((n_per_batch + 255) / 256), B);
+  hipLaunchKernelGGL(k_affine_points, g, dim3(256), 0, s, pts, R, t, translate_first,
+                     n_per_batch, out);
+  return hipGetLastError();
+}
+
+hipError_t run_map_quantize(const float* x, const float* z, const float* woff, const float* hoff,
+                            int B, size_t n_per_batch, float res, int map_height, int flip,
+                            long long* xb, long long* zb, hipStream_t s) {
+  if (B == 0 || n_per_batch == 0) return hipSuccess;
+  dim3 g((unsigned)((n_per_batch + 255) / 256), B);
+  hipLaunchKernelGGL(k_map_quantize, g, dim3(256), 0, s, x, z, woff, hoff, res,
+                     (float)(map_height - 1), flip, n_per_batch, xb, zb);
+  return hipGetLastError();
+}
+
+hipError_t run_camera_affine_grid(const dm_params& p, const dm_frame* frames_host,
+                                  const float* depth, float* grid, void* ws, hipStream_t s) {
+  if (p.B == 0) return hipSuccess;
+  hipError_t e = hipMemcpyAsync(ws, frames_host, (size_t)p.B * sizeof(dm_frame),
+                                hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  const View v = make_view(p);
+  dim3 g((unsigned)((p.H * p.W + 255) / 256), p.dc, p.B);
+  hipLaunchKernelGGL(k_camera_affine_grid, g, dim3(256), 0, s, v, p.dc,
+                     static_cast<const dm_frame*>(ws), depth, grid);
+  return hipGetLastError();
+}
+
+size_t scatter_workspace_bytes(size_t rows, size_t M, int has_fill, int reduction) {
+  size_t n = 0;
+  if (!has_fill) n += rows * M * sizeof(float);
+  if (reduction == DM_REDUCE_MEAN) n += rows * M * sizeof(float);
+  return n;
+}
+
+hipError_t run_scatter(const float* values, const long long* index, float* canvas, uint8_t* mask,
+                       int R, int C, int Ci, size_t N, size_t M, float fill, int has_fill,
+                       int reduction, void* ws, hipStream_t s) {
+  const size_t rows = (size_t)R * C, n = rows * M;
+  if (n == 0) return hipSuccess;
+  float* before = nullptr;
+  float* count = nullptr;
+  float* w = static_cast<float*>(ws);
+  if (has_fill) {
+    hipLaunchKernelGGL(k_fill1, dim3(nblocks(n)), dim3(256), 0, s, canvas, fill, n);
+  } else {
+    before = w; w += n;
+    hipError_t e = hipMemcpyAsync(before, canvas, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return e;
+  }
+  if (reduction == DM_REDUCE_MEAN) {
+    count = w;
+    hipLaunchKernelGGL(k_fill1, dim3(nblocks(n)), dim3(256), 0, s, count, 0.0f, n);
+  }
+  if (N > 0) {
+    dim3 g((unsigned)((N + 255) / 256), (unsigned)rows);
+    hipLaunchKernelGGL(k_scatter_flat, g, dim3(256), 0, s, values, index, canvas, count, C, Ci, N,
+                       M, reduction);
+  }
+  hipLaunchKernelGGL(k_scatter_finalize, dim3(nblocks(n)), dim3(256), 0, s, canvas, before, fill,
+                     count, mask, n);
+  return hipGetLastError();
+}
+
+}  // namespace dm

@@ -578,7 +578,7 @@ size_t window_workspace_bytes(const dm_params& p) {
 // then takes the generic path); nothing has been enqueued in that case.
 hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const float* depth,
                       const uint8_t* valid, float* out, uint8_t* mask, float* fused,
-                      uint8_t* fused_mask, void* ws, hipStream_t s) {
+                      uint8_t* fused_mask, void* ws, hipEvent_t after_projection, hipStream_t s) {
   const Parts parts = choose_parts(p);
   const int nparts = parts.pc * parts.pr;
   if ((long)p.B * p.dc > 65535) return hipErrorNotSupported;
@@ -699,6 +699,10 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     dim3 g((unsigned)((max_union / 4 + per_block - 1) / per_block), p.B * p.dc);
     if (is_max) hipLaunchKernelGGL(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma);
     else hipLaunchKernelGGL(k_window_merge<false>, g, dim3(kMergeThreads), 0, s, ma);
+  }
+  if (after_projection) {
+    e = hipEventRecord(after_projection, s);
+    if (e != hipSuccess) return e;
   }
   if (fused) {
     FuseArgs fa;

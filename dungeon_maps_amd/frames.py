@@ -76,10 +76,19 @@ def _terms(angle, batch: int):
 
 
 def build_frame_table(batch: int, cam_pose, cam_pitch, cam_height, width_offset,
-                      height_offset) -> torch.Tensor:
+                      height_offset, inverse_pitch: bool = False) -> torch.Tensor:
   """(batch, 32) float32 CPU tensor laid out as ``dm_frame``:
-  [0:9] Rp, [9] cam_height, [10:19] Ry, [19] tx, [20] tz, [21] woff, [22] hoff."""
+  [0:9] Rp, [9] cam_height, [10:19] Ry, [19] tx, [20] tz, [21] woff, [22] hoff,
+  [23:32] rotate(X, -pitch) when ``inverse_pitch`` (camera_affine_grid)."""
   table = np.zeros((batch, FRAME_FLOATS), dtype=_F32)
+  if inverse_pitch:
+    neg = -cam_pitch if _is_scalar(cam_pitch) else -_column(cam_pitch, batch)
+    si, di = _terms(neg, batch)
+    table[:, 23] = _ONE
+    table[:, 27] = di
+    table[:, 28] = -si
+    table[:, 30] = si
+    table[:, 31] = di
   sp, dp = _terms(cam_pitch, batch)
   table[:, 0] = _ONE
   table[:, 4] = dp

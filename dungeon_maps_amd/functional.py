@@ -381,28 +381,69 @@ def camera_to_image_space(points, focal_x, focal_y, center_x, center_y, flip_h=T
   return torch.stack((u, v, z), dim=-1).reshape(shape)
 
 
-def _lift(cam_height: torch.Tensor, sign: float) -> torch.Tensor:
-  o = torch.zeros_like(cam_height)
-  return torch.stack((o, sign * cam_height, o), dim=-1)
+def _cpu_f32(v, width: Optional[int] = None) -> torch.Tensor:
+  t = utils.to_tensor(v).detach().to(device="cpu", dtype=torch.float32)
+  return t.reshape(-1) if width is None else t.reshape(-1, width)
+
+
+def _rows(t: torch.Tensor, batch: int) -> torch.Tensor:
+  if t.shape[0] == 1 and batch != 1:
+    t = t.expand(batch, *t.shape[1:])
+  if t.shape[0] != batch:
+    raise ValueError(f"per-batch argument has {t.shape[0]} rows, expected 1 or {batch}")
+  return t
+
+
+def _affine(points: torch.Tensor, axis, angle, offset: torch.Tensor,
+            translate_first: bool) -> torch.Tensor:
+  """rotate(points) + offset, or rotate(points + offset): reference
+  utils.rotate / utils.translate (utils.py:229-330) with the rotation matrix
+  built on the CPU.  GPU tensors go through dm_affine_points_f32 (the exact FMA
+  chain of the reference's CPU bmm); CPU tensors use torch (= the reference)."""
+  shape = points.shape
+  b = shape[0]
+  angle_cpu = _cpu_f32(angle)
+  offset_cpu = _rows(_cpu_f32(offset, 3), b)
+  if points.device.type != "cuda":
+    flat = points.reshape(b, -1, 3)
+    if translate_first:
+      flat = utils.translate(flat, offset_cpu)
+    flat = utils.rotate(flat, axis, angle_cpu)
+    if not translate_first:
+      flat = utils.translate(flat, offset_cpu)
+    return flat.reshape(shape)
+  rot = _rows(utils.rotation_matrix(torch.tensor([axis]), angle_cpu).reshape(-1, 9), b)
+  dev = points.device
+  pts = points.reshape(b, -1, 3).contiguous()
+  out = torch.empty_like(pts)
+  rot_d = rot.contiguous().to(dev)
+  off_d = offset_cpu.contiguous().to(dev)
+  with torch.cuda.device(dev):
+    _native.check(_native.lib().dm_affine_points_f32(
+        _ptr(pts), _ptr(rot_d), _ptr(off_d), b, pts.shape[1], int(translate_first), _ptr(out),
+        _stream_ptr(dev)))
+  return out.reshape(shape)
+
+
+def _lift(cam_height, sign: float) -> torch.Tensor:
+  h = _cpu_f32(cam_height)
+  o = torch.zeros_like(h)
+  return torch.stack((o, sign * h, o), dim=-1)
 
 
 def camera_to_local_space(points, cam_pitch, cam_height, device=None,
                           _validate_args=True) -> torch.Tensor:
-  """Rotate by the camera pitch about X, then lift by the camera height."""
+  """Rotate by the camera pitch about X, then lift by the camera height
+  (reference maps.py:753-800)."""
   pts = _points(points, device)
-  pitch = utils.to_tensor(cam_pitch, device=pts.device).to(torch.float32).reshape(-1)
-  h = utils.to_tensor(cam_height, device=pts.device).to(torch.float32).reshape(-1)
-  out = utils.rotate(pts.reshape(pts.shape[0], -1, 3), [1., 0., 0.], pitch)
-  return utils.translate(out, _lift(h, 1.0)).reshape(pts.shape)
+  return _affine(pts, [1., 0., 0.], _cpu_f32(cam_pitch), _lift(cam_height, 1.0), False)
 
 
 def local_to_camera_space(points, cam_pitch, cam_height, device=None,
                           _validate_args=True) -> torch.Tensor:
+  """Drop by the camera height, then rotate by -pitch (reference maps.py:802-848)."""
   pts = _points(points, device)
-  pitch = utils.to_tensor(cam_pitch, device=pts.device).to(torch.float32).reshape(-1)
-  h = utils.to_tensor(cam_height, device=pts.device).to(torch.float32).reshape(-1)
-  out = utils.translate(pts.reshape(pts.shape[0], -1, 3), _lift(h, -1.0))
-  return utils.rotate(out, [1., 0., 0.], -pitch).reshape(pts.shape)
+  return _affine(pts, [1., 0., 0.], -_cpu_f32(cam_pitch), _lift(cam_height, -1.0), True)
 
 
 def _pose_offset(pose: torch.Tensor) -> torch.Tensor:
@@ -410,18 +451,18 @@ def _pose_offset(pose: torch.Tensor) -> torch.Tensor:
 
 
 def local_to_global_space(points, cam_pose, device=None, _validate_args=True) -> torch.Tensor:
-  """Rotate by yaw about Y, then translate by (pose_x, 0, pose_z)."""
+  """Rotate by yaw about Y, then translate by (pose_x, 0, pose_z)
+  (reference maps.py:850-895)."""
   pts = _points(points, device)
-  pose = utils.to_tensor(cam_pose, device=pts.device).to(torch.float32).reshape(-1, 3)
-  out = utils.rotate(pts.reshape(pts.shape[0], -1, 3), [0., 1., 0.], pose[:, 2])
-  return utils.translate(out, _pose_offset(pose)).reshape(pts.shape)
+  pose = _cpu_f32(cam_pose, 3)
+  return _affine(pts, [0., 1., 0.], pose[:, 2], _pose_offset(pose), False)
 
 
 def global_to_local_space(points, cam_pose, device=None, _validate_args=True) -> torch.Tensor:
+  """Translate by -(pose_x, 0, pose_z), then rotate by -yaw (reference maps.py:897-942)."""
   pts = _points(points, device)
-  pose = utils.to_tensor(cam_pose, device=pts.device).to(torch.float32).reshape(-1, 3)
-  out = utils.translate(pts.reshape(pts.shape[0], -1, 3), -_pose_offset(pose))
-  return utils.rotate(out, [0., 1., 0.], -pose[:, 2]).reshape(pts.shape)
+  pose = _cpu_f32(cam_pose, 3)
+  return _affine(pts, [0., 1., 0.], -pose[:, 2], -_pose_offset(pose), True)
 
 
 def _offset_column(v, like: torch.Tensor) -> torch.Tensor:
@@ -439,12 +480,35 @@ def map_quantize(x_coords, z_coords, width_offset, height_offset, map_res,
   x, z = torch.broadcast_tensors(x, z)
   if x.dim() < 2:
     x, z = x.reshape(1, -1), z.reshape(1, -1)
+  if x.device.type == "cuda":
+    return _map_quantize_native(x, z, width_offset, height_offset, map_res, map_height, flip_h)
   col = x / map_res + _offset_column(width_offset, x)
   row = z / map_res + _offset_column(height_offset, x)
   if flip_h:
     assert map_height is not None
     row = (torch.tensor(map_height, device=x.device) - 1) - row
   return (torch.floor(col + 0.5).to(torch.int64), torch.floor(row + 0.5).to(torch.int64))
+
+
+def _map_quantize_native(x, z, width_offset, height_offset, map_res, map_height, flip_h):
+  """GPU tensors: dm_map_quantize_f32 (true IEEE division -- PyTorch's own GPU
+  division by a scalar multiplies by the reciprocal and can flip cells)."""
+  b = x.shape[0]
+  dev = x.device
+  xs = x.reshape(b, -1).contiguous()
+  zs = z.reshape(b, -1).contiguous()
+  woff = _rows(_cpu_f32(width_offset), b).contiguous().to(dev)
+  hoff = _rows(_cpu_f32(height_offset), b).contiguous().to(dev)
+  if flip_h:
+    assert map_height is not None
+  xb = torch.empty(xs.shape, dtype=torch.int64, device=dev)
+  zb = torch.empty(xs.shape, dtype=torch.int64, device=dev)
+  with torch.cuda.device(dev):
+    _native.check(_native.lib().dm_map_quantize_f32(
+        _ptr(xs), _ptr(zs), _ptr(woff), _ptr(hoff), b, xs.shape[1], float(map_res),
+        int(map_height) if map_height is not None else 1, int(bool(flip_h)), _ptr(xb), _ptr(zb),
+        _stream_ptr(dev)))
+  return xb.reshape(x.shape), zb.reshape(x.shape)
 
 
 def map_dequantize(x_coords, z_coords, width_offset, height_offset, map_res,
@@ -520,15 +584,114 @@ def compute_center_offsets(cam_pose, width_offset, height_offset, map_res, map_w
 # ---------------------------------------------------------------------------
 # project / scatter (reference maps.py:1089-1173, utils.py:389-492)
 # ---------------------------------------------------------------------------
+def _scatter_flat(canvas: torch.Tensor, flat_index: torch.Tensor, values: torch.Tensor,
+                  n_data: int, fill_value, reduction) -> Tuple[torch.Tensor, torch.Tensor]:
+  """canvas (b..., d1..dn) with n_data trailing data dims, flat_index (b..., N)
+  int64 (< 0 = dropped), values (b..., N).  Runs dm_scatter_f32 on the GPU."""
+  import ctypes
+  target = canvas.device
+  dev = _compute_device(target)
+  batch_shape = tuple(canvas.shape[:canvas.dim() - n_data])
+  M = int(np.prod(canvas.shape[canvas.dim() - n_data:]))
+  N = values.shape[-1]
+  vshape = torch.broadcast_shapes(tuple(values.shape[:-1]), batch_shape)
+  if tuple(vshape) != batch_shape:
+    raise ValueError(f"values {tuple(values.shape)} do not broadcast to canvas batch {batch_shape}")
+  C = batch_shape[-1] if len(batch_shape) >= 1 else 1
+  R = int(np.prod(batch_shape[:-1])) if len(batch_shape) >= 1 else 1
+  vals = values.to(device=dev, dtype=torch.float32).expand(*batch_shape, N).contiguous()
+  idx = flat_index.to(device=dev, dtype=torch.int64)
+  # index rows either follow every channel or are shared by all channels of a row
+  if idx.dim() == len(batch_shape) + 1 and len(batch_shape) >= 1 and idx.shape[-2] == 1 and C > 1:
+    idx = idx.expand(*batch_shape[:-1], 1, N).contiguous()
+    Ci = 1
+  else:
+    idx = idx.expand(*batch_shape, N).contiguous()
+    Ci = C
+  out = canvas.to(device=dev, dtype=torch.float32).contiguous().clone()
+  mask = torch.empty(out.shape, dtype=torch.bool, device=dev)
+  has_fill = fill_value is not None
+  red = _reduction_code(reduction)
+  lib = _native.lib()
+  need = lib.dm_scatter_workspace_bytes(R, C, M, int(has_fill), red)
+  ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+  with torch.cuda.device(dev):
+    _native.check(lib.dm_scatter_f32(
+        _ptr(vals), _ptr(idx), _ptr(out), _ptr(mask), R, C, Ci, N, M,
+        float(fill_value) if has_fill else 0.0, int(has_fill), red, _ptr(ws), need,
+        _stream_ptr(dev)))
+  if target != dev:
+    out, mask = out.to(target), mask.to(target)
+  return out, mask
+
+
 def scatter_nd(canvas, indices, values, masks=None, fill_value=None, reduction=None):
-  raise NotImplementedError("scatter_nd lands with dm_scatter_f32")
+  """utils.scatter_tensor (reference utils.py:389-492): canvas (b..., d1..dn),
+  indices (b..., N, n), values (b..., N), masks (b..., N)."""
+  canvas = utils.to_tensor(canvas)
+  indices = utils.to_tensor(indices, device=canvas.device).to(torch.int64)
+  values = utils.to_tensor(values, device=canvas.device)
+  n = indices.shape[-1]
+  if canvas.dim() <= n:
+    raise AssertionError(f"The rank of `canvas` must be greater than {n}, got {canvas.dim()}")
+  dims = canvas.shape[-n:]
+  ok = torch.ones(indices.shape[:-1], dtype=torch.bool, device=canvas.device)
+  if masks is not None:
+    ok = ok & utils.to_tensor(masks, device=canvas.device).to(torch.bool)
+  flat = torch.zeros(indices.shape[:-1], dtype=torch.int64, device=canvas.device)
+  for i in range(n):
+    di = indices[..., i]
+    ok = ok & (di >= 0) & (di < dims[i])
+    flat = flat * dims[i] + di
+  flat = torch.where(ok, flat, torch.full_like(flat, -1))
+  return _scatter_flat(canvas, flat, values, n, fill_value, reduction)
 
 
 def project(coords, values, masks, canvas, canvas_masks=None, fill_value=None,
             reduction=None, device=None, _validate_args=True):
-  raise NotImplementedError("project lands with dm_scatter_f32")
+  """Scatter ``values`` (b, ..., n) onto ``canvas`` (b, ..., mh, mw) at
+  ``coords`` (b, ..., n, 2) = (row, col) with a reduction; returns (canvas,
+  mask).  Reference maps.py:1089-1173; runs on dm_scatter_f32."""
+  coords = utils.to_tensor(coords, device=device)
+  if coords.dim() < 3:
+    coords = coords.reshape(1, -1, 2)
+  dev = coords.device
+  values = utils.to_tensor(values, device=dev).to(torch.float32)
+  masks = utils.to_tensor(masks, device=dev).to(torch.bool)
+  canvas = utils.to_tensor(canvas, device=dev).to(torch.float32)
+  batch = torch.broadcast_shapes(tuple(values.shape), tuple(masks.shape),
+                                 tuple(coords.shape[:-1]), tuple(canvas.shape[:-2]) + (1,))
+  canvas = canvas.expand(*batch[:-1], *canvas.shape[-2:])
+  out, changed = scatter_nd(canvas, coords.to(torch.int64), values, masks, fill_value, reduction)
+  if canvas_masks is not None:
+    cm = utils.to_tensor(canvas_masks, device=out.device).to(torch.bool)
+    changed = torch.logical_or(torch.broadcast_to(cm, changed.shape), changed)
+  return out, changed
 
 
 def camera_affine_grid(depth_map, trans_pose, cam_pitch, cam_height, focal_x, focal_y,
                        center_x, center_y, flip_h=True, device=None, _validate_args=True):
-  raise NotImplementedError("camera_affine_grid lands with dm_camera_affine_grid_f32")
+  """Pixel coordinates (b, c, h, w, 2) every pixel of ``depth_map`` maps to
+  after the camera moved by ``trans_pose`` = [x, z, yaw] (ego-motion flow field).
+  Reference maps.py:353-460; one fused HIP kernel (dm_camera_affine_grid_f32)."""
+  import ctypes
+  first = depth_map if torch.is_tensor(depth_map) else utils.to_tensor(depth_map)
+  target = torch.device(device) if device is not None else first.device
+  dev = _compute_device(target)
+  depth = _image(first, dev, torch.float32)
+  B, dc, H, W = depth.shape
+  p = _native.Params()
+  p.B, p.dc, p.vc, p.H, p.W, p.mh, p.mw = B, dc, 0, H, W, 1, 1
+  p.flip_h = int(bool(flip_h))
+  p.cx, p.cy, p.fx, p.fy = float(center_x), float(center_y), float(focal_x), float(focal_y)
+  p.res = 1.0
+  table = frames.build_frame_table(B, trans_pose, cam_pitch, cam_height, 0., 0.,
+                                   inverse_pitch=True)
+  grid = torch.empty((B, dc, H, W, 2), dtype=torch.float32, device=dev)
+  ws_bytes = B * _native.FRAME_FLOATS * 4
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+  with torch.cuda.device(dev):
+    _native.check(_native.lib().dm_camera_affine_grid_f32(
+        ctypes.byref(p), _ptr(table), _ptr(depth), _ptr(grid), _ptr(ws), ws_bytes,
+        _stream_ptr(dev)))
+  return grid if target == dev else grid.to(target)

@@ -217,10 +217,96 @@ def crop_topdown_map(source: TopdownMap, center, crop_width: int, crop_height: i
                     is_height_map=source.is_height_map, map_projector=new_proj)
 
 
+def _map_points(source: TopdownMap):
+  """Cell-centre points (b, c, N, 3) of a map in GLOBAL space, its flattened
+  mask and (for value maps) its flattened values (reference maps.py:2039-2069)."""
+  proj = source.proj
+  assert not source.is_empty and proj is not None
+  cloud = proj.height_map_to_point_cloud(source.height_map)          # (b, c, h, w, 3)
+  points = torch.flatten(cloud, -3, -2)
+  mask = torch.flatten(source.mask.to(points.device), -2, -1)
+  if proj.to_global is False:
+    points = proj.local_to_global_space(points)
+  values = None
+  if not source.is_height_map:
+    values = torch.flatten(source.topdown_map.to(points.device), -2, -1)
+  return points, mask, values
+
+
 def fuse_topdown_maps(*maps: TopdownMap, map_projector: Optional[MapProjector] = None,
                       fill_value: Optional[float] = None,
                       reduction: Optional[Reduction] = None) -> TopdownMap:
-  raise NotImplementedError("fuse_topdown_maps lands with dm_fuse (next row)")
+  """Re-project several top-down maps into the frame of ``map_projector`` and
+  reduce them cell-wise into one map that is just large enough (bounding box of
+  the valid cells + 2), with offsets that centre it.
+
+  Semantics of reference maps.py:2181-2287 (incl. 2071-2179): every valid cell
+  becomes a point at its cell centre, goes local -> global with its own map's
+  pose and global -> local with the target's, is quantised with zero offsets to
+  find the bounding box (one D2H of five numbers replaces the reference's two
+  ``.item()`` syncs), re-quantised with the new offsets and scattered.  All
+  per-point arithmetic runs on the exact HIP primitives (dm_affine_points_f32,
+  dm_map_quantize_f32, dm_scatter_f32).
+  """
+  if len(maps) == 0:
+    return TopdownMap(map_projector=map_projector)
+  if map_projector is None:
+    map_projector = maps[0].proj
+  proj = map_projector
+  assert proj is not None, "map_projector is not provided"
+  clouds = [_map_points(m) for m in maps if not m.is_empty]
+  if not clouds:
+    return TopdownMap(map_projector=map_projector)
+  kinds = {c[2] is None for c in clouds}
+  assert len(kinds) == 1, "All maps must be the same type of maps (height or value maps)"
+  is_height_map = clouds[0][2] is None
+  dev = clouds[0][0].device
+  points = torch.cat([c[0].to(dev) for c in clouds], dim=-2)          # (b, c, N, 3)
+  masks = torch.cat([c[1].to(dev) for c in clouds], dim=-1)           # (b, c, N)
+  if proj.to_global is False:
+    points = proj.global_to_local_space(points)
+  heights = points[..., 1]
+  values = heights if is_height_map else torch.cat([c[2].to(dev) for c in clouds], dim=-1)
+
+  # bounding box of the valid cells at zero offsets, unflipped (maps.py:2146-2179)
+  col0, row0 = proj.map_quantize(points[..., 0], points[..., 2], width_offset=0.,
+                                 height_offset=0., flip_h=False)
+  big = torch.iinfo(torch.int64).max
+  stats = torch.stack((
+      torch.where(masks, col0, torch.full_like(col0, big)).amin(),
+      torch.where(masks, col0, torch.full_like(col0, -big)).amax(),
+      torch.where(masks, row0, torch.full_like(row0, big)).amin(),
+      torch.where(masks, row0, torch.full_like(row0, -big)).amax(),
+      masks.any().to(torch.int64))).cpu().tolist()                     # the one host sync
+  min_x, max_x, min_z, max_z, any_valid = stats
+  if not any_valid:
+    last = maps[-1]
+    return TopdownMap(topdown_map=last.topdown_map, mask=last.mask, height_map=last.height_map,
+                      map_projector=proj)
+  map_width = int(max_x - min_x) + 2
+  map_height = int(max_z - min_z) + 2
+  f32 = np.float32
+  woff = torch.tensor([f32(map_width / 2.) - f32(max_x + min_x) / f32(2.)], dtype=torch.float32)
+  hoff = torch.tensor([f32(map_height / 2.) - f32(max_z + min_z) / f32(2.)], dtype=torch.float32)
+
+  col, row = proj.map_quantize(points[..., 0], points[..., 2], width_offset=woff,
+                               height_offset=hoff, map_height=map_height)
+  coords = torch.stack((row, col), dim=-1)
+  canvas = torch.zeros((*values.shape[:-1], map_height, map_width), device=dev)
+  topdown, new_mask = proj.project(coords=coords, values=values, masks=masks, canvas=canvas,
+                                   fill_value=get(fill_value, proj.fill_value, NINF),
+                                   reduction=reduction)
+  if is_height_map:
+    height_map = topdown
+  else:
+    canvas = torch.zeros((*heights.shape[:-1], map_height, map_width), device=dev)
+    height_map, _ = proj.project(coords=coords, values=heights, masks=masks, canvas=canvas,
+                                 fill_value=NINF, reduction=Reduction.max)
+    height_map = torch.broadcast_to(height_map, topdown.shape)
+  new_proj = proj.clone(width_offset=woff, height_offset=hoff, map_width=map_width,
+                        map_height=map_height)
+  return TopdownMap(topdown_map=topdown, mask=new_mask, height_map=height_map,
+                    map_projector=new_proj, is_height_map=is_height_map)
 
 
 class MapBuilder:

@@ -66,7 +66,8 @@ typedef struct dm_frame {
   float tx, tz;          /* cam_pose[b,0], cam_pose[b,1]  (maps.py:887-892) */
   float width_offset;    /* maps.py:1004 */
   float height_offset;   /* maps.py:1005 */
-  float reserved[9];
+  float reserved[9];     /* dm_camera_affine_grid_f32: rotate([1,0,0], -cam_pitch[b])
+                            (maps.py:845); unused by the projector */
 } dm_frame;
 
 /*
@@ -141,11 +142,69 @@ int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames,
                               void* stream);
 
 /*
+ * camera_affine_grid (maps.py:353-460): per pixel of depth (B, dc, H, W) the
+ * (column, row) it maps to after the camera moved by trans_pose -- frames[b]
+ * holds Rp = rotate(X, pitch), cam_height, Ry/tx/tz = the pose TRANSITION
+ * (maps.py:435-439) and reserved = rotate(X, -pitch).  Uses p->B, dc, H, W,
+ * cx, cy, fx, fy, flip_h.  grid_dev (B, dc, H, W, 2) f32.  The workspace needs
+ * B * sizeof(dm_frame) bytes.
+ */
+int dm_camera_affine_grid_f32(const dm_params* p, const dm_frame* frames,
+                              const float* depth_dev, float* grid_dev,
+                              void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/*
+ * utils.rotate + utils.translate on materialised points (utils.py:229-330; used
+ * by camera_to_local_space / local_to_global_space / global_to_local_space /
+ * local_to_camera_space, maps.py:753-942).  pts_dev, out_dev (B, n, 3) f32;
+ * R_dev (B, 9) row-major as utils.py:326-327; t_dev (B, 3).
+ *   translate_first == 0:  out = rotate(p) + t        (camera->local, local->global)
+ *   translate_first != 0:  out = rotate(p + t)        (global->local, local->camera)
+ * rotate is out_i = fma(p2,R[6+i], fma(p1,R[3+i], p0*R[i])) -- the reference's
+ * CPU bmm order.  In-place (out_dev == pts_dev) is allowed.
+ */
+int dm_affine_points_f32(const float* pts_dev, const float* R_dev, const float* t_dev,
+                         int64_t B, size_t n, int translate_first, float* out_dev,
+                         void* stream);
+
+/*
+ * map_quantize (maps.py:944-1019): xb = floor(x/res + woff[b] + 0.5),
+ * zb = floor((flip ? (mh-1) - (z/res + hoff[b]) : z/res + hoff[b]) + 0.5) as
+ * int64 (NaN / out of range -> INT64_MIN, like the reference on x86).
+ * x_dev, z_dev (B, n) f32; woff_dev, hoff_dev (B) f32; xb_dev, zb_dev (B, n) i64.
+ */
+int dm_map_quantize_f32(const float* x_dev, const float* z_dev, const float* woff_dev,
+                        const float* hoff_dev, int64_t B, size_t n, float res,
+                        int32_t map_height, int32_t flip_h, int64_t* xb_dev,
+                        int64_t* zb_dev, void* stream);
+
+/*
+ * utils.scatter_tensor incl. the torch_scatter call (utils.py:389-492) on
+ * pre-ravelled indices: values_dev (R, C, N) f32; index_dev (R, Ci, N) i64 with
+ * Ci in {1, C}, a flat cell in [0, M) or anything else = dropped;
+ * canvas_dev (R, C, M) f32 in/out -- filled with `fill` first if has_fill, else
+ * its content takes part; mask_dev (R, C, M) u8 = cell changed (utils.py:489-491).
+ */
+size_t dm_scatter_workspace_bytes(int64_t R, int32_t C, size_t M, int32_t has_fill,
+                                  int32_t reduction);
+int dm_scatter_f32(const float* values_dev, const int64_t* index_dev, float* canvas_dev,
+                   uint8_t* mask_dev, int64_t R, int32_t C, int32_t Ci, size_t N, size_t M,
+                   float fill, int32_t has_fill, int32_t reduction, void* workspace_dev,
+                   size_t workspace_bytes, void* stream);
+
+/*
  * Test hook: non-zero forces dm_orth_project_f32 onto the generic
  * (global-atomic) path on the calling thread; returns the previous setting.
  * The LDS-windowed fast path is checked against it on the device.
  */
 int dm_debug_force_generic_path(int on);
+
+/*
+ * Measurement hook (bench.py): the next dm_orth_project_f32 call on this thread
+ * records `event` (a hipEvent_t) on its stream right after the kernels that
+ * produce out/mask and before the optional batch fuse, then forgets it.
+ */
+void dm_debug_record_after_projection(void* event);
 
 /*
  * Fuse B maps that share one frame (same res/offsets/size) into one:

@@ -267,3 +267,26 @@ int dmo_max_threads(void) {
   return 1;
 #endif
 }
+
+/* utils.rotate + utils.translate on explicit points (utils.py:229-330), the
+ * restatement behind camera_to_local_space / local_to_global_space /
+ * global_to_local_space / local_to_camera_space (maps.py:753-942).
+ * pts, out (B, n, 3); R (B, 9); t (B, 3).  translate_first: out = rot(p + t). */
+void dmo_affine_points(const float* pts, const float* R, const float* t, int B, int64_t n,
+                       int translate_first, float* out) {
+  for (int b = 0; b < B; ++b) {
+    const float* r = R + 9 * b;
+    const float* tb = t + 3 * b;
+    for (int64_t i = 0; i < n; ++i) {
+      const float* p = pts + ((int64_t)b * n + i) * 3;
+      float p0 = p[0], p1 = p[1], p2 = p[2];
+      if (translate_first) { p0 = p0 + tb[0]; p1 = p1 + tb[1]; p2 = p2 + tb[2]; }
+      float o0 = fmaf(p2, r[6], fmaf(p1, r[3], p0 * r[0]));
+      float o1 = fmaf(p2, r[7], fmaf(p1, r[4], p0 * r[1]));
+      float o2 = fmaf(p2, r[8], fmaf(p1, r[5], p0 * r[2]));
+      if (!translate_first) { o0 = o0 + tb[0]; o1 = o1 + tb[1]; o2 = o2 + tb[2]; }
+      float* o = out + ((int64_t)b * n + i) * 3;
+      o[0] = o0; o[1] = o1; o[2] = o2;
+    }
+  }
+}

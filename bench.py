@@ -46,7 +46,7 @@ def algorithmic_bytes(B, H, W, mh, mw, C):
   depth = B * H * W * 4
   if C == 0:
     return depth + B * mh * mw * (4 + 1)
-  return depth + B * C * H * W * 4 + B * C * mh * mw * (4 + 1) + B * mh * mw * 4
+  return depth + B * C * H * W * 4 + B * C * mh * mw * (4 + 1)     # object map, no height map
 
 
 def synthetic_inputs(B, H, W, C, seed, device, scene):
@@ -179,7 +179,7 @@ def main():
       "data": "synthetic",
       "config": {
           "workload": f"{args.workload}: B={B}/GPU, {W}x{H} depth -> {mw}x{mh} "
-                      f"{'height map' if not C else f'{C}-class object map + height map'}, "
+                      f"{'height map' if not C else f'{C}-class object map'}, "
                       f"depth={args.depth}, project + fuse(max over frames)"
                       f"{' + RCCL all-reduce(max)' if world > 1 else ''} + mask",
           "frames_per_gpu": B, "global_frames": world * B,

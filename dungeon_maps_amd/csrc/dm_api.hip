@@ -84,8 +84,9 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
   const hipEvent_t mid = g_mid_event;
   g_mid_event = nullptr;
   if (dm::window_path_supported(*p) && !g_force_generic)
-    e = dm::run_window(*p, frames, depth_dev, valid_dev, out_dev, mask_dev, fused_dev,
-                       fused_mask_dev, workspace_dev, mid, s);
+    e = dm::run_window(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
+                       p->vc ? height_dev : nullptr, fused_dev, fused_mask_dev, workspace_dev,
+                       workspace_bytes, mid, s);
   if (e == hipErrorNotSupported) { // nothing enqueued: a window exceeds LDS, odd alignment, ...
     e = dm::run_generic(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
                         p->vc ? height_dev : nullptr, workspace_dev, s);

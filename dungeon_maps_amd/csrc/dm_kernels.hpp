@@ -16,16 +16,18 @@ hipError_t run_generic_fused(const dm_params& p, const dm_frame* frames_host, co
                              const float* value, const uint8_t* valid, float* out,
                              uint8_t* mask, int accumulate, void* ws, hipStream_t s);
 
-// dm_window.hip -- LDS-windowed scatter + slab merge (max/min height maps)
-bool window_path_supported(const dm_params& p);
-size_t window_workspace_bytes(const dm_params& p);
-hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const float* depth,
-                      const uint8_t* valid, float* out, uint8_t* mask, float* fused,
-                      uint8_t* fused_mask, void* ws, hipEvent_t after_projection, hipStream_t s);
 hipError_t run_fuse_batch(const float* maps, int B, size_t n, float* out, bool is_max,
                           int accumulate, hipStream_t s);
 hipError_t run_mask_from_map(const float* map, float fill, uint8_t* mask, size_t n,
                              hipStream_t s);
+
+// dm_window.hip -- LDS-windowed scatter + slab merge (max/min; heights or value maps)
+bool window_path_supported(const dm_params& p);
+size_t window_workspace_bytes(const dm_params& p);
+hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const float* depth,
+                      const float* value, const uint8_t* valid, float* out, uint8_t* mask,
+                      float* height, float* fused, uint8_t* fused_mask, void* ws,
+                      size_t ws_bytes, hipEvent_t after_projection, hipStream_t s);
 
 // dm_points.hip -- exact point-set primitives (affine, quantise, flat scatter)
 hipError_t run_affine_points(const float* pts, const float* R, const float* t, int B,

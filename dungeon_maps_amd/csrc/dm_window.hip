@@ -46,11 +46,13 @@ struct Window {
   int x0, z0, w, h;
 };
 
-__host__ Parts choose_parts(const dm_params& p) {
-  // enough workgroups to fill 256 CUs, parts not smaller than 32 columns,
-  // strip boundaries on 128-byte lines (32 floats) when W allows it
-  const long frames = (long)p.B * p.dc;
+__host__ Parts choose_parts(const dm_params& p, int min_parts = 1) {
+  // enough workgroups to fill 256 CUs (and at least min_parts, so that windows fit
+  // in LDS), parts not smaller than 32 columns, strip boundaries on 128-byte lines
+  // (32 floats) when W allows it
+  const long frames = (long)p.B * (p.vc ? p.vc : p.dc);
   int want = (int)((256 + frames - 1) / frames);
+  if (want < min_parts) want = min_parts;
   if (want < 1) want = 1;
   Parts s;
   s.pc = 1; s.pr = 1;
@@ -178,11 +180,15 @@ struct ScatterArgs {
   float Hm1, mhm1;
   Parts parts;
   int dc, valid_c;
+  int oc;                     // output channels per frame handled by this pass
+  int ch0;                    // first output channel of this launch (channel groups)
+  int oc_total;               // channels of `out` / `value`
   int slab_stride;            // cells per slab
   float fill;
   const dm_frame* frames;     // device copy (yaw already neutralised if !to_global)
   const Window* windows;      // (B, pr, pc): the same for every channel of a frame
   const float* depth;
+  const float* value;         // (B, oc_total, H, W) or NULL: project the heights
   const uint8_t* valid;
   float* slabs;
   // fill duty: the part of every output map outside its frame's union window
@@ -211,12 +217,15 @@ __device__ inline void lds_reduce(float* cell, float v) {
 //       and rotate([0,1,0],.) AND the Markstein reciprocals are usable
 //       (dm_pixel.hpp).  !FAST: full FMA chains and IEEE division.
 // VEC = 4: 16-byte depth loads (W % 4 == 0, 16-byte aligned base); VEC = 1: any shape.
-template <bool IS_MAX, bool FAST, bool HAS_VALID, int VEC>
+// HAS_VALUE: scatter value[b, ch] (maps.py:314-316) instead of the height.
+template <bool IS_MAX, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC>
 __global__ void __launch_bounds__(kScatterThreads)
 k_window_scatter(ScatterArgs a) {
   extern __shared__ float lds[];
   const int part = blockIdx.x;                 // pr-major, pc-minor
-  const int ch = blockIdx.y, b = blockIdx.z;
+  const int chl = blockIdx.y, b = blockIdx.z;  // channel within this launch's group
+  const int ch = a.ch0 + chl;                  // output channel
+  const int dch = a.dc == 1 ? 0 : ch;          // depth / cell-index channel (utils.py:475-477)
   const int nparts = a.parts.pc * a.parts.pr;
   const int pcx = part % a.parts.pc, pry = part / a.parts.pc;
   const Window w = a.windows[(size_t)b * nparts + part];
@@ -231,7 +240,7 @@ k_window_scatter(ScatterArgs a) {
   const int g4_shift = (g4 & (g4 - 1)) == 0 ? __builtin_ctz(g4) : -1;   // wave-uniform
   const int fill_total = ((a.mh - part + nparts - 1) / nparts) * g4;
   const int fill_steps = (fill_total + kScatterThreads - 1) / kScatterThreads;
-  const size_t map_base = ((size_t)b * a.dc + ch) * (size_t)a.mh * a.mw;
+  const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
   int fs = 0;
   auto fill_step = [&]() {
     const int i = fs * kScatterThreads + (int)threadIdx.x;
@@ -244,7 +253,7 @@ k_window_scatter(ScatterArgs a) {
       if (!inside) {
         const size_t cell = map_base + (size_t)r * a.mw + x;
         *reinterpret_cast<float4*>(a.out + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
-        *reinterpret_cast<uint32_t*>(a.mask + cell) = 0u;
+        if (a.mask) *reinterpret_cast<uint32_t*>(a.mask + cell) = 0u;
       }
     }
   };
@@ -274,9 +283,10 @@ k_window_scatter(ScatterArgs a) {
   const int rows_per_iter = kScatterThreads / ntx;
   const int gx = threadIdx.x % ntx, gy = threadIdx.x / ntx;
   const size_t N = (size_t)a.H * a.W;
-  const float* dimg = a.depth + ((size_t)b * a.dc + ch) * N;
+  const float* dimg = a.depth + ((size_t)b * a.dc + dch) * N;
   const uint8_t* vimg = HAS_VALID
-      ? a.valid + ((size_t)b * a.valid_c + (a.valid_c == 1 ? 0 : ch)) * N : nullptr;
+      ? a.valid + ((size_t)b * a.valid_c + (a.valid_c == 1 ? 0 : dch)) * N : nullptr;
+  const float* simg = HAS_VALUE ? a.value + ((size_t)b * a.oc_total + ch) * N : nullptr;
   const float qnan = __builtin_nanf("");
   const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
   const unsigned dummy = (unsigned)area + (threadIdx.x & 63u);   // 64 scratch cells after the window
@@ -299,7 +309,9 @@ k_window_scatter(ScatterArgs a) {
       // run in phase, so latency has to be hidden inside each wave).
       const int step = rows_per_iter * kRowsInFlight;
       float za[kRowsInFlight][VEC], zb_[kRowsInFlight][VEC];
-      auto load_rows = [&](float (&z)[kRowsInFlight][VEC], int r) {
+      float va[HAS_VALUE ? kRowsInFlight : 1][VEC], vb_[HAS_VALUE ? kRowsInFlight : 1][VEC];
+      auto load_rows = [&](float (&z)[kRowsInFlight][VEC],
+                           float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u) {
           // rows past the part are clamped to its last row (a legal address);
@@ -318,9 +330,18 @@ k_window_scatter(ScatterArgs a) {
             for (int k = 0; k < VEC; ++k)
               z[u][k] = vimg[(size_t)rr * a.W + q + k] ? z[u][k] : qnan;
           }
+          if (HAS_VALUE) {
+            if (VEC == 4) {
+              const float4 t = *reinterpret_cast<const float4*>(simg + (size_t)rr * a.W + q);
+              sv[u][0] = t.x; sv[u][1 % VEC] = t.y; sv[u][2 % VEC] = t.z; sv[u][3 % VEC] = t.w;
+            } else {
+              sv[u][0] = simg[(size_t)rr * a.W + q];
+            }
+          }
         }
       };
-      auto project_rows = [&](const float (&z)[kRowsInFlight][VEC], int r) {
+      auto project_rows = [&](const float (&z)[kRowsInFlight][VEC],
+                              const float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u) {
           const int rr = r + u * rows_per_iter;
@@ -370,14 +391,16 @@ k_window_scatter(ScatterArgs a) {
             const unsigned uz = (unsigned)(floor_to_int(zf) - w.z0);
             ok[k] = !__builtin_isunordered(xf, zf) && ux < (unsigned)w.w &&
                     uz < (unsigned)w.h && zz <= a.dmax && zz >= a.dmin && h1 <= a.hmax;
-            if (!FAST) ok[k] = ok[k] && (h2 == h2);
+            if (!FAST && !HAS_VALUE) ok[k] = ok[k] && (h2 == h2);
+            const float sval = HAS_VALUE ? sv[u][k] : h2;
+            if (HAS_VALUE) ok[k] = ok[k] && (sval == sval);      // NaN never replaces a number
             // rejected pixels are redirected to a per-lane dummy cell behind the
             // window instead of being branched around: the whole row group stays
             // one basic block the scheduler can interleave
             unsigned cell = __umul24(uz, (unsigned)w.w) + ux;
             asm("" : "+v"(cell));   // keep the select below a v_cndmask, not a branch
             li[k] = ok[k] ? cell : dummy;
-            hv[k] = h2;
+            hv[k] = sval;
           }
 #pragma unroll
           for (int k = 0; k < VEC; ++k) lds_reduce<IS_MAX>(lds + li[k], hv[k]);
@@ -386,16 +409,16 @@ k_window_scatter(ScatterArgs a) {
       const int niter = (r1 - r0 + step - 1) / step;             // wave-uniform
       const int fill_per_iter = (fill_steps + niter - 1) / niter;
       int r = r0 + gy;
-      load_rows(za, r);
+      load_rows(za, va, r);
       for (int it = 0; it < niter; it += 2) {
-        load_rows(zb_, r + step);
+        load_rows(zb_, vb_, r + step);
         // fill stores are issued after the loads, so no load ever waits on them
         for (int t = 0; t < fill_per_iter && fs < fill_steps; ++t) fill_step();
-        project_rows(za, r);
+        project_rows(za, va, r);
         if (it + 1 < niter) {
-          load_rows(za, r + 2 * step);
+          load_rows(za, va, r + 2 * step);
           for (int t = 0; t < fill_per_iter && fs < fill_steps; ++t) fill_step();
-          project_rows(zb_, r + step);
+          project_rows(zb_, vb_, r + step);
         }
         r += 2 * step;
       }
@@ -403,14 +426,14 @@ k_window_scatter(ScatterArgs a) {
   }
   while (fs < fill_steps) fill_step();
   __syncthreads();
-  const int pid = (b * a.dc + ch) * nparts + part;
+  const int pid = (b * a.oc + chl) * nparts + part;      // slabs are per channel group
   float* slab = a.slabs + (size_t)pid * a.slab_stride;
   for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
     *reinterpret_cast<float4*>(slab + i) = *reinterpret_cast<const float4*>(lds + i);
 }
 
 struct MergeArgs {
-  int B, dc, mh, mw;
+  int B, oc, ch0, oc_total, mh, mw;   // oc channels per frame in this launch, starting at ch0
   int nparts;                 // pc * pr
   int slab_stride;
   float fill;
@@ -431,8 +454,9 @@ constexpr int kMergeGroups = 1;     // float4 groups per thread (more waves hide
 template <bool IS_MAX>
 __global__ void __launch_bounds__(kMergeThreads)
 k_window_merge(MergeArgs a) {
-  const int fc = blockIdx.y;                   // frame * dc + channel
-  const int b = fc / a.dc;
+  const int fc = blockIdx.y;                   // frame * oc + channel of the group
+  const int b = fc / a.oc;
+  const size_t fo = (size_t)b * a.oc_total + a.ch0 + (fc - b * a.oc);   // map index in `out`
   const Window U = a.unions[b];
   const int ug4 = U.w >> 2;                    // float4 groups per U row
   const int total = ug4 * U.h;
@@ -468,13 +492,13 @@ k_window_merge(MergeArgs a) {
 #pragma unroll
   for (int j = 0; j < kMergeGroups; ++j) {
     if (first + j * kMergeThreads >= total) break;
-    const size_t cell = (size_t)fc * M + (size_t)zb[j] * a.mw + x[j];
+    const size_t cell = fo * M + (size_t)zb[j] * a.mw + x[j];
     *reinterpret_cast<float4*>(a.out + cell) = acc[j];
     const uint32_t mk = (uint32_t)mask_of(acc[j].x, a.fill) |
                         ((uint32_t)mask_of(acc[j].y, a.fill) << 8) |
                         ((uint32_t)mask_of(acc[j].z, a.fill) << 16) |
                         ((uint32_t)mask_of(acc[j].w, a.fill) << 24);
-    *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+    if (a.mask) *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
   }
 }
 
@@ -556,42 +580,184 @@ k_fuse_unions(FuseArgs a) {
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 bool window_path_supported(const dm_params& p) {
-  if (p.vc != 0) return false;
   if (p.reduction != DM_REDUCE_MAX && p.reduction != DM_REDUCE_MIN) return false;
   if (p.mw % 4 != 0) return false;
   if (!(p.fill == p.fill)) return false;       // NaN fill has no order
   return true;
 }
 
+static constexpr size_t kSlabBudget = (size_t)256 << 20;   // slab bytes per channel group
+
 size_t window_workspace_bytes(const dm_params& p) {
-  // frames | windows | slabs (worst case: every window as large as LDS allows)
-  const Parts s = choose_parts(p);
-  const size_t nparts = (size_t)s.pc * s.pr;
+  // frames | windows + unions | slabs of one channel group.  Sized for up to 4x the
+  // default number of parts (run_window splits further only when windows do not fit
+  // in LDS, and falls back to the generic path if the workspace cannot hold that).
   size_t cap = (size_t)p.mh * p.mw;
   if (cap > kMaxLdsBytes / 4) cap = kMaxLdsBytes / 4;
+  const Parts d = choose_parts(p, 1);
+  size_t np = (size_t)d.pc * d.pr * 4;
+  if (np > 128) np = 128;
+  const size_t oc = p.vc ? p.vc : p.dc;
+  const size_t one = (size_t)p.B * np * align_up(cap, 4) * 4;     // one channel of every frame
+  size_t slabs = one * oc;
+  if (slabs > kSlabBudget) slabs = one > kSlabBudget ? one : kSlabBudget;
   return align_up((size_t)p.B * sizeof(dm_frame), 256) +
-         align_up((size_t)p.B * (nparts + 1) * sizeof(Window), 256) +
-         (size_t)p.B * p.dc * nparts * align_up(cap, 4) * 4;
+         align_up((size_t)p.B * (128 + 1) * sizeof(Window), 256) + slabs;
 }
 
-// Returns hipErrorNotSupported when some window does not fit in LDS (the caller
-// then takes the generic path); nothing has been enqueued in that case.
+namespace {
+
+struct Staged {                 // what run_window keeps between its passes
+  Parts parts;
+  int nparts, slab_stride, max_union;
+  size_t frames_bytes, win_bytes;
+  bool fast, fast_div;
+  float res_inv, fx_inv, fy_inv;
+};
+
+// One pass: scatter `value` (or the heights when NULL) of channels [0, oc_total)
+// into out/mask, channel group by channel group.
+hipError_t window_pass(const dm_params& p, const Staged& st, unsigned char* base,
+                       const float* depth, const float* value, const uint8_t* valid, float* out,
+                       uint8_t* mask, int oc_total, float fill, bool is_max, size_t slab_bytes,
+                       hipStream_t s) {
+  ScatterArgs sa;
+  sa.W = p.W; sa.H = p.H;
+  sa.clip = p.clip_border > 0 ? p.clip_border : 0;
+  sa.flip_h = p.flip_h != 0;
+  sa.cx = p.cx; sa.cy = p.cy; sa.fx = p.fx; sa.fy = p.fy; sa.res = p.res;
+  sa.res_inv = st.res_inv; sa.fx_inv = st.fx_inv; sa.fy_inv = st.fy_inv;
+  sa.dmin = p.has_dmin ? p.dmin : -INFINITY;
+  sa.dmax = p.has_dmax ? p.dmax : INFINITY;
+  sa.hmax = p.has_hmax ? p.hmax : INFINITY;
+  sa.Hm1 = (float)(p.H - 1); sa.mhm1 = (float)(p.mh - 1);
+  sa.parts = st.parts;
+  sa.dc = p.dc; sa.valid_c = p.valid_c;
+  sa.oc_total = oc_total;
+  sa.slab_stride = st.slab_stride;
+  sa.fill = fill;
+  sa.frames = reinterpret_cast<const dm_frame*>(base);
+  sa.windows = reinterpret_cast<const Window*>(base + st.frames_bytes);
+  sa.depth = depth; sa.value = value; sa.valid = valid;
+  sa.slabs = reinterpret_cast<float*>(base + st.frames_bytes + st.win_bytes);
+  sa.unions = sa.windows + (size_t)p.B * st.nparts;
+  sa.out = out; sa.mask = mask; sa.mh = p.mh; sa.mw = p.mw;
+
+  const bool has_valid = valid != nullptr, has_value = value != nullptr;
+  const bool vec4 = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(depth) % 16 == 0) &&
+                    (!value || reinterpret_cast<uintptr_t>(value) % 16 == 0) &&
+                    (st.parts.wp % 4 == 0);
+  const size_t lds_bytes = align_up((size_t)st.slab_stride * 4, 16) + 64 * 4;   // + dummy cells
+  using Kernel = void (*)(ScatterArgs);
+#define DM_K(M, F, V, S) {k_window_scatter<M, F, V, S, 1>, k_window_scatter<M, F, V, S, 4>}
+  // [is_max][fast][has_valid][has_value][vec4]
+  static const Kernel table[2][2][2][2][2] = {
+      {{{DM_K(false, false, false, false), DM_K(false, false, false, true)},
+        {DM_K(false, false, true, false), DM_K(false, false, true, true)}},
+       {{DM_K(false, true, false, false), DM_K(false, true, false, true)},
+        {DM_K(false, true, true, false), DM_K(false, true, true, true)}}},
+      {{{DM_K(true, false, false, false), DM_K(true, false, false, true)},
+        {DM_K(true, false, true, false), DM_K(true, false, true, true)}},
+       {{DM_K(true, true, false, false), DM_K(true, true, false, true)},
+        {DM_K(true, true, true, false), DM_K(true, true, true, true)}}}};
+#undef DM_K
+  const Kernel kfn = table[is_max][st.fast][has_valid][has_value][vec4];
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
+  if (e != hipSuccess) return e;
+
+  // channel groups: the slabs of one group fit the workspace's slab region
+  const size_t per_channel = (size_t)p.B * st.nparts * st.slab_stride * 4;
+  int group = (int)(slab_bytes / (per_channel ? per_channel : 1));
+  if (group < 1) group = 1;
+  if (group > oc_total) group = oc_total;
+  while ((long)p.B * group > 65535) --group;
+  for (int ch0 = 0; ch0 < oc_total; ch0 += group) {
+    const int oc = oc_total - ch0 < group ? oc_total - ch0 : group;
+    sa.oc = oc; sa.ch0 = ch0;
+    hipLaunchKernelGGL(kfn, dim3(st.nparts, oc, p.B), dim3(kScatterThreads), lds_bytes, s, sa);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (st.max_union > 0) {
+      MergeArgs ma;
+      ma.B = p.B; ma.oc = oc; ma.ch0 = ch0; ma.oc_total = oc_total; ma.mh = p.mh; ma.mw = p.mw;
+      ma.nparts = st.nparts; ma.slab_stride = st.slab_stride; ma.fill = fill;
+      ma.windows = sa.windows; ma.unions = sa.unions; ma.slabs = sa.slabs;
+      ma.out = out; ma.mask = mask;
+      const int per_block = kMergeThreads * kMergeGroups;          // float4 groups
+      dim3 g((unsigned)((st.max_union / 4 + per_block - 1) / per_block), p.B * oc);
+      if (is_max) hipLaunchKernelGGL(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma);
+      else hipLaunchKernelGGL(k_window_merge<false>, g, dim3(kMergeThreads), 0, s, ma);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+    }
+  }
+  return hipSuccess;
+}
+
+}  // namespace
+
+// Returns hipErrorNotSupported when the windows cannot be made to fit in LDS (the
+// caller then takes the generic path); nothing has been enqueued in that case.
 hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const float* depth,
-                      const uint8_t* valid, float* out, uint8_t* mask, float* fused,
-                      uint8_t* fused_mask, void* ws, hipEvent_t after_projection, hipStream_t s) {
-  const Parts parts = choose_parts(p);
-  const int nparts = parts.pc * parts.pr;
-  if ((long)p.B * p.dc > 65535) return hipErrorNotSupported;
+                      const float* value, const uint8_t* valid, float* out, uint8_t* mask,
+                      float* height, float* fused, uint8_t* fused_mask, void* ws,
+                      size_t ws_bytes, hipEvent_t after_projection, hipStream_t s) {
+  const int oc_total = p.vc ? p.vc : p.dc;
   if (reinterpret_cast<uintptr_t>(out) % 16 != 0 || reinterpret_cast<uintptr_t>(mask) % 4 != 0 ||
       reinterpret_cast<uintptr_t>(ws) % 256 != 0 || reinterpret_cast<uintptr_t>(fused) % 16 != 0 ||
-      reinterpret_cast<uintptr_t>(fused_mask) % 4 != 0)
+      reinterpret_cast<uintptr_t>(fused_mask) % 4 != 0 ||
+      reinterpret_cast<uintptr_t>(height) % 16 != 0)
     return hipErrorNotSupported;
   // host staging (thread-local: hipMemcpyAsync from pageable memory has copied
   // the bytes out by the time it returns)
   thread_local std::vector<unsigned char> staging;
-  const size_t frames_bytes = align_up((size_t)p.B * sizeof(dm_frame), 256);
-  const size_t win_bytes = align_up((size_t)p.B * (nparts + 1) * sizeof(Window), 256);
-  staging.resize(frames_bytes + win_bytes);
+  Staged st;
+  st.frames_bytes = align_up((size_t)p.B * sizeof(dm_frame), 256);
+  // more, narrower parts until every window fits in LDS
+  int max_area = 0;
+  Window* wins = nullptr;
+  Window* unions = nullptr;
+  for (int min_parts = 1;; min_parts *= 2) {
+    st.parts = choose_parts(p, min_parts);
+    st.nparts = st.parts.pc * st.parts.pr;
+    if (st.nparts > 128) return hipErrorNotSupported;
+    st.win_bytes = align_up((size_t)p.B * (st.nparts + 1) * sizeof(Window), 256);
+    staging.resize(st.frames_bytes + st.win_bytes);
+    wins = reinterpret_cast<Window*>(staging.data() + st.frames_bytes);
+    unions = wins + (size_t)p.B * st.nparts;     // (B): bounding box of a frame's windows
+    max_area = 0; st.max_union = 0;
+    for (int b = 0; b < p.B; ++b) {
+      int ux0 = p.mw, ux1 = 0, uz0 = p.mh, uz1 = 0;
+      for (int pr = 0; pr < st.parts.pr; ++pr)
+        for (int pc = 0; pc < st.parts.pc; ++pc) {
+          const int q0 = pc * st.parts.wp, r0 = pr * st.parts.hp;
+          const int q1 = q0 + st.parts.wp < p.W ? q0 + st.parts.wp : p.W;
+          const int r1 = r0 + st.parts.hp < p.H ? r0 + st.parts.hp : p.H;
+          const Window w = part_window(p, frames_host[b], q0, q1, r0, r1);
+          wins[(size_t)b * st.nparts + pr * st.parts.pc + pc] = w;
+          if (w.w * w.h > max_area) max_area = w.w * w.h;
+          if (w.w > 0) {
+            if (w.x0 < ux0) ux0 = w.x0;
+            if (w.x0 + w.w > ux1) ux1 = w.x0 + w.w;
+            if (w.z0 < uz0) uz0 = w.z0;
+            if (w.z0 + w.h > uz1) uz1 = w.z0 + w.h;
+          }
+        }
+      unions[b] = ux1 > ux0 ? Window{ux0, uz0, ux1 - ux0, uz1 - uz0} : Window{0, 0, 0, 0};
+      if (unions[b].w * unions[b].h > st.max_union) st.max_union = unions[b].w * unions[b].h;
+    }
+    if ((size_t)max_area * 4 + 64 * 4 + 16 <= (size_t)kMaxLdsBytes) break;
+    // a window that is the whole map cannot shrink by splitting the image
+    if (!p.has_dmin || !p.has_dmax || st.nparts >= 64 ||
+        st.parts.pc * st.parts.pr == choose_parts(p, min_parts * 2).pc * choose_parts(p, min_parts * 2).pr)
+      return hipErrorNotSupported;
+  }
+  st.slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 4);
+  const size_t fixed = st.frames_bytes + st.win_bytes;
+  if (ws_bytes < fixed + (size_t)p.B * st.nparts * st.slab_stride * 4) return hipErrorNotSupported;
+  const size_t slab_bytes = ws_bytes - fixed;
+
   memcpy(staging.data(), frames_host, (size_t)p.B * sizeof(dm_frame));
   if (!p.to_global) {     // local map: neutral yaw, no translation (exact: x*1 + z*0 + 0)
     dm_frame* fr = reinterpret_cast<dm_frame*>(staging.data());
@@ -601,104 +767,25 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
       fr[b].tx = 0.0f; fr[b].tz = 0.0f;
     }
   }
-  Window* wins = reinterpret_cast<Window*>(staging.data() + frames_bytes);
-  Window* unions = wins + (size_t)p.B * nparts;       // (B): bounding box of a frame's windows
-  int max_area = 0, max_union = 0;
-  for (int b = 0; b < p.B; ++b) {
-    int ux0 = p.mw, ux1 = 0, uz0 = p.mh, uz1 = 0;
-    for (int pr = 0; pr < parts.pr; ++pr)
-      for (int pc = 0; pc < parts.pc; ++pc) {
-        const int q0 = pc * parts.wp, r0 = pr * parts.hp;
-        const int q1 = q0 + parts.wp < p.W ? q0 + parts.wp : p.W;
-        const int r1 = r0 + parts.hp < p.H ? r0 + parts.hp : p.H;
-        const Window w = part_window(p, frames_host[b], q0, q1, r0, r1);
-        wins[(size_t)b * nparts + pr * parts.pc + pc] = w;
-        if (w.w * w.h > max_area) max_area = w.w * w.h;
-        if (w.w > 0) {
-          if (w.x0 < ux0) ux0 = w.x0;
-          if (w.x0 + w.w > ux1) ux1 = w.x0 + w.w;
-          if (w.z0 < uz0) uz0 = w.z0;
-          if (w.z0 + w.h > uz1) uz1 = w.z0 + w.h;
-        }
-      }
-    unions[b] = ux1 > ux0 ? Window{ux0, uz0, ux1 - ux0, uz1 - uz0} : Window{0, 0, 0, 0};
-    if (unions[b].w * unions[b].h > max_union) max_union = unions[b].w * unions[b].h;
-  }
-  if ((size_t)max_area * 4 + 64 * 4 + 16 > (size_t)kMaxLdsBytes) return hipErrorNotSupported;
-  const int slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 4);
-  hipError_t e;
+  // branch-free exact division needs exactly rounded reciprocals and sane magnitudes
+  st.fast_div = exact_reciprocal(p.res, &st.res_inv) && exact_reciprocal(p.fx, &st.fx_inv) &&
+                exact_reciprocal(p.fy, &st.fy_inv) && p.res >= 1e-6f && p.res <= 1e6f &&
+                p.fx >= 1e-6f && p.fx <= 1e6f && p.fy >= 1e-6f && p.fy <= 1e6f;
+  if (!st.fast_div) st.res_inv = st.fx_inv = st.fy_inv = 0.0f;
+  st.fast = st.fast_div && axis_aligned(reinterpret_cast<const dm_frame*>(staging.data()), p.B);
 
   unsigned char* base = static_cast<unsigned char*>(ws);
-  e = hipMemcpyAsync(base, staging.data(), frames_bytes + win_bytes,
-                                hipMemcpyHostToDevice, s);
+  hipError_t e = hipMemcpyAsync(base, staging.data(), fixed, hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return e;
 
-  ScatterArgs sa;
-  sa.W = p.W; sa.H = p.H;
-  sa.clip = p.clip_border > 0 ? p.clip_border : 0;
-  sa.flip_h = p.flip_h != 0;
-  sa.cx = p.cx; sa.cy = p.cy; sa.fx = p.fx; sa.fy = p.fy; sa.res = p.res;
-  // branch-free exact division needs exactly rounded reciprocals and sane magnitudes
-  const bool fast_div = exact_reciprocal(p.res, &sa.res_inv) &&
-                        exact_reciprocal(p.fx, &sa.fx_inv) &&
-                        exact_reciprocal(p.fy, &sa.fy_inv) &&
-                        p.res >= 1e-6f && p.res <= 1e6f && p.fx >= 1e-6f && p.fx <= 1e6f &&
-                        p.fy >= 1e-6f && p.fy <= 1e6f;
-  if (!fast_div) sa.res_inv = sa.fx_inv = sa.fy_inv = 0.0f;
-  sa.dmin = p.has_dmin ? p.dmin : -INFINITY;
-  sa.dmax = p.has_dmax ? p.dmax : INFINITY;
-  sa.hmax = p.has_hmax ? p.hmax : INFINITY;
-  sa.Hm1 = (float)(p.H - 1); sa.mhm1 = (float)(p.mh - 1);
-  sa.parts = parts;
-  sa.dc = p.dc; sa.valid_c = p.valid_c;
-  sa.slab_stride = slab_stride;
-  sa.fill = p.fill;
-  sa.frames = reinterpret_cast<const dm_frame*>(base);
-  sa.windows = reinterpret_cast<const Window*>(base + frames_bytes);
-  sa.depth = depth; sa.valid = valid;
-  sa.slabs = reinterpret_cast<float*>(base + frames_bytes + win_bytes);
-  sa.unions = sa.windows + (size_t)p.B * nparts;
-  sa.out = out; sa.mask = mask; sa.mh = p.mh; sa.mw = p.mw;
-
   const bool is_max = p.reduction == DM_REDUCE_MAX;
-  const bool fast = fast_div && axis_aligned(reinterpret_cast<const dm_frame*>(staging.data()), p.B);
-  const bool has_valid = valid != nullptr;
-  const bool vec4 = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(depth) % 16 == 0) &&
-                    (parts.wp % 4 == 0);
-  const size_t lds_bytes = align_up((size_t)slab_stride * 4, 16) + 64 * 4;   // + dummy cells
-  dim3 grid(nparts, p.dc, p.B);
-
-  {
-    using Kernel = void (*)(ScatterArgs);
-    // [is_max][fast][has_valid][vec4]
-    static const Kernel table[2][2][2][2] = {
-        {{{k_window_scatter<false, false, false, 1>, k_window_scatter<false, false, false, 4>},
-          {k_window_scatter<false, false, true, 1>, k_window_scatter<false, false, true, 4>}},
-         {{k_window_scatter<false, true, false, 1>, k_window_scatter<false, true, false, 4>},
-          {k_window_scatter<false, true, true, 1>, k_window_scatter<false, true, true, 4>}}},
-        {{{k_window_scatter<true, false, false, 1>, k_window_scatter<true, false, false, 4>},
-          {k_window_scatter<true, false, true, 1>, k_window_scatter<true, false, true, 4>}},
-         {{k_window_scatter<true, true, false, 1>, k_window_scatter<true, true, false, 4>},
-          {k_window_scatter<true, true, true, 1>, k_window_scatter<true, true, true, 4>}}}};
-    const Kernel kfn = table[is_max][fast][has_valid][vec4];
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
+  e = window_pass(p, st, base, depth, value, valid, out, mask, oc_total, p.fill, is_max,
+                  slab_bytes, s);
+  if (e != hipSuccess) return e;
+  if (height && value) {      // maps.py:332-350: second projection, NINF fill, max
+    e = window_pass(p, st, base, depth, nullptr, valid, height, nullptr, p.dc, -INFINITY, true,
+                    slab_bytes, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kfn, grid, dim3(kScatterThreads), lds_bytes, s, sa);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-  }
-
-  if (max_union > 0) {
-    MergeArgs ma;
-    ma.B = p.B; ma.dc = p.dc; ma.mh = p.mh; ma.mw = p.mw;
-    ma.nparts = nparts; ma.slab_stride = slab_stride; ma.fill = p.fill;
-    ma.windows = sa.windows; ma.unions = sa.unions; ma.slabs = sa.slabs;
-    ma.out = out; ma.mask = mask;
-    const int per_block = kMergeThreads * kMergeGroups;          // float4 groups
-    dim3 g((unsigned)((max_union / 4 + per_block - 1) / per_block), p.B * p.dc);
-    if (is_max) hipLaunchKernelGGL(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma);
-    else hipLaunchKernelGGL(k_window_merge<false>, g, dim3(kMergeThreads), 0, s, ma);
   }
   if (after_projection) {
     e = hipEventRecord(after_projection, s);
@@ -706,9 +793,10 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
   }
   if (fused) {
     FuseArgs fa;
-    fa.B = p.B; fa.dc = p.dc; fa.mh = p.mh; fa.mw = p.mw; fa.fill = p.fill;
-    fa.unions = sa.unions; fa.maps = out; fa.fused = fused; fa.fused_mask = fused_mask;
-    dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kFuseGroups - 1) / kFuseGroups), p.dc);
+    fa.B = p.B; fa.dc = oc_total; fa.mh = p.mh; fa.mw = p.mw; fa.fill = p.fill;
+    fa.unions = reinterpret_cast<const Window*>(base + st.frames_bytes) + (size_t)p.B * st.nparts;
+    fa.maps = out; fa.fused = fused; fa.fused_mask = fused_mask;
+    dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kFuseGroups - 1) / kFuseGroups), oc_total);
     const dim3 blk(kFuseGroups * kFuseLanes);
     if (is_max) hipLaunchKernelGGL(k_fuse_unions<true>, g, blk, 0, s, fa);
     else hipLaunchKernelGGL(k_fuse_unions<false>, g, blk, 0, s, fa);

@@ -266,16 +266,26 @@ def test_full_size_properties(dmap):
     dict(B=300, H=24, W=32, mh=64, mw=64),                        # more frames than CUs
     dict(B=2, H=96, W=128, mh=128, mw=128, res=1.0 / 3),
     dict(B=2, H=96, W=128, mh=128, mw=128, woff=1000.0),          # frustum misses the map
+    dict(B=3, H=96, W=128, mh=128, mw=128, C=5, fill_value=0.0),   # value map, shared index
+    dict(B=2, H=96, W=128, mh=128, mw=128, C=3, dc=3, fill_value=-1.0, reduction="min"),
+    dict(B=70, H=48, W=64, mh=256, mw=256, C=9, res=0.02),         # many channels: 1 strip too big -> split
 ])
 def test_window_path_equals_generic_path(dmap, oracle, case):
   from dungeon_maps_amd import _native
   c = dict(case)
   B, H, W, mh, mw = (c.pop(k) for k in ("B", "H", "W", "mh", "mw"))
+  C, dcn = c.pop("C", 0), c.pop("dc", 1)
   use_valid = c.pop("valid", False)
   res = c.pop("res", 0.05)
   woff = c.pop("woff", mw / 2.)
   depth, pose = _synthetic(B, H, W, seed=4321)
   depth[:, :, 0, :3] = [np.nan, np.inf, -1.0]
+  if dcn > 1:
+    depth = np.concatenate([depth * (1 + 0.1 * k) for k in range(dcn)], axis=1)
+  value = None
+  if C:
+    value = np.random.default_rng(2).normal(size=(B, C, H, W)).astype(np.float32)
+    value[:, :, 1, :2] = np.nan                  # NaN values never replace a number
   valid = None
   if use_valid:
     valid = (np.random.default_rng(1).uniform(size=(B, 1, H, W)) > 0.4)
@@ -285,16 +295,19 @@ def test_window_path_equals_generic_path(dmap, oracle, case):
              to_global=True, fill_value=-np.inf)
   cfg.update(c)
   lib = _native.lib()
-  fast = _run(dmap, cfg, depth, valid=valid, cam_pose=pose)
+  gh = bool(C)
+  fast = _run(dmap, cfg, depth, value=value, valid=valid, get_height_map=gh, cam_pose=pose)
   lib.dm_debug_force_generic_path(1)
   try:
-    slow = _run(dmap, cfg, depth, valid=valid, cam_pose=pose)
+    slow = _run(dmap, cfg, depth, value=value, valid=valid, get_height_map=gh, cam_pose=pose)
   finally:
     lib.dm_debug_force_generic_path(0)
-  np.testing.assert_array_equal(fast[1], slow[1])
-  np.testing.assert_array_equal(fast[0], slow[0])
+  for f, s_ in zip(fast, slow):
+    np.testing.assert_array_equal(f, s_)
   if B <= 8:
-    want = oracle.orth_project(depth, valid_map=valid,
+    want = oracle.orth_project(depth, value_map=value, valid_map=valid, get_height_map=gh,
                                **dict(_oracle_kwargs(oracle, cfg), cam_pose=pose))
     np.testing.assert_array_equal(fast[1], want[1])
     np.testing.assert_array_equal(fast[0], want[0])
+    if gh:
+      np.testing.assert_array_equal(fast[2], np.ascontiguousarray(want[2]))

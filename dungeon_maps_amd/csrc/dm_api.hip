@@ -113,7 +113,7 @@ int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames,
                 p->reduction);
   if (!out_dev || !mask_dev || (p->B > 0 && (!frames || !depth_dev)))
     return fail(DM_ERR_INVALID_ARGUMENT, "frames/depth/out/mask must not be NULL");
-  const size_t need = dm::generic_workspace_bytes(*p);
+  const size_t need = dm_orth_project_workspace_bytes(p);
   if (need > workspace_bytes || !workspace_dev)
     return fail(DM_ERR_WORKSPACE_TOO_SMALL, "workspace %zu B < required %zu B", workspace_bytes,
                 need);
@@ -121,9 +121,16 @@ int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames,
     return fail(DM_ERR_INVALID_ARGUMENT, "value pointer and vc=%d disagree", p->vc);
   if ((p->valid_c > 0) != (valid_dev != nullptr) && p->B > 0)
     return fail(DM_ERR_INVALID_ARGUMENT, "valid pointer and valid_c=%d disagree", p->valid_c);
-  hipError_t e = dm::run_generic_fused(*p, frames, depth_dev, value_dev, valid_dev, out_dev,
-                                       mask_dev, accumulate, workspace_dev,
-                                       static_cast<hipStream_t>(stream));
+  if (p->B == 0 && !accumulate)
+    return fail(DM_ERR_INVALID_ARGUMENT, "cannot fuse an empty batch without accumulate");
+  hipError_t e = hipErrorNotSupported;
+  if (p->B > 0 && dm::window_path_supported(*p) && !g_force_generic)
+    e = dm::run_window_fused(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
+                             accumulate, workspace_dev, workspace_bytes,
+                             static_cast<hipStream_t>(stream));
+  if (e == hipErrorNotSupported)
+    e = dm::run_generic_fused(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
+                              accumulate, workspace_dev, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
   return DM_OK;
 }

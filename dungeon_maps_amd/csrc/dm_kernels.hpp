@@ -29,6 +29,10 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
                       float* height, float* fused, uint8_t* fused_mask, void* ws,
                       size_t ws_bytes, hipEvent_t after_projection, hipStream_t s);
 
+hipError_t run_window_fused(const dm_params& p, const dm_frame* frames_host, const float* depth,
+                            const float* value, const uint8_t* valid, float* out, uint8_t* mask,
+                            int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+
 // dm_points.hip -- exact point-set primitives (affine, quantise, flat scatter)
 hipError_t run_affine_points(const float* pts, const float* R, const float* t, int B,
                              size_t n_per_batch, int translate_first, float* out, hipStream_t s);

@@ -238,7 +238,7 @@ k_window_scatter(ScatterArgs a) {
   const Window U = a.unions[b];
   const int g4 = a.mw >> 2;
   const int g4_shift = (g4 & (g4 - 1)) == 0 ? __builtin_ctz(g4) : -1;   // wave-uniform
-  const int fill_total = ((a.mh - part + nparts - 1) / nparts) * g4;
+  const int fill_total = a.out ? ((a.mh - part + nparts - 1) / nparts) * g4 : 0;
   const int fill_steps = (fill_total + kScatterThreads - 1) / kScatterThreads;
   const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
   int fs = 0;
@@ -572,6 +572,79 @@ k_fuse_unions(FuseArgs a) {
   }
 }
 
+// Direct batch fuse from the slabs (dm_orth_project_fused_f32): fused[c] =
+// max/min over every (frame, part) window covering c of its slab value -- the
+// per-frame maps are never materialised.  Same block shape as k_fuse_unions; the
+// 8 lanes of a group split the B * nparts windows.
+struct FuseWinArgs {
+  int nwin;                   // B * nparts windows per channel
+  int nparts, oc, ch0, oc_total, mh, mw;
+  int slab_stride;
+  int accumulate;
+  float fill;
+  const Window* windows;
+  const float* slabs;         // ((b * oc + chl) * nparts + p) * slab_stride
+  float* fused;               // (oc_total, mh, mw)
+  uint8_t* fused_mask;
+};
+
+template <bool IS_MAX>
+__global__ void __launch_bounds__(kFuseGroups * kFuseLanes)
+k_fuse_windows(FuseWinArgs a) {
+  __shared__ float4 part[kFuseLanes][kFuseGroups];
+  const int chl = blockIdx.y, ch = a.ch0 + chl;
+  const int g4 = a.mw >> 2;
+  const int gi = threadIdx.x & (kFuseGroups - 1), lane = threadIdx.x / kFuseGroups;
+  const int g = blockIdx.x * kFuseGroups + gi;
+  const bool live = g < g4 * a.mh;
+  const int z = live ? g / g4 : 0, x = live ? (g - z * g4) << 2 : 0;
+  const size_t M = (size_t)a.mh * a.mw;
+  const size_t cell = (size_t)ch * M + (size_t)z * a.mw + x;
+  float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+  if (a.accumulate && lane == 0 && live) acc = *reinterpret_cast<const float4*>(a.fused + cell);
+  for (int r0 = lane; r0 < a.nwin; r0 += 8 * kFuseLanes) {
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = r0 + k * kFuseLanes;
+      v[k] = acc;
+      if (r < a.nwin) {
+        const Window w = a.windows[r];
+        const unsigned ux = (unsigned)(x - w.x0), uz = (unsigned)(z - w.z0);
+        if (ux < (unsigned)w.w && uz < (unsigned)w.h) {
+          const int b = r / a.nparts, p = r - b * a.nparts;
+          const float* slab = a.slabs + ((size_t)(b * a.oc + chl) * a.nparts + p) * a.slab_stride;
+          v[k] = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc.x = IS_MAX ? fmaxf(acc.x, v[k].x) : fminf(acc.x, v[k].x);
+      acc.y = IS_MAX ? fmaxf(acc.y, v[k].y) : fminf(acc.y, v[k].y);
+      acc.z = IS_MAX ? fmaxf(acc.z, v[k].z) : fminf(acc.z, v[k].z);
+      acc.w = IS_MAX ? fmaxf(acc.w, v[k].w) : fminf(acc.w, v[k].w);
+    }
+  }
+  part[lane][gi] = acc;
+  __syncthreads();
+  if (lane == 0 && live) {
+#pragma unroll
+    for (int k = 1; k < kFuseLanes; ++k) {
+      const float4 o = part[k][gi];
+      acc.x = IS_MAX ? fmaxf(acc.x, o.x) : fminf(acc.x, o.x);
+      acc.y = IS_MAX ? fmaxf(acc.y, o.y) : fminf(acc.y, o.y);
+      acc.z = IS_MAX ? fmaxf(acc.z, o.z) : fminf(acc.z, o.z);
+      acc.w = IS_MAX ? fmaxf(acc.w, o.w) : fminf(acc.w, o.w);
+    }
+    *reinterpret_cast<float4*>(a.fused + cell) = acc;
+    const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+                        ((uint32_t)mask_of(acc.z, a.fill) << 16) |
+                        ((uint32_t)mask_of(acc.w, a.fill) << 24);
+    *reinterpret_cast<uint32_t*>(a.fused_mask + cell) = mk;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -617,10 +690,13 @@ struct Staged {                 // what run_window keeps between its passes
 
 // One pass: scatter `value` (or the heights when NULL) of channels [0, oc_total)
 // into out/mask, channel group by channel group.
+// With `fused` set, the per-frame maps are skipped (out/mask NULL) and every channel
+// group's slabs are reduced straight into the (oc_total, mh, mw) fused map.
 hipError_t window_pass(const dm_params& p, const Staged& st, unsigned char* base,
                        const float* depth, const float* value, const uint8_t* valid, float* out,
                        uint8_t* mask, int oc_total, float fill, bool is_max, size_t slab_bytes,
-                       hipStream_t s) {
+                       hipStream_t s, float* fused = nullptr, uint8_t* fused_mask = nullptr,
+                       int accumulate = 0) {
   ScatterArgs sa;
   sa.W = p.W; sa.H = p.H;
   sa.clip = p.clip_border > 0 ? p.clip_border : 0;
@@ -678,7 +754,19 @@ hipError_t window_pass(const dm_params& p, const Staged& st, unsigned char* base
     hipLaunchKernelGGL(kfn, dim3(st.nparts, oc, p.B), dim3(kScatterThreads), lds_bytes, s, sa);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (st.max_union > 0) {
+    if (fused) {
+      FuseWinArgs fa;
+      fa.nwin = p.B * st.nparts; fa.nparts = st.nparts; fa.oc = oc; fa.ch0 = ch0;
+      fa.oc_total = oc_total; fa.mh = p.mh; fa.mw = p.mw; fa.slab_stride = st.slab_stride;
+      fa.accumulate = accumulate; fa.fill = fill;
+      fa.windows = sa.windows; fa.slabs = sa.slabs; fa.fused = fused; fa.fused_mask = fused_mask;
+      dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kFuseGroups - 1) / kFuseGroups), oc);
+      const dim3 blk(kFuseGroups * kFuseLanes);
+      if (is_max) hipLaunchKernelGGL(k_fuse_windows<true>, g, blk, 0, s, fa);
+      else hipLaunchKernelGGL(k_fuse_windows<false>, g, blk, 0, s, fa);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+    } else if (st.max_union > 0) {
       MergeArgs ma;
       ma.B = p.B; ma.oc = oc; ma.ch0 = ch0; ma.oc_total = oc_total; ma.mh = p.mh; ma.mw = p.mw;
       ma.nparts = st.nparts; ma.slab_stride = st.slab_stride; ma.fill = fill;
@@ -699,20 +787,12 @@ hipError_t window_pass(const dm_params& p, const Staged& st, unsigned char* base
 
 // Returns hipErrorNotSupported when the windows cannot be made to fit in LDS (the
 // caller then takes the generic path); nothing has been enqueued in that case.
-hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const float* depth,
-                      const float* value, const uint8_t* valid, float* out, uint8_t* mask,
-                      float* height, float* fused, uint8_t* fused_mask, void* ws,
-                      size_t ws_bytes, hipEvent_t after_projection, hipStream_t s) {
-  const int oc_total = p.vc ? p.vc : p.dc;
-  if (reinterpret_cast<uintptr_t>(out) % 16 != 0 || reinterpret_cast<uintptr_t>(mask) % 4 != 0 ||
-      reinterpret_cast<uintptr_t>(ws) % 256 != 0 || reinterpret_cast<uintptr_t>(fused) % 16 != 0 ||
-      reinterpret_cast<uintptr_t>(fused_mask) % 4 != 0 ||
-      reinterpret_cast<uintptr_t>(height) % 16 != 0)
-    return hipErrorNotSupported;
+static hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* ws,
+                                size_t ws_bytes, Staged& st, size_t& slab_bytes, hipStream_t s) {
+  if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return hipErrorNotSupported;
   // host staging (thread-local: hipMemcpyAsync from pageable memory has copied
   // the bytes out by the time it returns)
   thread_local std::vector<unsigned char> staging;
-  Staged st;
   st.frames_bytes = align_up((size_t)p.B * sizeof(dm_frame), 256);
   // more, narrower parts until every window fits in LDS
   int max_area = 0;
@@ -756,7 +836,7 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
   st.slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 4);
   const size_t fixed = st.frames_bytes + st.win_bytes;
   if (ws_bytes < fixed + (size_t)p.B * st.nparts * st.slab_stride * 4) return hipErrorNotSupported;
-  const size_t slab_bytes = ws_bytes - fixed;
+  slab_bytes = ws_bytes - fixed;
 
   memcpy(staging.data(), frames_host, (size_t)p.B * sizeof(dm_frame));
   if (!p.to_global) {     // local map: neutral yaw, no translation (exact: x*1 + z*0 + 0)
@@ -774,9 +854,24 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
   if (!st.fast_div) st.res_inv = st.fx_inv = st.fy_inv = 0.0f;
   st.fast = st.fast_div && axis_aligned(reinterpret_cast<const dm_frame*>(staging.data()), p.B);
 
-  unsigned char* base = static_cast<unsigned char*>(ws);
-  hipError_t e = hipMemcpyAsync(base, staging.data(), fixed, hipMemcpyHostToDevice, s);
+  return hipMemcpyAsync(ws, staging.data(), fixed, hipMemcpyHostToDevice, s);
+}
+
+hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const float* depth,
+                      const float* value, const uint8_t* valid, float* out, uint8_t* mask,
+                      float* height, float* fused, uint8_t* fused_mask, void* ws,
+                      size_t ws_bytes, hipEvent_t after_projection, hipStream_t s) {
+  const int oc_total = p.vc ? p.vc : p.dc;
+  if (reinterpret_cast<uintptr_t>(out) % 16 != 0 || reinterpret_cast<uintptr_t>(mask) % 4 != 0 ||
+      reinterpret_cast<uintptr_t>(fused) % 16 != 0 ||
+      reinterpret_cast<uintptr_t>(fused_mask) % 4 != 0 ||
+      reinterpret_cast<uintptr_t>(height) % 16 != 0)
+    return hipErrorNotSupported;
+  Staged st;
+  size_t slab_bytes = 0;
+  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s);
   if (e != hipSuccess) return e;
+  unsigned char* base = static_cast<unsigned char*>(ws);
 
   const bool is_max = p.reduction == DM_REDUCE_MAX;
   e = window_pass(p, st, base, depth, value, valid, out, mask, oc_total, p.fill, is_max,
@@ -802,6 +897,22 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     else hipLaunchKernelGGL(k_fuse_unions<false>, g, blk, 0, s, fa);
   }
   return hipGetLastError();
+}
+
+// dm_orth_project_fused_f32: scatter into the LDS windows, then reduce the slabs of
+// all frames straight into ONE (oc, mh, mw) map (optionally on top of its content).
+hipError_t run_window_fused(const dm_params& p, const dm_frame* frames_host, const float* depth,
+                            const float* value, const uint8_t* valid, float* out, uint8_t* mask,
+                            int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (reinterpret_cast<uintptr_t>(out) % 16 != 0 || reinterpret_cast<uintptr_t>(mask) % 4 != 0)
+    return hipErrorNotSupported;
+  Staged st;
+  size_t slab_bytes = 0;
+  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s);
+  if (e != hipSuccess) return e;
+  return window_pass(p, st, static_cast<unsigned char*>(ws), depth, value, valid, nullptr, nullptr,
+                     p.vc ? p.vc : p.dc, p.fill, p.reduction == DM_REDUCE_MAX, slab_bytes, s, out,
+                     mask, accumulate);
 }
 
 }  // namespace dm

@@ -195,6 +195,14 @@ def test_fused_equals_max_over_frames(dmap, oracle):
                              **dict(_oracle_kwargs(oracle, cfg), cam_pose=pose))
   np.testing.assert_array_equal(fused.cpu().numpy(), want[0])
   np.testing.assert_array_equal(fmask.cpu().numpy(), want[1])
+  # the direct fused projection: LDS fast path == generic path
+  from dungeon_maps_amd import _native as _nat
+  _nat.lib().dm_debug_force_generic_path(1)
+  try:
+    gfused, gmask = proj.orth_project_fused(d, cam_pose=pose)
+  finally:
+    _nat.lib().dm_debug_force_generic_path(0)
+  assert torch.equal(gfused, fused) and torch.equal(gmask, fmask)
   # running world map: fusing two halves one after the other == fusing all
   acc, _ = proj.orth_project_fused(d[:3], cam_pose=pose[:3])
   acc, amask = proj.orth_project_fused(d[3:], cam_pose=pose[3:], out=acc)

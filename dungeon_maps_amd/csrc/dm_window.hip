@@ -588,43 +588,71 @@ struct FuseWinArgs {
   uint8_t* fused_mask;
 };
 
+constexpr int kFuseChunk = 1024;    // windows examined per candidate-list round
+
 template <bool IS_MAX>
 __global__ void __launch_bounds__(kFuseGroups * kFuseLanes)
 k_fuse_windows(FuseWinArgs a) {
   __shared__ float4 part[kFuseLanes][kFuseGroups];
+  __shared__ int4 cwin[kFuseChunk];     // candidate windows {x0, z0, w, h} ...
+  __shared__ int cslab[kFuseChunk];     // ... and their slab index
+  __shared__ int ncand;
   const int chl = blockIdx.y, ch = a.ch0 + chl;
   const int g4 = a.mw >> 2;
   const int gi = threadIdx.x & (kFuseGroups - 1), lane = threadIdx.x / kFuseGroups;
-  const int g = blockIdx.x * kFuseGroups + gi;
-  const bool live = g < g4 * a.mh;
+  const int g0 = blockIdx.x * kFuseGroups;
+  const int g = g0 + gi;
+  const int total = g4 * a.mh;
+  const bool live = g < total;
   const int z = live ? g / g4 : 0, x = live ? (g - z * g4) << 2 : 0;
+  // cells this block covers: rows z_lo..z_hi, and (when it stays in one row) columns
+  const int g_last = (g0 + kFuseGroups - 1 < total ? g0 + kFuseGroups - 1 : total - 1);
+  const int z_lo = g0 / g4, z_hi = g_last / g4;
+  const int x_lo = z_lo == z_hi ? (g0 - z_lo * g4) << 2 : 0;
+  const int x_hi = z_lo == z_hi ? ((g_last - z_lo * g4) << 2) + 4 : a.mw;
   const size_t M = (size_t)a.mh * a.mw;
   const size_t cell = (size_t)ch * M + (size_t)z * a.mw + x;
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
   if (a.accumulate && lane == 0 && live) acc = *reinterpret_cast<const float4*>(a.fused + cell);
-  for (int r0 = lane; r0 < a.nwin; r0 += 8 * kFuseLanes) {
-    float4 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int r = r0 + k * kFuseLanes;
-      v[k] = acc;
-      if (r < a.nwin) {
-        const Window w = a.windows[r];
-        const unsigned ux = (unsigned)(x - w.x0), uz = (unsigned)(z - w.z0);
-        if (ux < (unsigned)w.w && uz < (unsigned)w.h) {
-          const int b = r / a.nparts, p = r - b * a.nparts;
-          const float* slab = a.slabs + ((size_t)(b * a.oc + chl) * a.nparts + p) * a.slab_stride;
-          v[k] = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
-        }
+  for (int c0 = 0; c0 < a.nwin; c0 += kFuseChunk) {
+    // round 1: which windows of this chunk touch the block's cells at all?
+    if (threadIdx.x == 0) ncand = 0;
+    __syncthreads();
+    for (int r = c0 + threadIdx.x; r < a.nwin && r < c0 + kFuseChunk; r += blockDim.x) {
+      const Window w = a.windows[r];
+      if (w.w > 0 && w.z0 <= z_hi && w.z0 + w.h > z_lo && w.x0 < x_hi && w.x0 + w.w > x_lo) {
+        const int slot = atomicAdd(&ncand, 1);
+        const int b = r / a.nparts, p = r - b * a.nparts;
+        cwin[slot] = make_int4(w.x0, w.z0, w.w, w.h);
+        cslab[slot] = (b * a.oc + chl) * a.nparts + p;
       }
     }
+    __syncthreads();
+    // round 2: the 8 lanes of a group split the candidates, four slab loads in flight
+    const int n = ncand;
+    for (int i0 = lane; i0 < n; i0 += 4 * kFuseLanes) {
+      float4 v[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      acc.x = IS_MAX ? fmaxf(acc.x, v[k].x) : fminf(acc.x, v[k].x);
-      acc.y = IS_MAX ? fmaxf(acc.y, v[k].y) : fminf(acc.y, v[k].y);
-      acc.z = IS_MAX ? fmaxf(acc.z, v[k].z) : fminf(acc.z, v[k].z);
-      acc.w = IS_MAX ? fmaxf(acc.w, v[k].w) : fminf(acc.w, v[k].w);
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * kFuseLanes;
+        v[k] = acc;
+        if (i < n) {
+          const int4 w = cwin[i];
+          const unsigned ux = (unsigned)(x - w.x), uz = (unsigned)(z - w.y);
+          if (ux < (unsigned)w.z && uz < (unsigned)w.w)
+            v[k] = *reinterpret_cast<const float4*>(
+                a.slabs + (size_t)cslab[i] * a.slab_stride + (size_t)uz * w.z + ux);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc.x = IS_MAX ? fmaxf(acc.x, v[k].x) : fminf(acc.x, v[k].x);
+        acc.y = IS_MAX ? fmaxf(acc.y, v[k].y) : fminf(acc.y, v[k].y);
+        acc.z = IS_MAX ? fmaxf(acc.z, v[k].z) : fminf(acc.z, v[k].z);
+        acc.w = IS_MAX ? fmaxf(acc.w, v[k].w) : fminf(acc.w, v[k].w);
+      }
     }
+    __syncthreads();
   }
   part[lane][gi] = acc;
   __syncthreads();

@@ -100,6 +100,45 @@ __global__ void __launch_bounds__(1024) k_valu_pkfma(float* out, int iters, floa
   v2f r = x0 + x1 + x2 + x3;
   if (r.x + r.y == 123.456f) out[0] = r.x;
 }
+// instruction-mix probes: 8 independent chains per wave, iters loop trips
+template <int MODE>
+__global__ void __launch_bounds__(1024) k_valu_mix(float* out, int iters, float a, float b, int ia) {
+  float x[8]; int n[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { x[k] = threadIdx.x + k; n[k] = threadIdx.x * 3 + k; }
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (MODE == 0) x[k] = __builtin_fmaf(x[k], a, b);                       // v_fma
+      if (MODE == 1) x[k] = x[k] * a;                                          // v_mul
+      if (MODE == 2) x[k] = __builtin_floorf(x[k] + b);                        // add + floor
+      if (MODE == 3) x[k] = (x[k] > a) ? x[k] - b : x[k] + b;                   // cmp + 2 alu + cndmask
+      if (MODE == 4) n[k] = n[k] * ia + 7;                                     // int mad (32-bit mul)
+      if (MODE == 5) n[k] = (int)__umul24((unsigned)n[k], (unsigned)ia) + 7;   // mul24 + add
+      if (MODE == 6) { n[k] = (int)x[k]; x[k] = (float)(n[k] + 1); }           // cvt i32 <-> f32 + add
+      if (MODE == 7) n[k] = (n[k] + ia) ^ (n[k] >> 3);                         // int add/xor/shift
+    }
+  }
+  float r = 0; int m = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { r += x[k]; m += n[k]; }
+  if (r == 123.456f || m == 123456789) out[0] = r + m;
+}
+// ILP probe: CH independent fma chains per wave
+template <int CH>
+__global__ void __launch_bounds__(1024) k_valu_ilp(float* out, int iters, float a, float b) {
+  float x[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) x[k] = threadIdx.x + k;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < CH; ++k) x[k] = __builtin_fmaf(x[k], a, b);
+  }
+  float r = 0;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) r += x[k];
+  if (r == 123.456f) out[0] = r;
+}
 __global__ void k_empty() {}
 
 template <class F> float time_ms(F f, int reps = 5) {
@@ -127,6 +166,30 @@ int main() {
       n = 256.0 * threads * iters * 4;
       printf("v_pk_fma_f32  %4d thr/CU: %.3f ms  %.1f Tlane-instr/s  (%.1f lanes/clk/CU; x2 flops)\n", threads, ms, n / ms / 1e9, n / ms / 1e-3 / 256 / 2.4e9);
     }
+  }
+  {
+    const int iters = 2048;
+    const char* names[8] = {"v_fma_f32 (1 op)", "v_mul_f32 (1 op)", "add+floor (2 ops)", "cmp+sub+add+cndmask (4 ops)",
+                            "v_mul_lo_u32+add (2 ops)", "mul_u24+add (2 ops)", "cvt_i32_f32+add+cvt_f32_i32 (3 ops)", "add+shift+xor (3 ops)"};
+    const int nops[8] = {1, 1, 2, 4, 2, 2, 3, 3};
+    auto run = [&](int mode, auto kern) {
+      float ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(256), dim3(1024), 0, 0, (float*)dout, iters, 1.0001f, 0.5f, 3); });
+      double waveinstr = 256.0 * 16 * iters * 8 * nops[mode];
+      printf("mix %-40s %.3f ms  %.2f cycles/wave-instr/SIMD @2.1GHz\n", names[mode], ms, ms * 1e-3 * 2.1e9 / (waveinstr / 1024));
+    };
+    run(0, k_valu_mix<0>); run(1, k_valu_mix<1>); run(2, k_valu_mix<2>); run(3, k_valu_mix<3>);
+    run(4, k_valu_mix<4>); run(5, k_valu_mix<5>); run(6, k_valu_mix<6>); run(7, k_valu_mix<7>);
+  }
+  {
+    const int iters = 4096;
+    auto run = [&](int ch, int threads, auto kern) {
+      float ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, (float*)dout, iters, 1.0001f, 0.5f); });
+      double waveinstr = 256.0 * (threads / 64) * iters * ch;
+      printf("ilp chains=%d waves/SIMD=%d: %.2f cycles/wave-instr/SIMD @2.1GHz\n", ch, threads / 256, ms * 1e-3 * 2.1e9 / (waveinstr / 1024));
+    };
+    run(1, 1024, k_valu_ilp<1>); run(2, 1024, k_valu_ilp<2>); run(4, 1024, k_valu_ilp<4>); run(8, 1024, k_valu_ilp<8>); run(16, 1024, k_valu_ilp<16>);
+    run(1, 512, k_valu_ilp<1>); run(4, 512, k_valu_ilp<4>); run(16, 512, k_valu_ilp<16>);
+    run(1, 256, k_valu_ilp<1>); run(4, 256, k_valu_ilp<4>); run(16, 256, k_valu_ilp<16>);
   }
   // LDS atomics: 32K cells (128 KB), 1 block per CU
   {

@@ -103,9 +103,10 @@ def main():
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   dist = None
-  if world > 1:
+  if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run (any N)
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
   import dungeon_maps_amd as dmap
@@ -138,26 +139,65 @@ def main():
     k = torch.arange(B, dtype=torch.float32) + rank * B
     pose = torch.stack((0.02 * k, 0.01 * k, 0.01 * k), dim=1)
 
+  # Cross-rank fuse: every step writes its partial global map into a slot of a ring;
+  # once per RING steps ONE RCCL all-reduce(max) fuses the whole ring (fewer, larger
+  # collectives: xGMI rings are latency bound at 1 MiB) on RCCL's own stream while the
+  # next steps project; the masks of the reduced maps are recomputed afterwards.
+  RING = 8
+  C_out = C if C else 1
+  ring = ring_mask = None
+  if dist is not None:
+    ring = [torch.empty((RING, C_out, mh, mw), dtype=torch.float32, device=dev) for _ in range(2)]
+    ring_mask = [torch.empty((RING, C_out, mh, mw), dtype=torch.bool, device=dev) for _ in range(2)]
+  state = {"slot": 0, "buf": 0, "pending": None}
+
+  def finish_reduce():
+    if state["pending"] is not None:
+      work, buf, n = state["pending"]
+      state["pending"] = None
+      work.wait()                                   # compute stream waits for the collective
+      return dmap.mask_from_map(ring[buf][:n], fill)
+    return None
+
+  def flush_ring():
+    n = state["slot"]
+    if n == 0:
+      return
+    finish_reduce()
+    buf = state["buf"]
+    work = dist.all_reduce(ring[buf][:n], op=dist.ReduceOp.MAX, async_op=True)
+    state["pending"] = (work, buf, n)
+    state["buf"], state["slot"] = 1 - buf, 0
+
+  def next_slot():
+    buf, slot = state["buf"], state["slot"]
+    state["slot"] = slot + 1
+    return ring[buf][slot], ring_mask[buf][slot]
+
   def step(i=None):
     if fused_only:
       if i is not None:
         ev_a[i].record()
-      fused, fmask = proj.orth_project_fused(depth_d, cam_pose=pose)
+      if dist is not None:
+        fused, fmask = next_slot()
+        fused.fill_(fill)          # running-map semantics: start from fill, accumulate
+        fused, fmask = proj.orth_project_fused(depth_d, cam_pose=pose, out=fused)
+      else:
+        fused, fmask = proj.orth_project_fused(depth_d, cam_pose=pose)
       if i is not None:
         ev_b[i].record()
-      if dist is not None:
-        dist.all_reduce(fused, op=dist.ReduceOp.MAX)
-        fmask = dmap.mask_from_map(fused, fill)
+      if dist is not None and state["slot"] == RING:
+        flush_ring()
       return fused, fmask, fused, fmask
     if i is not None:
       ev_a[i].record()
       lib.dm_debug_record_after_projection(ev_b[i].cuda_event)
     # per-frame maps + masks and this rank's partial global map, one launch sequence
-    top, mask, fused, fmask = proj.orth_project_and_fuse(depth_d, value_map=value_d,
-                                                         cam_pose=pose)
-    if dist is not None:
-      dist.all_reduce(fused, op=dist.ReduceOp.MAX)      # RCCL, element-wise max
-      fmask = dmap.mask_from_map(fused, fill)
+    top, mask, fused, fmask = proj.orth_project_and_fuse(
+        depth_d, value_map=value_d, cam_pose=pose,
+        fused_out=next_slot() if dist is not None else None)
+    if dist is not None and state["slot"] == RING:
+      flush_ring()                                      # RCCL, element-wise max
     return top, mask, fused, fmask
 
   def barrier():
@@ -167,10 +207,16 @@ def main():
 
   for _ in range(args.warmup):
     step()
+  if dist is not None:
+    flush_ring()
+    finish_reduce()
   barrier()
   t0 = time.perf_counter()
   for i in range(args.steps):
     out = step(i)
+  if dist is not None:            # every step's all-reduce + mask is inside the timed region
+    flush_ring()
+    finish_reduce()
   torch.cuda.synchronize()
   barrier()
   elapsed = time.perf_counter() - t0
@@ -203,6 +249,9 @@ def main():
                       f"depth={args.depth}, project + fuse(max over frames)"
                       f"{' + RCCL all-reduce(max)' if world > 1 else ''} + mask",
           "frames_per_gpu": B, "global_frames": world * B,
+          "parallelism": f"frames sharded {world}-way; fused maps all-reduced (RCCL max) "
+                         f"{RING} steps at a time, overlapped with the next steps"
+                         if dist is not None else "single GPU",
       },
       "roofline": {
           "bound": "hbm",

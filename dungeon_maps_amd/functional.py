@@ -183,7 +183,7 @@ def orth_project(
     clip_border: Optional[int], to_global: bool, flip_h: bool = True,
     fill_value: Optional[float] = None, reduction: Optional[Reduction] = None,
     get_height_map: bool = False, device: Optional[torch.device] = None,
-    _validate_args: bool = True, _fuse: bool = False
+    _validate_args: bool = True, _fuse: bool = False, _fused_out=None
 ) -> Union[Tuple[torch.Tensor, torch.Tensor],
            Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
   """Orthographic projection of depth maps (b, c, h, w) to top-down maps.
@@ -211,7 +211,13 @@ def orth_project(
   if get_height_map and p.vc:
     height = torch.empty((p.B, p.dc, p.mh, p.mw), dtype=torch.float32, device=call.dev)
   fused = fmask = None
-  if _fuse:
+  if _fuse and _fused_out is not None:
+    fused, fmask = _fused_out
+    for t, dt in ((fused, torch.float32), (fmask, torch.bool)):
+      if tuple(t.shape) != shape[1:] or t.dtype != dt or t.device != call.dev \
+          or not t.is_contiguous():
+        raise ValueError(f"`fused_out` must be contiguous {dt} {shape[1:]} tensors on {call.dev}")
+  elif _fuse:
     fused = torch.empty(shape[1:], dtype=torch.float32, device=call.dev)
     fmask = torch.empty(shape[1:], dtype=torch.bool, device=call.dev)
   ws, ws_bytes = call.workspace()
@@ -238,19 +244,23 @@ def orth_project_and_fuse(depth_map, value_map, valid_map, cam_pose, width_offse
                           height_offset, cam_pitch, cam_height, map_res, map_width, map_height,
                           focal_x, focal_y, center_x, center_y, trunc_depth_min,
                           trunc_depth_max, trunc_height_max, clip_border, to_global=True,
-                          flip_h=True, fill_value=NINF, reduction=None, device=None
+                          flip_h=True, fill_value=NINF, reduction=None, device=None,
+                          fused_out=None
                           ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
   """``orth_project`` plus the batch-fused map in the same launch sequence:
   returns ``(topdown (b,C,mh,mw), mask, fused (C,mh,mw), fused_mask)`` with
   ``fused = max (or min) over the batch axis of topdown`` -- what the
   reference's MapBuilder.merge computes for maps that share one frame
   (element-wise max).  The fused map of each rank is what a
-  multi-GPU job all-reduces (``parallel.all_reduce_fused``)."""
+  multi-GPU job all-reduces (``parallel.all_reduce_fused``).  ``fused_out`` =
+  (float32 (C,mh,mw), bool (C,mh,mw)) writes the fused map and its mask into
+  caller-owned buffers, e.g. slots of a ring that is all-reduced once per several
+  steps (fewer, larger collectives)."""
   return orth_project(depth_map, value_map, valid_map, cam_pose, width_offset, height_offset,
                       cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
                       center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
                       clip_border, to_global, flip_h, fill_value, reduction, False, device,
-                      True, _fuse=True)
+                      True, _fuse=True, _fused_out=fused_out)
 
 
 def orth_project_fused(

@@ -357,32 +357,67 @@ k_window_scatter(ScatterArgs a) {
           unsigned li[VEC];
           float hv[VEC];
           bool ok[VEC];
+          float xfv[VEC], zfv[VEC], h1v[VEC], h2v[VEC];
+          if (FAST && VEC == 4) {
+            // two pixels per instruction (v_pk_mul/fma/add_f32): the kernel is bound by
+            // dependent-instruction issue, and the packed forms have the same rounding
+            // per element as the scalar ones
+            typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int k = 0; k < VEC; k += 2) {
+              const f2 zz = {z[u][k], z[u][(k + 1) % VEC]};
+              const f2 axp = {ax[k], ax[(k + 1) % VEC]};
+              const f2 X = axp * zz;
+              const f2 Y = zz * ay;                                            // maps.py:677-678
+              f2 h1 = __builtin_elementwise_fma(zz, (f2){p7, p7}, Y * p4) + cam_h;   // maps.py:790-797
+              const f2 z1 = __builtin_elementwise_fma(zz, (f2){p8, p8}, Y * p5);
+              const f2 x2 = __builtin_elementwise_fma(z1, (f2){y6, y6}, X * y0) + tx;   // maps.py:884-892
+              const f2 z2 = __builtin_elementwise_fma(z1, (f2){y8, y8}, X * y2r) + tz;
+              const f2 ri = {a.res_inv, a.res_inv}, nres = {-a.res, -a.res};
+              const f2 qx = x2 * ri, qz = z2 * ri;                             // exact division
+              f2 xf2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nres, qx, x2), ri, qx) + wo;
+              f2 zf2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nres, qz, z2), ri, qz) + ho;
+              zf2 = __builtin_elementwise_fma(zf2, (f2){flip_s, flip_s}, (f2){flip_c, flip_c});
+              xf2 = xf2 + 0.5f;
+              zf2 = zf2 + 0.5f;
+              xfv[k] = xf2.x; xfv[(k + 1) % VEC] = xf2.y;
+              zfv[k] = zf2.x; zfv[(k + 1) % VEC] = zf2.y;
+              h1v[k] = h1.x; h1v[(k + 1) % VEC] = h1.y;
+              h2v[k] = h1.x; h2v[(k + 1) % VEC] = h1.y;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+              const float zz = z[u][k];
+              const float X = ax[k] * zz, Y = ay * zz;             // maps.py:677-678
+              float x1, h1, z1, x2, h2, z2;
+              if (FAST) {
+                x1 = X;
+                h1 = __builtin_fmaf(zz, p7, Y * p4) + cam_h;       // maps.py:790-797
+                z1 = __builtin_fmaf(zz, p8, Y * p5);
+                x2 = __builtin_fmaf(z1, y6, x1 * y0) + tx;         // maps.py:884-892
+                z2 = __builtin_fmaf(z1, y8, x1 * y2r) + tz;
+                h2 = h1;
+              } else {
+                x1 = __builtin_fmaf(zz, p6, __builtin_fmaf(Y, p3, X * p0)) + 0.0f;
+                h1 = __builtin_fmaf(zz, p7, __builtin_fmaf(Y, p4, X * p1)) + cam_h;
+                z1 = __builtin_fmaf(zz, p8, __builtin_fmaf(Y, p5, X * p2)) + 0.0f;
+                x2 = __builtin_fmaf(z1, y6, __builtin_fmaf(h1, y3, x1 * y0)) + tx;
+                h2 = __builtin_fmaf(z1, y7, __builtin_fmaf(h1, y4, x1 * y1r)) + 0.0f;
+                z2 = __builtin_fmaf(z1, y8, __builtin_fmaf(h1, y5, x1 * y2r)) + tz;
+              }
+              float xf = (FAST ? div_markstein(x2, a.res, a.res_inv) : x2 / a.res) + wo;
+              float zf = (FAST ? div_markstein(z2, a.res, a.res_inv) : z2 / a.res) + ho;
+              // flip: (mh-1) - zf as fma(zf, -1, mh-1); no flip: fma(zf, 1, 0) -- both exact
+              zf = __builtin_fmaf(zf, flip_s, flip_c);             // maps.py:1006-1009
+              xfv[k] = xf + 0.5f;                                  // maps.py:1012-1013
+              zfv[k] = zf + 0.5f;
+              h1v[k] = h1; h2v[k] = h2;
+            }
+          }
 #pragma unroll
           for (int k = 0; k < VEC; ++k) {
-            const float zz = z[u][k];
-            const float X = ax[k] * zz, Y = ay * zz;             // maps.py:677-678
-            float x1, h1, z1, x2, h2, z2;
-            if (FAST) {
-              x1 = X;
-              h1 = __builtin_fmaf(zz, p7, Y * p4) + cam_h;       // maps.py:790-797
-              z1 = __builtin_fmaf(zz, p8, Y * p5);
-              x2 = __builtin_fmaf(z1, y6, x1 * y0) + tx;         // maps.py:884-892
-              z2 = __builtin_fmaf(z1, y8, x1 * y2r) + tz;
-              h2 = h1;
-            } else {
-              x1 = __builtin_fmaf(zz, p6, __builtin_fmaf(Y, p3, X * p0)) + 0.0f;
-              h1 = __builtin_fmaf(zz, p7, __builtin_fmaf(Y, p4, X * p1)) + cam_h;
-              z1 = __builtin_fmaf(zz, p8, __builtin_fmaf(Y, p5, X * p2)) + 0.0f;
-              x2 = __builtin_fmaf(z1, y6, __builtin_fmaf(h1, y3, x1 * y0)) + tx;
-              h2 = __builtin_fmaf(z1, y7, __builtin_fmaf(h1, y4, x1 * y1r)) + 0.0f;
-              z2 = __builtin_fmaf(z1, y8, __builtin_fmaf(h1, y5, x1 * y2r)) + tz;
-            }
-            float xf = (FAST ? div_markstein(x2, a.res, a.res_inv) : x2 / a.res) + wo;
-            float zf = (FAST ? div_markstein(z2, a.res, a.res_inv) : z2 / a.res) + ho;
-            // flip: (mh-1) - zf as fma(zf, -1, mh-1); no flip: fma(zf, 1, 0) -- both exact
-            zf = __builtin_fmaf(zf, flip_s, flip_c);             // maps.py:1006-1009
-            xf = xf + 0.5f;                                      // maps.py:1012-1013
-            zf = zf + 0.5f;
+            const float zz = z[u][k], xf = xfv[k], zf = zfv[k], h1 = h1v[k], h2 = h2v[k];
             // floor + convert in one instruction; window test in integers (the
             // window lies inside the map).  The conversion saturates and maps
             // NaN to 0, so NaN is excluded by the ordered compare.

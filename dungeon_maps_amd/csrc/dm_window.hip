@@ -218,7 +218,11 @@ __device__ inline void lds_reduce(float* cell, float v) {
 //       (dm_pixel.hpp).  !FAST: full FMA chains and IEEE division.
 // VEC = 4: 16-byte depth loads (W % 4 == 0, 16-byte aligned base); VEC = 1: any shape.
 // HAS_VALUE: scatter value[b, ch] (maps.py:314-316) instead of the height.
-template <bool IS_MAX, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC>
+// LEAN: finite depth bounds on both sides, no height truncation, no poisoned rays
+//       (no border clip, no valid map): a non-finite or out-of-range pixel is then
+//       already rejected by the two depth compares, so the ordered-compare and the
+//       height compare are dropped.  (Pipeline-tail rows are poisoned through z.)
+template <bool IS_MAX, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC, bool LEAN = false>
 __global__ void __launch_bounds__(kScatterThreads)
 k_window_scatter(ScatterArgs a) {
   extern __shared__ float lds[];
@@ -291,7 +295,6 @@ k_window_scatter(ScatterArgs a) {
   const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
   const unsigned dummy = (unsigned)area + (threadIdx.x & 63u);   // 64 scratch cells after the window
 
-  const bool idle = gy >= rows_per_iter;       // block size not a multiple of the strip width
   {
     for (int g = gx; g < nx; g += ntx) {       // one trip unless the strip is wider than the block
       const int q = q0 + g * VEC;
@@ -302,7 +305,9 @@ k_window_scatter(ScatterArgs a) {
       for (int k = 0; k < VEC; ++k) {
         const float d = (float)(q + k) - a.cx;
         ax[k] = FAST ? div_markstein(d, a.fx, a.fx_inv) : d / a.fx;
-        ax[k] = (idle || q + k < a.clip || q + k >= a.W - a.clip) ? qnan : ax[k];
+        // (idle threads and pipeline-tail rows simply repeat the part's last row: a max /
+        // min reduction is idempotent, so they need no poison)
+        if (!LEAN) ax[k] = (q + k < a.clip || q + k >= a.W - a.clip) ? qnan : ax[k];
       }
       // Software pipeline over groups of kRowsInFlight rows: the loads of group
       // i+1 are in flight while group i is projected (all waves of a workgroup
@@ -344,13 +349,14 @@ k_window_scatter(ScatterArgs a) {
                               const float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u) {
-          const int rr = r + u * rows_per_iter;
+          int rr = r + u * rows_per_iter;
+          rr = rr < r1 ? rr : r1 - 1;                            // tail: repeat the last row
           float yr = (float)rr;
           yr = a.flip_h ? a.Hm1 - yr : yr;                       // maps.py:670-671
           const float dy = yr - a.cy;
           float ay = FAST ? div_markstein(dy, a.fy, a.fy_inv) : dy / a.fy;
-          // rows outside the part (pipeline tail) or in the clipped border: poison
-          ay = (rr >= r1 || rr < a.clip || rr >= a.H - a.clip) ? qnan : ay;
+          // rows in the clipped border: poison
+          if (!LEAN) ay = (rr < a.clip || rr >= a.H - a.clip) ? qnan : ay;
           // the VEC pixels of a row are projected side by side (independent
           // chains for the scheduler); their LDS atomics come last so that no
           // branch separates the arithmetic of neighbouring pixels
@@ -424,8 +430,8 @@ k_window_scatter(ScatterArgs a) {
             // maps.py:537-544, 286-288, 1150-1158
             const unsigned ux = (unsigned)(floor_to_int(xf) - w.x0);
             const unsigned uz = (unsigned)(floor_to_int(zf) - w.z0);
-            ok[k] = !__builtin_isunordered(xf, zf) && ux < (unsigned)w.w &&
-                    uz < (unsigned)w.h && zz <= a.dmax && zz >= a.dmin && h1 <= a.hmax;
+            ok[k] = ux < (unsigned)w.w && uz < (unsigned)w.h && zz <= a.dmax && zz >= a.dmin;
+            if (!LEAN) ok[k] = ok[k] && !__builtin_isunordered(xf, zf) && h1 <= a.hmax;
             if (!FAST && !HAS_VALUE) ok[k] = ok[k] && (h2 == h2);
             const float sval = HAS_VALUE ? sv[u][k] : h2;
             if (HAS_VALUE) ok[k] = ok[k] && (sval == sval);      // NaN never replaces a number
@@ -800,7 +806,18 @@ hipError_t window_pass(const dm_params& p, const Staged& st, unsigned char* base
        {{DM_K(true, true, false, false), DM_K(true, true, false, true)},
         {DM_K(true, true, true, false), DM_K(true, true, true, true)}}}};
 #undef DM_K
-  const Kernel kfn = table[is_max][st.fast][has_valid][has_value][vec4];
+  Kernel kfn = table[is_max][st.fast][has_valid][has_value][vec4];
+  // lean variant: both depth bounds finite, no height truncation, no border, no valid map
+  const bool lean = st.fast && vec4 && !has_valid && p.has_dmin && p.has_dmax &&
+                    isfinite(p.dmin) && isfinite(p.dmax) && !p.has_hmax && p.clip_border <= 0;
+  if (lean) {
+    static const Kernel lean_table[2][2] = {
+        {k_window_scatter<false, true, false, false, 4, true>,
+         k_window_scatter<false, true, false, true, 4, true>},
+        {k_window_scatter<true, true, false, false, 4, true>,
+         k_window_scatter<true, true, false, true, 4, true>}};
+    kfn = lean_table[is_max][has_value];
+  }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
   if (e != hipSuccess) return e;

@@ -101,9 +101,48 @@ __host__ bool axis_aligned(const dm_frame* f, int B) {
   return true;
 }
 
-// Footprint of the pixel rectangle [q0,q1) x [r0,r1) of frame f in map cells,
+// Cell coordinates are affine in (ax*z, ay*z, z) for a given frame:
+//   xf = z * (xa*ax + xb*ay + xc) + xd,   zf = z * (za*ax + zb*ay + zc) + zd
+// (ax, ay = ray slopes of the pixel).  One coefficient set per frame, in double.
+struct FrameAffine {
+  double xa, xb, xc, xd, za, zb, zc, zd;
+  bool finite;
+};
+
+__host__ FrameAffine frame_affine(const dm_params& p, const dm_frame& f) {
+  // local = Rp^T-chain(X, Y, Z) + (0, h, 0);  global = Ry-chain(local) + (tx, 0, tz)
+  double L[3][3], t1[3] = {0.0, f.cam_height, 0.0};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) L[i][j] = f.Rp[3 * j + i];           // out_i = sum_j R[j][i] p_j
+  double G[3][3], t2[3];
+  if (p.to_global) {
+    double Y[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Y[i][j] = f.Ry[3 * j + i];
+    const double tr[3] = {f.tx, 0.0, f.tz};
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) G[i][j] = Y[i][0] * L[0][j] + Y[i][1] * L[1][j] + Y[i][2] * L[2][j];
+      t2[i] = Y[i][0] * t1[0] + Y[i][1] * t1[1] + Y[i][2] * t1[2] + tr[i];
+    }
+  } else {
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) G[i][j] = L[i][j]; t2[i] = t1[i]; }
+  }
+  FrameAffine a;
+  const double inv = 1.0 / p.res;
+  a.xa = G[0][0] * inv; a.xb = G[0][1] * inv; a.xc = G[0][2] * inv;
+  a.xd = t2[0] * inv + f.width_offset;
+  double za = G[2][0] * inv, zb = G[2][1] * inv, zc = G[2][2] * inv;
+  double zd = t2[2] * inv + f.height_offset;
+  if (p.flip_h) { za = -za; zb = -zb; zc = -zc; zd = (double)(p.mh - 1) - zd; }
+  a.za = za; a.zb = zb; a.zc = zc; a.zd = zd;
+  a.finite = isfinite(a.xa) && isfinite(a.xb) && isfinite(a.xc) && isfinite(a.xd) &&
+             isfinite(a.za) && isfinite(a.zb) && isfinite(a.zc) && isfinite(a.zd);
+  return a;
+}
+
+// Footprint of the pixel rectangle [q0,q1) x [r0,r1) of a frame in map cells,
 // padded by 2 cells and aligned to 4 columns, clipped to the map.
-__host__ Window part_window(const dm_params& p, const dm_frame& f, int q0, int q1, int r0,
+__host__ Window part_window(const dm_params& p, const FrameAffine& fa, int q0, int q1, int r0,
                             int r1) {
   Window full = {0, 0, p.mw, p.mh};
   if (p.clip_border > 0) {
@@ -115,35 +154,26 @@ __host__ Window part_window(const dm_params& p, const dm_frame& f, int q0, int q
   }
   if (q0 >= q1 || r0 >= r1) return Window{0, 0, 0, 0};
   if (!p.has_dmin || !p.has_dmax || !(p.dmin >= 0.0f) || !(p.dmax >= p.dmin) ||
-      !isfinite(p.dmax))
+      !isfinite(p.dmax) || !fa.finite)
     return full;
   double lo_x = INFINITY, hi_x = -INFINITY, lo_z = INFINITY, hi_z = -INFINITY;
   const int qs[2] = {q0, q1 - 1}, rs[2] = {r0, r1 - 1};
   const double zs[2] = {p.dmin, p.dmax};
-  for (int qi = 0; qi < 2; ++qi)
-    for (int ri = 0; ri < 2; ++ri)
+  for (int qi = 0; qi < 2; ++qi) {
+    const double ax = ((double)qs[qi] - p.cx) / p.fx;
+    for (int ri = 0; ri < 2; ++ri) {
+      double yr = rs[ri];
+      if (p.flip_h) yr = (double)(p.H - 1) - yr;
+      const double ay = (yr - p.cy) / p.fy;
+      const double sx = fa.xa * ax + fa.xb * ay + fa.xc, sz = fa.za * ax + fa.zb * ay + fa.zc;
       for (int zi = 0; zi < 2; ++zi) {
-        const double ax = ((double)qs[qi] - p.cx) / p.fx;
-        double yr = rs[ri];
-        if (p.flip_h) yr = (double)(p.H - 1) - yr;
-        const double ay = (yr - p.cy) / p.fy;
-        const double z = zs[zi];
-        const double X = ax * z, Y = ay * z, Z = z;
-        const double x1 = X * f.Rp[0] + Y * f.Rp[3] + Z * f.Rp[6];
-        const double y1 = X * f.Rp[1] + Y * f.Rp[4] + Z * f.Rp[7] + f.cam_height;
-        const double z1 = X * f.Rp[2] + Y * f.Rp[5] + Z * f.Rp[8];
-        double x2 = x1, z2 = z1;
-        if (p.to_global) {
-          x2 = x1 * f.Ry[0] + y1 * f.Ry[3] + z1 * f.Ry[6] + f.tx;
-          z2 = x1 * f.Ry[2] + y1 * f.Ry[5] + z1 * f.Ry[8] + f.tz;
-        }
-        double xf = x2 / p.res + f.width_offset;
-        double zf = z2 / p.res + f.height_offset;
-        if (p.flip_h) zf = (double)(p.mh - 1) - zf;
-        if (!isfinite(xf) || !isfinite(zf)) return full;
+        const double xf = zs[zi] * sx + fa.xd, zf = zs[zi] * sz + fa.zd;
         lo_x = fmin(lo_x, xf); hi_x = fmax(hi_x, xf);
         lo_z = fmin(lo_z, zf); hi_z = fmax(hi_z, zf);
       }
+    }
+  }
+  if (!isfinite(lo_x) || !isfinite(hi_x) || !isfinite(lo_z) || !isfinite(hi_z)) return full;
   // cells are floor(v + 0.5); 2 cells of slack cover the float32 rounding of
   // the device arithmetic (observed error < 1e-3 cell)
   double x0 = floor(lo_x + 0.5) - 2, x1 = floor(hi_x + 0.5) + 3;
@@ -818,9 +848,26 @@ hipError_t window_pass(const dm_params& p, const Staged& st, unsigned char* base
          k_window_scatter<true, true, false, true, 4, true>}};
     kfn = lean_table[is_max][has_value];
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
-  if (e != hipSuccess) return e;
+  hipError_t e = hipSuccess;
+  {   // raise the dynamic-LDS limit once per kernel variant and device
+    static thread_local const void* done[64][8] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const void* key = reinterpret_cast<const void*>(kfn);
+    bool seen = false;
+    int free_slot = -1;
+    if (dev >= 0 && dev < 8) {
+      for (int i = 0; i < 64; ++i) {
+        if (done[i][dev] == key) { seen = true; break; }
+        if (!done[i][dev] && free_slot < 0) free_slot = i;
+      }
+    }
+    if (!seen) {
+      e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 8 && free_slot >= 0) done[free_slot][dev] = key;
+    }
+  }
 
   // channel groups: the slabs of one group fit the workspace's slab region
   const size_t per_channel = (size_t)p.B * st.nparts * st.slab_stride * 4;
@@ -889,12 +936,13 @@ static hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host,
     max_area = 0; st.max_union = 0;
     for (int b = 0; b < p.B; ++b) {
       int ux0 = p.mw, ux1 = 0, uz0 = p.mh, uz1 = 0;
+      const FrameAffine fa = frame_affine(p, frames_host[b]);
       for (int pr = 0; pr < st.parts.pr; ++pr)
         for (int pc = 0; pc < st.parts.pc; ++pc) {
           const int q0 = pc * st.parts.wp, r0 = pr * st.parts.hp;
           const int q1 = q0 + st.parts.wp < p.W ? q0 + st.parts.wp : p.W;
           const int r1 = r0 + st.parts.hp < p.H ? r0 + st.parts.hp : p.H;
-          const Window w = part_window(p, frames_host[b], q0, q1, r0, r1);
+          const Window w = part_window(p, fa, q0, q1, r0, r1);
           wins[(size_t)b * st.nparts + pr * st.parts.pc + pc] = w;
           if (w.w * w.h > max_area) max_area = w.w * w.h;
           if (w.w > 0) {

@@ -69,29 +69,43 @@ class MapProjector:
 
 
 def _forwarding_method(fn, doc_ref: str):
-  names = list(inspect.signature(fn).parameters)
-  defaults = {n: p.default for n, p in inspect.signature(fn).parameters.items()
-              if p.default is not inspect.Parameter.empty}
+  params = inspect.signature(fn).parameters
+  names = tuple(params)
+  index = {n: i for i, n in enumerate(names)}
+  fn_defaults = tuple(None if p.default is inspect.Parameter.empty else p.default
+                      for p in params.values())
+  intr = {"focal_x": "fx", "focal_y": "fy", "center_x": "cx", "center_y": "cy"}
+  # where each argument's fallback lives: 1 = projector field, 2 = intrinsic, 0 = none
+  kinds = tuple(2 if n in intr else (1 if n in MapProjector._FIELDS else 0) for n in names)
+  attrs = tuple(intr.get(n, n) for n in names)
+  nargs = len(names)
 
   def method(self, *args, **kwargs):
-    if len(args) > len(names):
-      raise TypeError(f"{fn.__name__}() takes at most {len(names)} arguments")
-    given = dict(zip(names, args))
+    if len(args) > nargs:
+      raise TypeError(f"{fn.__name__}() takes at most {nargs} arguments")
+    call = list(args) + [None] * (nargs - len(args))
+    given = len(args)
     for k, v in kwargs.items():
-      if k not in names:
+      i = index.get(k)
+      if i is None:
         raise TypeError(f"{fn.__name__}() got an unexpected keyword argument '{k}'")
-      if k in given:
+      if i < given:
         raise TypeError(f"{fn.__name__}() got multiple values for argument '{k}'")
-      given[k] = v
-    call = {}
-    for n in names:
-      v = given.get(n)
-      if v is None:
-        v = self._default_for(n)            # get(arg, self.<arg>)
-      if v is None and n not in given:
-        v = defaults.get(n)                 # the functional API's own default
-      call[n] = v
-    return fn(**call)
+      call[i] = v
+    cam = self.cam_params
+    for i in range(nargs):
+      if call[i] is None:
+        kind = kinds[i]
+        if kind == 1:
+          v = getattr(self, attrs[i])          # get(arg, self.<arg>)
+        elif kind == 2:
+          v = getattr(cam, attrs[i])
+        else:
+          v = None
+        if v is None and i >= given and names[i] not in kwargs:
+          v = fn_defaults[i]                   # the functional API's own default
+        call[i] = v
+    return fn(*call)
 
   method.__name__ = fn.__name__
   method.__doc__ = (f"``{fn.__name__}`` with None arguments taken from this projector "

@@ -24,6 +24,10 @@ def t(fn, n=300):
   return dt
 
 print("full API call            %7.1f us" % t(lambda: proj.orth_project(depth, cam_pose=pose)))
+print("orth_project_and_fuse    %7.1f us" % t(lambda: proj.orth_project_and_fuse(depth, cam_pose=pose)))
+print("functional (no forward)  %7.1f us" % t(lambda: F.orth_project(depth, None, None, pose, 256., 256., proj.cam_pitch, proj.cam_height, 0.03, mw, mh,
+               proj.cam_params.fx, proj.cam_params.fy, proj.cam_params.cx, proj.cam_params.cy,
+               0.15, 5.05, None, None, True, True, -np.inf, None)))
 print("build_frame_table        %7.1f us" % t(lambda: frames.build_frame_table(B, pose, proj.cam_pitch, proj.cam_height, 256., 256.)))
 call = F._Call(depth, None, None, pose, 256., 256., proj.cam_pitch, proj.cam_height, 0.03, mw, mh,
                proj.cam_params.fx, proj.cam_params.fy, proj.cam_params.cx, proj.cam_params.cy,
@@ -38,7 +42,7 @@ lib = _native.lib()
 stream = torch.cuda.current_stream().cuda_stream
 def native():
   lib.dm_orth_project_f32(ctypes.byref(p), call.frames.data_ptr(), depth.data_ptr(), None, None,
-                          top.data_ptr(), mask.data_ptr(), None, ws.data_ptr(), wsb, stream)
+                          top.data_ptr(), mask.data_ptr(), None, None, None, ws.data_ptr(), wsb, stream)
 print("native call only         %7.1f us  (window calc + memcpy + 2 launches)" % t(native))
 print("3x torch.empty           %7.1f us" % t(lambda: (torch.empty((B, 1, mh, mw), device="cuda"), torch.empty((B, 1, mh, mw), dtype=torch.bool, device="cuda"), torch.empty(wsb, dtype=torch.uint8, device="cuda"))))
 print("workspace_bytes call     %7.1f us" % t(lambda: lib.dm_orth_project_workspace_bytes(ctypes.byref(p))))

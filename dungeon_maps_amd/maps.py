@@ -58,15 +58,6 @@ class MapProjector:
     return MapProjector(**{name: get(overrides.get(name), getattr(self, name))
                            for name in self._FIELDS})
 
-  # projector attribute (or intrinsic) behind a functional-API argument name
-  def _default_for(self, name: str):
-    if name in ("focal_x", "focal_y", "center_x", "center_y"):
-      return getattr(self.cam_params, {"focal_x": "fx", "focal_y": "fy",
-                                       "center_x": "cx", "center_y": "cy"}[name])
-    if name in self._FIELDS:
-      return getattr(self, name)
-    return None
-
 
 def _forwarding_method(fn, doc_ref: str):
   params = inspect.signature(fn).parameters

@@ -319,3 +319,36 @@ def test_window_path_equals_generic_path(dmap, oracle, case):
     np.testing.assert_array_equal(fast[0], want[0])
     if gh:
       np.testing.assert_array_equal(fast[2], np.ascontiguousarray(want[2]))
+
+
+def test_cfg5_geometry_and_large_batches(dmap, oracle):
+  """BASELINE configs[4] geometry (1280x960 depth -> 2048x2048 grid) at a small
+  batch vs the oracle, the ego-motion grid at that size, and a batch far larger
+  than the CU count."""
+  B, H, W, m = 2, 960, 1280, 2048
+  depth, pose = _synthetic(B, H, W, seed=55)
+  cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+             cam_height=0.88, width_offset=m / 2., height_offset=m / 2., map_res=0.03,
+             map_width=m, map_height=m, trunc_depth_min=0.15, trunc_depth_max=5.05,
+             to_global=True, fill_value=-np.inf)
+  outs = _run(dmap, cfg, depth, cam_pose=pose)
+  want = oracle.orth_project(depth, **dict(_oracle_kwargs(oracle, cfg), cam_pose=pose),
+                             nthreads=8)
+  np.testing.assert_array_equal(outs[1], want[1])
+  np.testing.assert_array_equal(outs[0], want[0])
+  proj = dmap.MapProjector(**cfg)
+  grid = proj.camera_affine_grid(torch.from_numpy(depth).cuda(), [0.05, 0.1, 0.02])
+  assert grid.shape == (B, 1, H, W, 2) and torch.isfinite(grid).all()
+  # 1500 small frames: more workgroups than a grid dimension of parts would give
+  Bn = 1500
+  d, p = _synthetic(Bn, 24, 32, seed=56)
+  cfg2 = dict(width=32, height=24, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+              cam_height=0.88, width_offset=32., height_offset=32., map_res=0.2,
+              map_width=64, map_height=64, trunc_depth_min=0.15, trunc_depth_max=5.05,
+              to_global=True, fill_value=-np.inf)
+  top, mask, fused, fmask = dmap.MapProjector(**cfg2).orth_project_and_fuse(
+      torch.from_numpy(d).cuda(), cam_pose=p)
+  want = oracle.orth_project(d, **dict(_oracle_kwargs(oracle, cfg2), cam_pose=p), nthreads=8)
+  np.testing.assert_array_equal(top.cpu().numpy(), want[0])
+  np.testing.assert_array_equal(mask.cpu().numpy(), want[1])
+  assert torch.equal(fused, top.amax(dim=0)) and torch.equal(fmask, mask.any(dim=0))

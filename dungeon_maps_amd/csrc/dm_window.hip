@@ -23,6 +23,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "dm_kernels.hpp"
@@ -33,6 +34,7 @@ namespace {
 
 constexpr int kScatterThreads = 1024;
 constexpr int kRowsInFlight = 4;
+constexpr int kFillPerHalf = 2;       // fill steps per pipeline half-iteration
 constexpr int kMaxLdsBytes = 160 * 1024;
 
 
@@ -266,30 +268,45 @@ k_window_scatter(ScatterArgs a) {
   const int area = w.w * w.h;                  // 0: nothing of this part can land
 
   // Fill duty, interleaved with the scatter so that these stores ride under the
-  // VALU-bound projection: map rows part, part + nparts, ... of (b, ch), minus
-  // the frame's union window U (k_window_merge writes U).  One float4 (+ 4 mask
-  // bytes) per thread and step.
+  // VALU-bound projection: map rows part, part + nparts, ... of (b, ch), minus the
+  // frame's union window U (k_window_merge writes U).  One float4 (+ 4 mask bytes)
+  // per thread and step, ALWAYS executed: an element that needs no store (inside U,
+  // or past the end) is redirected to `alt`, a cell of this workgroup's share that
+  // does get the fill value, so the stores are unconditional straight-line code and
+  // the compiler can count the pipelined loop's waits exactly.
   const Window U = a.unions[b];
   const int g4 = a.mw >> 2;
-  const int g4_shift = (g4 & (g4 - 1)) == 0 ? __builtin_ctz(g4) : -1;   // wave-uniform
-  const int fill_total = a.out ? ((a.mh - part + nparts - 1) / nparts) * g4 : 0;
-  const int fill_steps = (fill_total + kScatterThreads - 1) / kScatterThreads;
+  const int fill_rows = (a.mh - part + nparts - 1) / nparts;
   const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
+  // where redirected stores go: a cell of this share outside U if there is one (it gets
+  // the fill value anyway), else the share's first cell (inside U: k_window_merge,
+  // which runs after this kernel, overwrites it)
+  int alt_cell = part * a.mw;
+  if (fill_rows > 0 && U.w > 0 && U.h > 0 && U.x0 == 0) {
+    const int last_row = part + (fill_rows - 1) * nparts;
+    if (U.x0 + U.w < a.mw) alt_cell = part * a.mw + U.x0 + U.w;                  // right of U
+    else if (part >= U.z0 && last_row >= U.z0 + U.h) alt_cell = last_row * a.mw; // below U
+  }
+  const bool do_fill = a.out != nullptr && fill_rows > 0;                       // wave-uniform
+  const int fill_total = do_fill ? fill_rows * g4 : 0;
+  const int fill_steps = (fill_total + kScatterThreads - 1) / kScatterThreads;
+  const float g4_inv = 1.0f / (float)g4;
   int fs = 0;
   auto fill_step = [&]() {
-    const int i = fs * kScatterThreads + (int)threadIdx.x;
+    const int i = fs * kScatterThreads + (int)threadIdx.x;     // < 2^24
     ++fs;
-    if (i < fill_total) {
-      const int k = g4_shift >= 0 ? (i >> g4_shift) : i / g4;
-      const int g = i - k * g4;
-      const int r = part + k * nparts, x = g << 2;
-      const bool inside = (unsigned)(r - U.z0) < (unsigned)U.h && (unsigned)(x - U.x0) < (unsigned)U.w;
-      if (!inside) {
-        const size_t cell = map_base + (size_t)r * a.mw + x;
-        *reinterpret_cast<float4*>(a.out + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
-        if (a.mask) *reinterpret_cast<uint32_t*>(a.mask + cell) = 0u;
-      }
-    }
+    int k = (int)((float)i * g4_inv);          // i / g4 without a division routine or a branch
+    k -= (k * g4 > i);
+    k += ((k + 1) * g4 <= i);
+    const int g = i - k * g4;
+    const int r = part + k * nparts, x = g << 2;
+    const bool skip = i >= fill_total || ((unsigned)(r - U.z0) < (unsigned)U.h &&
+                                          (unsigned)(x - U.x0) < (unsigned)U.w);
+    int cell = r * a.mw + x;
+    asm("" : "+v"(cell));                      // keep the select a v_cndmask
+    cell = skip ? alt_cell : cell;
+    *reinterpret_cast<float4*>(a.out + map_base + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
+    *reinterpret_cast<uint32_t*>(a.mask + map_base + cell) = 0u;
   };
   if (area == 0) {                             // wave-uniform
     while (fs < fill_steps) fill_step();
@@ -478,21 +495,33 @@ k_window_scatter(ScatterArgs a) {
         }
       };
       const int niter = (r1 - r0 + step - 1) / step;             // wave-uniform
-      const int fill_per_iter = (fill_steps + niter - 1) / niter;
-      int r = r0 + gy;
-      load_rows(za, va, r);
-      for (int it = 0; it < niter; it += 2) {
-        load_rows(zb_, vb_, r + step);
-        // fill stores are issued after the loads, so no load ever waits on them
-        for (int t = 0; t < fill_per_iter && fs < fill_steps; ++t) fill_step();
-        project_rows(za, va, r);
-        if (it + 1 < niter) {
-          load_rows(za, va, r + 2 * step);
-          for (int t = 0; t < fill_per_iter && fs < fill_steps; ++t) fill_step();
-          project_rows(zb_, vb_, r + step);
+      // Two copies of the pipelined loop, with and without fill duty, chosen by ONE
+      // wave-uniform branch: inside, exactly kFillPerHalf unconditional fill stores
+      // follow each group of loads, so the waits count them and never wait on a store
+      // or on the prefetch.
+      auto pipeline = [&](auto with_fill) {
+        constexpr bool kFill = decltype(with_fill)::value;
+        int r = r0 + gy;
+        load_rows(za, va, r);
+        for (int it = 0; it < niter; it += 2) {
+          load_rows(zb_, vb_, r + step);
+          if (kFill) {
+#pragma unroll
+            for (int t = 0; t < kFillPerHalf; ++t) fill_step();
+          }
+          project_rows(za, va, r);
+          if (it + 1 < niter) {
+            load_rows(za, va, r + 2 * step);
+            if (kFill) {
+#pragma unroll
+              for (int t = 0; t < kFillPerHalf; ++t) fill_step();
+            }
+            project_rows(zb_, vb_, r + step);
+          }
+          r += 2 * step;
         }
-        r += 2 * step;
-      }
+      };
+      if (do_fill) pipeline(std::true_type{}); else pipeline(std::false_type{});
     }
   }
   while (fs < fill_steps) fill_step();
@@ -569,7 +598,7 @@ k_window_merge(MergeArgs a) {
                         ((uint32_t)mask_of(acc[j].y, a.fill) << 8) |
                         ((uint32_t)mask_of(acc[j].z, a.fill) << 16) |
                         ((uint32_t)mask_of(acc[j].w, a.fill) << 24);
-    if (a.mask) *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+    *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
   }
 }
 
@@ -773,8 +802,9 @@ size_t window_workspace_bytes(const dm_params& p) {
   const size_t one = (size_t)p.B * np * align_up(cap, 4) * 4;     // one channel of every frame
   size_t slabs = one * oc;
   if (slabs > kSlabBudget) slabs = one > kSlabBudget ? one : kSlabBudget;
+  const size_t height_mask = p.vc ? align_up((size_t)p.B * p.dc * p.mh * p.mw, 256) : 0;
   return align_up((size_t)p.B * sizeof(dm_frame), 256) +
-         align_up((size_t)p.B * (128 + 1) * sizeof(Window), 256) + slabs;
+         align_up((size_t)p.B * (128 + 1) * sizeof(Window), 256) + slabs + height_mask;
 }
 
 namespace {
@@ -1006,8 +1036,12 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
                   slab_bytes, s);
   if (e != hipSuccess) return e;
   if (height && value) {      // maps.py:332-350: second projection, NINF fill, max
-    e = window_pass(p, st, base, depth, nullptr, valid, height, nullptr, p.dc, -INFINITY, true,
-                    slab_bytes, s);
+    // its mask is not returned (maps.py:340): it goes to scratch at the workspace tail
+    const size_t hm = (size_t)p.B * p.dc * p.mh * p.mw;
+    if (slab_bytes < hm + (size_t)p.B * st.nparts * st.slab_stride * 4) return hipErrorNotSupported;
+    uint8_t* scratch_mask = base + ws_bytes - hm;
+    e = window_pass(p, st, base, depth, nullptr, valid, height, scratch_mask, p.dc, -INFINITY, true,
+                    slab_bytes - hm, s);
     if (e != hipSuccess) return e;
   }
   if (after_projection) {

@@ -266,6 +266,14 @@ k_window_scatter(ScatterArgs a) {
   const int pcx = part % a.parts.pc, pry = part / a.parts.pc;
   const Window w = a.windows[(size_t)b * nparts + part];
   const int area = w.w * w.h;                  // 0: nothing of this part can land
+  // younger waves of a SIMD get the higher issue priority (age arbitration favours the
+  // oldest wave otherwise, and the last wave left on a SIMD runs latency bound)
+  {
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (wave >= 12) __builtin_amdgcn_s_setprio(3);
+    else if (wave >= 8) __builtin_amdgcn_s_setprio(2);
+    else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  }
 
   // Fill duty, interleaved with the scatter so that these stores ride under the
   // VALU-bound projection: map rows part, part + nparts, ... of (b, ch), minus the

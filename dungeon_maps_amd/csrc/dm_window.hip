@@ -35,6 +35,7 @@ namespace {
 constexpr int kScatterThreads = 1024;
 constexpr int kRowsInFlight = 4;
 constexpr int kFillPerHalf = 2;       // fill steps per pipeline half-iteration
+constexpr int kFillAhead = 4;         // fill steps issued before the span tables are built
 constexpr int kMaxLdsBytes = 160 * 1024;
 
 
@@ -47,6 +48,41 @@ struct Parts {
 struct Window {
   int x0, z0, w, h;
 };
+
+// Tables the kernels read travel in the kernel-argument segment (one launch per chunk
+// of frames): no staging copy, no extra stream operation, and every access is a
+// scalar load of wave-uniform data.
+struct FrameRec {        // what the scatter kernel reads of a dm_frame
+  float p[9];            // pitch rotation (row-major)
+  float cam_h;
+  float y[9];            // yaw rotation (identity for a local map)
+  float tx, tz, wo, ho;
+  float pad;
+};
+struct Win16 { short x0, z0, w, h; };     // map sides <= 32767
+
+constexpr int kChunkFrames = 64;          // frames per scatter launch
+constexpr int kChunkWins = 512;           // part windows per scatter launch
+constexpr int kExclParts = 8;             // most parts per frame with exclusive row spans
+
+struct ScatterTables {
+  FrameRec frames[kChunkFrames];
+  // (frame, part): row stride kExclParts when a frame has at most kExclParts parts (a
+  // workgroup then finds its window without first loading the part count), else nparts
+  Win16 wins[kChunkWins];
+  Win16 unions[kChunkFrames];             // bounding box of a frame's windows, x aligned to 4
+};
+
+// Row r of a part's window: the part can only reach cells [l, r) of it (its "span":
+// the frustum slab is convex), and [e0, e1) of those belong to no other part's span --
+// the scatter kernel writes them to the map itself; everything else inside the frame's
+// union window is k_window_merge's.  Absolute map columns, multiples of 4.
+struct RowSpan { short l, r, e0, e1; };
+
+__device__ __host__ inline Window widen(Win16 w) { return Window{w.x0, w.z0, w.w, w.h}; }
+__host__ inline Win16 narrow(Window w) {
+  return Win16{(short)w.x0, (short)w.z0, (short)w.w, (short)w.h};
+}
 
 __host__ Parts choose_parts(const dm_params& p, int min_parts = 1) {
   // enough workgroups to fill 256 CUs (and at least min_parts, so that windows fit
@@ -92,9 +128,9 @@ __host__ bool exact_reciprocal(float b, float* y_out) {
   return true;
 }
 
-__host__ bool axis_aligned(const dm_frame* f, int B) {
+__host__ bool axis_aligned(const FrameRec* f, int B) {
   for (int b = 0; b < B; ++b) {
-    const float* p = f[b].Rp; const float* y = f[b].Ry;
+    const float* p = f[b].p; const float* y = f[b].y;
     if (!(p[0] == 1.0f && p[1] == 0.0f && p[2] == 0.0f && p[3] == 0.0f && p[6] == 0.0f))
       return false;
     if (!(y[1] == 0.0f && y[3] == 0.0f && y[4] == 1.0f && y[5] == 0.0f && y[7] == 0.0f))
@@ -202,6 +238,17 @@ __host__ Window part_window(const dm_params& p, const FrameAffine& fa, int q0, i
 // +inf: they then only reject NaN, which never reaches the map anyway) and a
 // local-space projection as an identity yaw with zero translation, so the
 // pixel loop has no flag to branch on.
+// -DDM_STAMPS: instrumented build for tools/phase_stamps.py -- thread 0 of every
+// workgroup of k_window_scatter records the 100 MHz real-time counter at phase boundaries.
+#ifdef DM_STAMPS
+#define DM_STAMP(k) do { long long t_; \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    stamp[k] = t_; } while (0)
+static long long* g_stamp_buffer = nullptr;
+#else
+#define DM_STAMP(k) do { } while (0)
+#endif
+
 struct ScatterArgs {
   int W, H;
   int clip;                   // border pixels to drop (0 = none)
@@ -217,14 +264,22 @@ struct ScatterArgs {
   int oc_total;               // channels of `out` / `value`
   int slab_stride;            // cells per slab
   float fill;
-  const dm_frame* frames;     // device copy (yaw already neutralised if !to_global)
-  const Window* windows;      // (B, pr, pc): the same for every channel of a frame
+#ifdef DM_STAMPS
+  long long* stamps;
+#endif
+  int b0;                     // first frame of this launch's chunk
+  int excl;                   // exclusive row spans (<= kExclParts parts, finite depth bounds)
+  int tab_off;                // LDS word offset of the span tables (behind window + dummy cells)
+  int max_rows_sum;           // most window rows of one frame, all parts together
+  int max_h;                  // tallest window: row stride of g_rows
+  Win16* g_wins;              // (B, nparts)  device copies for the kernels that follow
+  Win16* g_unions;            // (B)
+  RowSpan* g_rows;            // (B, mh, nparts), excl only: row z of part p's window
   const float* depth;
   const float* value;         // (B, oc_total, H, W) or NULL: project the heights
   const uint8_t* valid;
   float* slabs;
   // fill duty: the part of every output map outside its frame's union window
-  const Window* unions;       // (B): bounding box of the frame's windows, x aligned to 4
   float* out;
   uint8_t* mask;
   int mh, mw;
@@ -235,6 +290,13 @@ __device__ inline int floor_to_int(float x) {
   int r;
   asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
   return r;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// global load and store of the wave (s_waitcnt vmcnt(0)), which would expose the latency
+// of the depth rows and fill stores deliberately left in flight across it.
+__device__ inline void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // ds_max_f32 / ds_min_f32: "store if new > old" -- torch_scatter's rule; a NaN
@@ -256,16 +318,23 @@ __device__ inline void lds_reduce(float* cell, float v) {
 //       height compare are dropped.  (Pipeline-tail rows are poisoned through z.)
 template <bool IS_MAX, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC, bool LEAN = false>
 __global__ void __launch_bounds__(kScatterThreads)
-k_window_scatter(ScatterArgs a) {
+k_window_scatter(ScatterArgs a, ScatterTables t) {
   extern __shared__ float lds[];
   const int part = blockIdx.x;                 // pr-major, pc-minor
-  const int chl = blockIdx.y, b = blockIdx.z;  // channel within this launch's group
+  const int chl = blockIdx.y;                  // channel within this launch's group
+  const int bl = blockIdx.z, b = a.b0 + bl;    // frame within the chunk / in the batch
   const int ch = a.ch0 + chl;                  // output channel
   const int dch = a.dc == 1 ? 0 : ch;          // depth / cell-index channel (utils.py:475-477)
   const int nparts = a.parts.pc * a.parts.pr;
   const int pcx = part % a.parts.pc, pry = part / a.parts.pc;
-  const Window w = a.windows[(size_t)b * nparts + part];
+  const Win16 w_few = t.wins[bl * kExclParts + (part & (kExclParts - 1))];
+  const int win_stride = nparts <= kExclParts ? kExclParts : nparts;
+  const Window w = nparts <= kExclParts ? widen(w_few) : widen(t.wins[bl * nparts + part]);
   const int area = w.w * w.h;                  // 0: nothing of this part can land
+#ifdef DM_STAMPS
+  long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  DM_STAMP(0);
   // younger waves of a SIMD get the higher issue priority (age arbitration favours the
   // oldest wave otherwise, and the last wave left on a SIMD runs latency bound)
   {
@@ -282,19 +351,26 @@ k_window_scatter(ScatterArgs a) {
   // or past the end) is redirected to `alt`, a cell of this workgroup's share that
   // does get the fill value, so the stores are unconditional straight-line code and
   // the compiler can count the pipelined loop's waits exactly.
-  const Window U = a.unions[b];
+  const Window U = widen(t.unions[bl]);
   const int g4 = a.mw >> 2;
   const int fill_rows = (a.mh - part + nparts - 1) / nparts;
   const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
   // where redirected stores go: a cell of this share outside U if there is one (it gets
-  // the fill value anyway), else the share's first cell (inside U: k_window_merge,
-  // which runs after this kernel, overwrites it)
+  // the fill value anyway), else the share's first cell.  That one lies inside U: fine
+  // when k_window_merge, which runs after this kernel, rewrites all of U; with exclusive
+  // spans other workgroups store into U concurrently, so the fill is then done with
+  // conditional stores after the scatter instead (alt_safe == false; only when U spans
+  // the whole map width and this share's first and last rows).
   int alt_cell = part * a.mw;
+  bool alt_safe = true;
   if (fill_rows > 0 && U.w > 0 && U.h > 0 && U.x0 == 0) {
     const int last_row = part + (fill_rows - 1) * nparts;
     if (U.x0 + U.w < a.mw) alt_cell = part * a.mw + U.x0 + U.w;                  // right of U
-    else if (part >= U.z0 && last_row >= U.z0 + U.h) alt_cell = last_row * a.mw; // below U
+    else if (last_row >= U.z0 + U.h) alt_cell = last_row * a.mw;                 // below U
+    else alt_safe = part < U.z0;                                                 // above U
   }
+  const bool excl = a.excl != 0;
+  const bool cond_fill = excl && !alt_safe;                                      // wave-uniform
   const bool do_fill = a.out != nullptr && fill_rows > 0;                       // wave-uniform
   const int fill_total = do_fill ? fill_rows * g4 : 0;
   const int fill_steps = (fill_total + kScatterThreads - 1) / kScatterThreads;
@@ -316,22 +392,205 @@ k_window_scatter(ScatterArgs a) {
     *reinterpret_cast<float4*>(a.out + map_base + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
     *reinterpret_cast<uint32_t*>(a.mask + map_base + cell) = 0u;
   };
+  auto fill_rest = [&]() {
+    if (!cond_fill) {
+      while (fs < fill_steps) fill_step();
+      return;
+    }
+    for (int i = fs * kScatterThreads + (int)threadIdx.x; i < fill_total; i += kScatterThreads) {
+      const int k = i / g4, g = i - k * g4;
+      const int r = part + k * nparts, x = g << 2;
+      if ((unsigned)(r - U.z0) < (unsigned)U.h && (unsigned)(x - U.x0) < (unsigned)U.w) continue;
+      const size_t cell = map_base + (size_t)r * a.mw + x;
+      *reinterpret_cast<float4*>(a.out + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
+      *reinterpret_cast<uint32_t*>(a.mask + cell) = 0u;
+    }
+    fs = fill_steps;
+  };
+  // device copies of the geometry for the kernels that follow
+  if (chl == 0 && threadIdx.x == 0) {
+    a.g_wins[(size_t)b * nparts + part] = t.wins[bl * win_stride + part];
+    if (part == 0) a.g_unions[b] = t.unions[bl];
+  }
   if (area == 0) {                             // wave-uniform
-    while (fs < fill_steps) fill_step();
+    fill_rest();
     return;
   }
   for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
     *reinterpret_cast<float4*>(lds + i) = make_float4(a.fill, a.fill, a.fill, a.fill);
-  __syncthreads();
-
-  const dm_frame* f = a.frames + b;
+  const FrameRec& f = t.frames[bl];
   // pitch: rows 1,2 of R; yaw: rows 0,2 (the rest is 0/1 when FAST)
-  const float p0 = f->Rp[0], p1 = f->Rp[1], p2 = f->Rp[2], p3 = f->Rp[3], p4 = f->Rp[4],
-              p5 = f->Rp[5], p6 = f->Rp[6], p7 = f->Rp[7], p8 = f->Rp[8];
-  const float y0 = f->Ry[0], y1r = f->Ry[1], y2r = f->Ry[2], y3 = f->Ry[3], y4 = f->Ry[4],
-              y5 = f->Ry[5], y6 = f->Ry[6], y7 = f->Ry[7], y8 = f->Ry[8];
-  const float cam_h = f->cam_height, tx = f->tx, tz = f->tz;
-  const float wo = f->width_offset, ho = f->height_offset;
+  const float p0 = f.p[0], p1 = f.p[1], p2 = f.p[2], p3 = f.p[3], p4 = f.p[4],
+              p5 = f.p[5], p6 = f.p[6], p7 = f.p[7], p8 = f.p[8];
+  const float y0 = f.y[0], y1r = f.y[1], y2r = f.y[2], y3 = f.y[3], y4 = f.y[4],
+              y5 = f.y[5], y6 = f.y[6], y7 = f.y[7], y8 = f.y[8];
+  const float cam_h = f.cam_h, tx = f.tx, tz = f.tz;
+  const float wo = f.wo, ho = f.ho;
+  const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
+
+  // ---- exclusive row spans -------------------------------------------------------
+  // LDS behind the window and its dummy cells:
+  //   edges  (nparts, 12, 4) float   xa, za, xb - xa, 1 / (zb - za) of the slab's edges
+  //   winl   (nparts, 4)     int     the frame's part windows x0, z0, w, h
+  //   bad    (nparts)        int     a corner of the part is not finite: no spans
+  //   sp     (rows of all parts of the frame) int   l | r << 16
+  //   own    (w.h, 2)        int     l | r << 16, e0 | e1 << 16 of this part
+  int* const tabs = reinterpret_cast<int*>(lds) + a.tab_off;
+  float* const edges = reinterpret_cast<float*>(tabs);
+  int* const winl = tabs + nparts * 48;
+  int* const bad = winl + nparts * 4;
+  int* const sp = bad + nparts;
+  int* const own = sp + a.max_rows_sum;
+  int row_off[kExclParts + 1];                 // first sp entry of each part (wave-uniform)
+  if (excl) {
+    row_off[0] = 0;
+#pragma unroll
+    for (int q = 0; q < kExclParts; ++q) {
+      int hq = 0;
+      if (q < nparts) {
+        const Win16 wq = t.wins[bl * kExclParts + q];
+        hq = wq.w > 0 ? wq.h : 0;
+        if (threadIdx.x == 0) {
+          winl[4 * q] = wq.x0; winl[4 * q + 1] = wq.z0; winl[4 * q + 2] = wq.w; winl[4 * q + 3] = wq.h;
+          bad[q] = 0;
+        }
+      }
+      row_off[q + 1] = row_off[q] + hq;
+    }
+  }
+  lds_barrier();
+  DM_STAMP(1);
+  // (run by every thread once its first depth rows are requested: the table arithmetic
+  // hides the latency of those loads)
+  auto build_tables = [&]() {
+    // the frustum slab of a part (its pixel rectangle x [dmin, dmax]) is convex, so its
+    // footprint is the hull of its 8 projected corners and the hull's boundary is made
+    // of the projections of the slab's 12 edges: one thread per (part, edge)
+    // (the asm keeps this arithmetic under its guards: hoisted in front of the pixel
+    // loop it would be executed by every wave)
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    if (tid < nparts * 12) {
+      const int q = tid / 12, e = tid - q * 12;
+      // corner index: bit 0 = depth, bit 1 = image row, bit 2 = image column
+      const int axis = e >> 2, k = e & 3;      // the bit that differs along the edge
+      const int lowmask = (1 << axis) - 1;
+      const int ia = ((k & ~lowmask) << 1) | (k & lowmask), ib = ia | (1 << axis);
+      const int qc = q % a.parts.pc, qr = q / a.parts.pc;
+      const int cq0 = qc * a.parts.wp, cr0 = qr * a.parts.hp;
+      int cq1 = cq0 + a.parts.wp; if (cq1 > a.W) cq1 = a.W;
+      int cr1 = cr0 + a.parts.hp; if (cr1 > a.H) cr1 = a.H;
+      float px[2], pz[2];
+      const float rfx = __builtin_amdgcn_rcpf(a.fx), rfy = __builtin_amdgcn_rcpf(a.fy),
+                  rres = __builtin_amdgcn_rcpf(a.res);
+      auto corner = [&](int ci, float& cxo, float& czo) {
+        const float zz = (ci & 1) ? a.dmax : a.dmin;
+        float yr = (float)((ci & 2) ? cr1 - 1 : cr0);
+        yr = a.flip_h ? a.Hm1 - yr : yr;
+        // (reciprocal multiplies: the spans carry 2 cells of slack)
+        const float ax = ((float)((ci & 4) ? cq1 - 1 : cq0) - a.cx) * rfx;
+        const float ay = (yr - a.cy) * rfy;
+        const float X = ax * zz, Y = ay * zz;
+        const float x1 = __builtin_fmaf(zz, p6, __builtin_fmaf(Y, p3, X * p0));
+        const float h1 = __builtin_fmaf(zz, p7, __builtin_fmaf(Y, p4, X * p1)) + cam_h;
+        const float z1 = __builtin_fmaf(zz, p8, __builtin_fmaf(Y, p5, X * p2));
+        const float x2 = __builtin_fmaf(z1, y6, __builtin_fmaf(h1, y3, x1 * y0)) + tx;
+        const float z2 = __builtin_fmaf(z1, y8, __builtin_fmaf(h1, y5, x1 * y2r)) + tz;
+        const float xf = x2 * rres + wo;
+        const float zf = __builtin_fmaf(z2 * rres + ho, flip_s, flip_c);
+        cxo = xf + 0.5f; czo = zf + 0.5f;
+      };
+      corner(ia, px[0], pz[0]);
+      corner(ib, px[1], pz[1]);
+      // edge record: x and z of the lower end, z of the upper end, dx/dz.  An edge along
+      // a map row is dropped (empty z range): its ends are ends of other edges too.
+      const bool up = pz[1] >= pz[0];
+      const float xa = up ? px[0] : px[1], za = up ? pz[0] : pz[1], zb = up ? pz[1] : pz[0];
+      const float dz = zb - za;
+      const bool flat = !(dz > 1e-6f);
+      float* ed = edges + tid * 4;
+      ed[0] = xa; ed[1] = flat ? 3e38f : za; ed[2] = flat ? -3e38f : zb;
+      ed[3] = flat ? 0.0f : ((up ? px[1] : px[0]) - xa) * __builtin_amdgcn_rcpf(dz);
+      const float lim = 1e6f;
+      if (!(fabsf(px[0]) < lim && fabsf(px[1]) < lim && fabsf(pz[0]) < lim && fabsf(pz[1]) < lim))
+        atomicOr(&bad[q], 1);
+    }
+    lds_barrier();
+    DM_STAMP(8);
+    // span of every row of every part's window
+    for (int idx = tid; idx < row_off[kExclParts]; idx += kScatterThreads) {
+      int q = 0, first = 0;                    // (static indices: row_off stays in registers)
+#pragma unroll
+      for (int j = 1; j < kExclParts; ++j) {
+        const bool past = row_off[j] <= idx;
+        q += past;
+        first = past ? row_off[j] : first;
+      }
+      const Window wq = {winl[4 * q], winl[4 * q + 1], winl[4 * q + 2], winl[4 * q + 3]};
+      const int z = wq.z0 + (idx - first);
+      int l = wq.x0, r = wq.x0 + wq.w;         // no usable corners: the whole window row
+      if (!bad[q]) {
+        // a pixel of row z has its centre coordinate in [z, z + 1): one row of margin
+        const float blo = (float)(z - 1), bhi = (float)(z + 2);
+        float lo = INFINITY, hi = -INFINITY;
+        const float4* ed = reinterpret_cast<const float4*>(edges + q * 48);
+#pragma unroll 4                       // (fully unrolled it spills: the first depth rows are live)
+        for (int e = 0; e < 12; ++e) {
+          const float4 g = ed[e];                                 // xa, za, zb, slope
+          const float c0 = fmaxf(blo, g.y), c1 = fminf(bhi, g.z); // the edge inside the band
+          const float xs = __builtin_fmaf(c0 - g.y, g.w, g.x), xe = __builtin_fmaf(c1 - g.y, g.w, g.x);
+          const bool hit = c0 <= c1;
+          lo = hit ? fminf(lo, fminf(xs, xe)) : lo;
+          hi = hit ? fmaxf(hi, fmaxf(xs, xe)) : hi;
+        }
+        if (lo <= hi) {
+          // 2 cells of slack for the float32 rounding of the pixel arithmetic
+          int l2 = floor_to_int(lo) - 2, r2 = floor_to_int(hi) + 3;
+          l2 = l2 < l ? l : l2; r2 = r2 > r ? r : r2;
+          l = l2 & ~3; r = (r2 + 3) & ~3;      // window sides are multiples of 4
+          if (l >= r) l = r = 0;
+        } else {
+          l = r = 0;
+        }
+      }
+      sp[idx] = l | (r << 16);
+    }
+    lds_barrier();
+    DM_STAMP(9);
+    // this part's rows: span minus every other part's span
+    int my_off = 0;
+#pragma unroll
+    for (int j = 0; j < kExclParts; ++j) my_off = j == part ? row_off[j] : my_off;
+    for (int uz = tid; uz < w.h; uz += kScatterThreads) {
+      const int z = w.z0 + uz;
+      const int mine = sp[my_off + uz];
+      const int l = mine & 0xffff, r = mine >> 16;
+      int e0 = l, e1 = r;
+#pragma unroll
+      for (int q = 0; q < kExclParts; ++q) {
+        if (q >= nparts || q == part) continue;                  // wave-uniform
+        const Window wq = {winl[4 * q], winl[4 * q + 1], winl[4 * q + 2], winl[4 * q + 3]};
+        const unsigned uq = (unsigned)(z - wq.z0);
+        if (wq.w <= 0 || uq >= (unsigned)wq.h) continue;
+        const int other = sp[row_off[q] + (int)uq];
+        const int lq = other & 0xffff, rq = other >> 16;
+        if (lq >= rq || rq <= e0 || lq >= e1) continue;
+        if (lq <= e0) e0 = rq < e1 ? rq : e1;  // covers the left end (or everything)
+        else e1 = lq;                          // covers the right end, or lies inside: keep the left piece
+      }
+      if (e0 >= e1) e0 = e1 = 0;
+      own[2 * uz] = mine;
+      own[2 * uz + 1] = e0 | (e1 << 16);
+      if (chl == 0) {
+        RowSpan rs;
+        rs.l = (short)l; rs.r = (short)r; rs.e0 = (short)e0; rs.e1 = (short)e1;
+        a.g_rows[((size_t)b * a.mh + z) * nparts + part] = rs;
+      }
+    }
+    // (own[] is read after the scatter loop's barrier)
+  };
+  bool tables_due = excl;
+
 
   const int q0 = pcx * a.parts.wp;
   int q1 = q0 + a.parts.wp; if (q1 > a.W) q1 = a.W;
@@ -347,7 +606,6 @@ k_window_scatter(ScatterArgs a) {
       ? a.valid + ((size_t)b * a.valid_c + (a.valid_c == 1 ? 0 : dch)) * N : nullptr;
   const float* simg = HAS_VALUE ? a.value + ((size_t)b * a.oc_total + ch) * N : nullptr;
   const float qnan = __builtin_nanf("");
-  const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
   const unsigned dummy = (unsigned)area + (threadIdx.x & 63u);   // 64 scratch cells after the window
 
   {
@@ -370,6 +628,9 @@ k_window_scatter(ScatterArgs a) {
       const int step = rows_per_iter * kRowsInFlight;
       float za[kRowsInFlight][VEC], zb_[kRowsInFlight][VEC];
       float va[HAS_VALUE ? kRowsInFlight : 1][VEC], vb_[HAS_VALUE ? kRowsInFlight : 1][VEC];
+#ifdef DM_TRIPLE
+      float zc_[kRowsInFlight][VEC], vc_[HAS_VALUE ? kRowsInFlight : 1][VEC];
+#endif
       auto load_rows = [&](float (&z)[kRowsInFlight][VEC],
                            float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
 #pragma unroll
@@ -511,6 +772,46 @@ k_window_scatter(ScatterArgs a) {
         constexpr bool kFill = decltype(with_fill)::value;
         int r = r0 + gy;
         load_rows(za, va, r);
+        DM_STAMP(2);
+        if (tables_due) {                      // wave-uniform, first trip only
+          if (kFill) {
+#pragma unroll
+            for (int t = 0; t < kFillAhead; ++t) fill_step();
+          }
+          DM_STAMP(7);
+          build_tables();
+          tables_due = false;
+        }
+        DM_STAMP(3);
+#ifdef DM_TRIPLE
+        load_rows(zb_, vb_, r + step);
+        for (int it = 0; it < niter; it += 3) {
+          load_rows(zc_, vc_, r + 2 * step);
+          if (kFill) {
+#pragma unroll
+            for (int t = 0; t < kFillPerHalf; ++t) fill_step();
+          }
+          project_rows(za, va, r);
+          if (it + 1 < niter) {
+            load_rows(za, va, r + 3 * step);
+            if (kFill) {
+#pragma unroll
+              for (int t = 0; t < kFillPerHalf; ++t) fill_step();
+            }
+            project_rows(zb_, vb_, r + step);
+          }
+          if (it + 2 < niter) {
+            load_rows(zb_, vb_, r + 4 * step);
+            if (kFill) {
+#pragma unroll
+              for (int t = 0; t < kFillPerHalf; ++t) fill_step();
+            }
+            project_rows(zc_, vc_, r + 2 * step);
+          }
+          r += 3 * step;
+        }
+        return;
+#endif
         for (int it = 0; it < niter; it += 2) {
           load_rows(zb_, vb_, r + step);
           if (kFill) {
@@ -529,83 +830,185 @@ k_window_scatter(ScatterArgs a) {
           r += 2 * step;
         }
       };
-      if (do_fill) pipeline(std::true_type{}); else pipeline(std::false_type{});
+      if (do_fill && !cond_fill) pipeline(std::true_type{}); else pipeline(std::false_type{});
     }
   }
-  while (fs < fill_steps) fill_step();
-  __syncthreads();
+  DM_STAMP(4);
+  fill_rest();
+  lds_barrier();
+  DM_STAMP(5);
   const int pid = (b * a.oc + chl) * nparts + part;      // slabs are per channel group
   float* slab = a.slabs + (size_t)pid * a.slab_stride;
-  for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
-    *reinterpret_cast<float4*>(slab + i) = *reinterpret_cast<const float4*>(lds + i);
+  if (!excl) {
+    for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
+      *reinterpret_cast<float4*>(slab + i) = *reinterpret_cast<const float4*>(lds + i);
+#ifdef DM_STAMPS
+    DM_STAMP(6);
+    if (threadIdx.x == 0 && a.stamps)
+      for (int k = 0; k < 12; ++k) a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 12 + k] = stamp[k];
+#endif
+    return;
+  }
+  // exclusive cells go to the map, the rest of the span to the slab (for k_window_merge);
+  // cells outside the span were never touched
+  const int wg4 = w.w >> 2;
+  const float wg4_inv = 1.0f / (float)wg4;
+  for (int i = threadIdx.x; i < (area >> 2); i += kScatterThreads) {
+    int uz = (int)((float)i * wg4_inv);
+    uz -= (uz * wg4 > i);
+    uz += ((uz + 1) * wg4 <= i);
+    const int x = w.x0 + ((i - uz * wg4) << 2);
+    const int s0 = own[2 * uz], s1 = own[2 * uz + 1];
+    if (x < (s0 & 0xffff) || x >= (s0 >> 16)) continue;
+    const float4 v = *reinterpret_cast<const float4*>(lds + 4 * i);
+    if (x >= (s1 & 0xffff) && x < (s1 >> 16)) {
+      const size_t cell = map_base + (size_t)(w.z0 + uz) * a.mw + x;
+      *reinterpret_cast<float4*>(a.out + cell) = v;
+      const uint32_t mk = (uint32_t)mask_of(v.x, a.fill) | ((uint32_t)mask_of(v.y, a.fill) << 8) |
+                          ((uint32_t)mask_of(v.z, a.fill) << 16) |
+                          ((uint32_t)mask_of(v.w, a.fill) << 24);
+      *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+    } else {
+      *reinterpret_cast<float4*>(slab + 4 * i) = v;
+    }
+  }
+#ifdef DM_STAMPS
+  DM_STAMP(6);
+  if (threadIdx.x == 0 && a.stamps)
+    for (int k = 0; k < 12; ++k) a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 12 + k] = stamp[k];
+#endif
 }
 
 struct MergeArgs {
-  int B, oc, ch0, oc_total, mh, mw;   // oc channels per frame in this launch, starting at ch0
+  int b0, oc, ch0, oc_total, mh, mw;  // oc channels per frame in this launch, starting at ch0
   int nparts;                 // pc * pr
   int slab_stride;
   float fill;
-  const Window* windows;
-  const Window* unions;
+  const Win16* wins;          // (B, nparts)   written by k_window_scatter
+  const Win16* unions;        // (B)
+  const RowSpan* rows;        // (B, mh, nparts), exclusive spans only
   const float* slabs;
   float* out;
   uint8_t* mask;
 };
 
 constexpr int kMergeThreads = 256;
-constexpr int kMergeGroups = 1;     // float4 groups per thread (more waves hide the 2-level latency)
 
-// Writes the union window U of every (frame, channel): max/min over the slabs
-// covering each cell, fill where none does.  A block owns kMergeThreads *
-// kMergeGroups consecutive float4 groups of U (row-major inside U), so a wave's
-// store covers up to 1 KiB (map) / 256 B (mask) contiguously.
+// Writes the union window U of every (frame, channel): max/min over the slabs covering
+// each cell, fill where none does.  One float4 group per thread, row-major inside U, so
+// a wave's store covers up to 1 KiB (map) / 256 B (mask) contiguously.
 template <bool IS_MAX>
 __global__ void __launch_bounds__(kMergeThreads)
 k_window_merge(MergeArgs a) {
-  const int fc = blockIdx.y;                   // frame * oc + channel of the group
-  const int b = fc / a.oc;
-  const size_t fo = (size_t)b * a.oc_total + a.ch0 + (fc - b * a.oc);   // map index in `out`
-  const Window U = a.unions[b];
+  const int fcl = blockIdx.y;                  // (frame in chunk) * oc + channel of the group
+  const int bl = fcl / a.oc, b = a.b0 + bl;
+  const int fc = fcl + a.b0 * a.oc;            // slab index of (frame, channel)
+  const size_t fo = (size_t)b * a.oc_total + a.ch0 + (fcl - bl * a.oc);   // map index in `out`
+  const Window U = widen(a.unions[b]);
   const int ug4 = U.w >> 2;                    // float4 groups per U row
   const int total = ug4 * U.h;
-  const int first = blockIdx.x * (kMergeThreads * kMergeGroups) + threadIdx.x;
-  if (blockIdx.x * (kMergeThreads * kMergeGroups) >= total) return;
-  const size_t M = (size_t)a.mh * a.mw;
-  float4 acc[kMergeGroups];
-  int zb[kMergeGroups], x[kMergeGroups];
+  const int i = blockIdx.x * kMergeThreads + threadIdx.x;
+  if (i >= total) return;
+  const int row = i / ug4;
+  const int zb = U.z0 + row, x = U.x0 + ((i - row * ug4) << 2);
+  float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+  for (int p = 0; p < a.nparts; ++p) {
+    const Window w = widen(a.wins[(size_t)b * a.nparts + p]);
+    if (w.w == 0) continue;
+    const unsigned ux = (unsigned)(x - w.x0), uz = (unsigned)(zb - w.z0);
+    if (ux >= (unsigned)w.w || uz >= (unsigned)w.h) continue;
+    const float* slab = a.slabs + ((size_t)fc * a.nparts + p) * a.slab_stride;
+    const float4 s = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
+    acc.x = IS_MAX ? fmaxf(acc.x, s.x) : fminf(acc.x, s.x);
+    acc.y = IS_MAX ? fmaxf(acc.y, s.y) : fminf(acc.y, s.y);
+    acc.z = IS_MAX ? fmaxf(acc.z, s.z) : fminf(acc.z, s.z);
+    acc.w = IS_MAX ? fmaxf(acc.w, s.w) : fminf(acc.w, s.w);
+  }
+  const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw + x;
+  *reinterpret_cast<float4*>(a.out + cell) = acc;
+  const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+                      ((uint32_t)mask_of(acc.z, a.fill) << 16) |
+                      ((uint32_t)mask_of(acc.w, a.fill) << 24);
+  *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+}
+
+// The same with exclusive spans: U minus the cells some part owns alone (already in the
+// map); a part's slab only holds its span.  The kernel is a chain of dependent loads
+// (row spans -> slabs -> store), so everything a thread may need is requested at once:
+// the union windows come with the kernel arguments, the spans of all parts of a map row
+// sit side by side, and the slab loads are unconditional (a thread that needs none reads
+// the slab's first cells).
+struct MergeUnions { Win16 u[kChunkFrames]; };
+
+constexpr int kMergeExclGroups = 2;   // float4 groups per thread
+
+template <bool IS_MAX>
+__global__ void __launch_bounds__(kMergeThreads)
+k_window_merge_excl(MergeArgs a, MergeUnions mu) {
+  const int fcl = blockIdx.y;
+  const int bl = fcl / a.oc, b = a.b0 + bl;
+  const int fc = fcl + a.b0 * a.oc;
+  const size_t fo = (size_t)b * a.oc_total + a.ch0 + (fcl - bl * a.oc);
+  const Window U = widen(mu.u[bl]);
+  const int ug4 = U.w >> 2;
+  const int total = ug4 * U.h;
+  const int first = blockIdx.x * (kMergeThreads * kMergeExclGroups) + threadIdx.x;
+  if (blockIdx.x * (kMergeThreads * kMergeExclGroups) >= total) return;
+  int zb[kMergeExclGroups], x[kMergeExclGroups];
+  bool live[kMergeExclGroups];
+  int2 rs[kMergeExclGroups][kExclParts];       // RowSpan as two words: l | r << 16, e0 | e1 << 16
 #pragma unroll
-  for (int j = 0; j < kMergeGroups; ++j) {
-    acc[j] = make_float4(a.fill, a.fill, a.fill, a.fill);
-    const int i = first + j * kMergeThreads;
+  for (int j = 0; j < kMergeExclGroups; ++j) {
+    int i = first + j * kMergeThreads;
+    live[j] = i < total;
+    i = live[j] ? i : total - 1;
     const int row = i / ug4;
     zb[j] = U.z0 + row;
     x[j] = U.x0 + ((i - row * ug4) << 2);
-  }
-  for (int p = 0; p < a.nparts; ++p) {
-    const Window w = a.windows[(size_t)b * a.nparts + p];
-    if (w.w == 0) continue;
-    const float* slab = a.slabs + ((size_t)fc * a.nparts + p) * a.slab_stride;
+    const int2* rowp = reinterpret_cast<const int2*>(a.rows + ((size_t)b * a.mh + zb[j]) * a.nparts);
 #pragma unroll
-    for (int j = 0; j < kMergeGroups; ++j) {
-      const unsigned ux = (unsigned)(x[j] - w.x0), uz = (unsigned)(zb[j] - w.z0);
-      if (ux < (unsigned)w.w && uz < (unsigned)w.h && first + j * kMergeThreads < total) {
-        const float4 s = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
-        acc[j].x = IS_MAX ? fmaxf(acc[j].x, s.x) : fminf(acc[j].x, s.x);
-        acc[j].y = IS_MAX ? fmaxf(acc[j].y, s.y) : fminf(acc[j].y, s.y);
-        acc[j].z = IS_MAX ? fmaxf(acc[j].z, s.z) : fminf(acc[j].z, s.z);
-        acc[j].w = IS_MAX ? fmaxf(acc[j].w, s.w) : fminf(acc[j].w, s.w);
+    for (int p = 0; p < kExclParts; ++p) rs[j][p] = p < a.nparts ? rowp[p] : make_int2(0, 0);
+  }
+  bool rd[kMergeExclGroups][kExclParts];
+  float4 v[kMergeExclGroups][kExclParts];
+#pragma unroll
+  for (int p = 0; p < kExclParts; ++p) {
+    if (p < a.nparts) {                                          // wave-uniform
+      const Window w = widen(a.wins[(size_t)b * a.nparts + p]);
+      const float* slab = a.slabs + ((size_t)fc * a.nparts + p) * a.slab_stride;
+#pragma unroll
+      for (int j = 0; j < kMergeExclGroups; ++j) {
+        const unsigned uz = (unsigned)(zb[j] - w.z0);
+        const bool in = w.w > 0 && uz < (unsigned)w.h;           // else: the entry is stale
+        // a cell some part owns alone is already in the map
+        live[j] = live[j] && !(in && x[j] >= (rs[j][p].y & 0xffff) && x[j] < (rs[j][p].y >> 16));
+        rd[j][p] = in && x[j] >= (rs[j][p].x & 0xffff) && x[j] < (rs[j][p].x >> 16);
+        size_t off = (size_t)uz * w.w + (unsigned)(x[j] - w.x0);
+        off = rd[j][p] ? off : 0;
+        v[j][p] = *reinterpret_cast<const float4*>(slab + off);
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < kMergeGroups; ++j) {
-    if (first + j * kMergeThreads >= total) break;
-    const size_t cell = fo * M + (size_t)zb[j] * a.mw + x[j];
-    *reinterpret_cast<float4*>(a.out + cell) = acc[j];
-    const uint32_t mk = (uint32_t)mask_of(acc[j].x, a.fill) |
-                        ((uint32_t)mask_of(acc[j].y, a.fill) << 8) |
-                        ((uint32_t)mask_of(acc[j].z, a.fill) << 16) |
-                        ((uint32_t)mask_of(acc[j].w, a.fill) << 24);
+  for (int j = 0; j < kMergeExclGroups; ++j) {
+    if (!live[j]) continue;
+    float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+#pragma unroll
+    for (int p = 0; p < kExclParts; ++p) {
+      if (p < a.nparts) {
+        const float4 m = make_float4(IS_MAX ? fmaxf(acc.x, v[j][p].x) : fminf(acc.x, v[j][p].x),
+                                     IS_MAX ? fmaxf(acc.y, v[j][p].y) : fminf(acc.y, v[j][p].y),
+                                     IS_MAX ? fmaxf(acc.z, v[j][p].z) : fminf(acc.z, v[j][p].z),
+                                     IS_MAX ? fmaxf(acc.w, v[j][p].w) : fminf(acc.w, v[j][p].w));
+        acc.x = rd[j][p] ? m.x : acc.x; acc.y = rd[j][p] ? m.y : acc.y;
+        acc.z = rd[j][p] ? m.z : acc.z; acc.w = rd[j][p] ? m.w : acc.w;
+      }
+    }
+    const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb[j] * a.mw + x[j];
+    *reinterpret_cast<float4*>(a.out + cell) = acc;
+    const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+                        ((uint32_t)mask_of(acc.z, a.fill) << 16) |
+                        ((uint32_t)mask_of(acc.w, a.fill) << 24);
     *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
   }
 }
@@ -614,10 +1017,11 @@ k_window_merge(MergeArgs a) {
 // whose union window covers c of out[b][c]; frames that do not cover c hold the
 // fill value there, so they cannot change the result and are never read.
 struct FuseArgs {
-  int B, dc, mh, mw;
+  int B, dc, mh, mw;          // B frames in this launch, starting at frame b0
+  int b0, accumulate;         // accumulate: fold into the current content of `fused`
   float fill;
-  const Window* unions;
-  const float* maps;          // (B, dc, mh, mw)
+  const Win16* unions;        // (B_total)   written by k_window_scatter
+  const float* maps;          // (B_total, dc, mh, mw)
   float* fused;               // (dc, mh, mw)
   uint8_t* fused_mask;
 };
@@ -641,6 +1045,8 @@ k_fuse_unions(FuseArgs a) {
   const size_t M = (size_t)a.mh * a.mw;
   const size_t cell = (size_t)z * a.mw + x;
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+  if (a.accumulate && lane == 0 && live)
+    acc = *reinterpret_cast<const float4*>(a.fused + (size_t)ch * M + cell);
   for (int b0 = lane; b0 < a.B; b0 += 8 * kFuseLanes) {
     float4 v[8];
 #pragma unroll
@@ -648,9 +1054,10 @@ k_fuse_unions(FuseArgs a) {
       const int bb = b0 + k * kFuseLanes;
       v[k] = acc;
       if (bb < a.B) {
-        const Window U = a.unions[bb];
+        const Window U = widen(a.unions[a.b0 + bb]);
         if ((unsigned)(z - U.z0) < (unsigned)U.h && (unsigned)(x - U.x0) < (unsigned)U.w)
-          v[k] = *reinterpret_cast<const float4*>(a.maps + ((size_t)bb * a.dc + ch) * M + cell);
+          v[k] = *reinterpret_cast<const float4*>(
+              a.maps + ((size_t)(a.b0 + bb) * a.dc + ch) * M + cell);
       }
     }
 #pragma unroll
@@ -685,12 +1092,13 @@ k_fuse_unions(FuseArgs a) {
 // per-frame maps are never materialised.  Same block shape as k_fuse_unions; the
 // 8 lanes of a group split the B * nparts windows.
 struct FuseWinArgs {
-  int nwin;                   // B * nparts windows per channel
+  int nwin;                   // windows of this launch: (frames of the chunk) * nparts
+  int b0;                     // first frame of the chunk
   int nparts, oc, ch0, oc_total, mh, mw;
   int slab_stride;
   int accumulate;
   float fill;
-  const Window* windows;
+  const Win16* wins;          // (B_total, nparts)   written by k_window_scatter
   const float* slabs;         // ((b * oc + chl) * nparts + p) * slab_stride
   float* fused;               // (oc_total, mh, mw)
   uint8_t* fused_mask;
@@ -727,12 +1135,12 @@ k_fuse_windows(FuseWinArgs a) {
     if (threadIdx.x == 0) ncand = 0;
     __syncthreads();
     for (int r = c0 + threadIdx.x; r < a.nwin && r < c0 + kFuseChunk; r += blockDim.x) {
-      const Window w = a.windows[r];
+      const Window w = widen(a.wins[(size_t)a.b0 * a.nparts + r]);
       if (w.w > 0 && w.z0 <= z_hi && w.z0 + w.h > z_lo && w.x0 < x_hi && w.x0 + w.w > x_lo) {
         const int slot = atomicAdd(&ncand, 1);
         const int b = r / a.nparts, p = r - b * a.nparts;
         cwin[slot] = make_int4(w.x0, w.z0, w.w, w.h);
-        cslab[slot] = (b * a.oc + chl) * a.nparts + p;
+        cslab[slot] = ((a.b0 + b) * a.oc + chl) * a.nparts + p;
       }
     }
     __syncthreads();
@@ -791,16 +1199,30 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 bool window_path_supported(const dm_params& p) {
   if (p.reduction != DM_REDUCE_MAX && p.reduction != DM_REDUCE_MIN) return false;
   if (p.mw % 4 != 0) return false;
+  if (p.mw > 32767 || p.mh > 32767) return false;   // Win16
   if (!(p.fill == p.fill)) return false;       // NaN fill has no order
   return true;
+}
+
+// Device copies of the call's geometry, written by k_window_scatter for the kernels that
+// follow it: part windows, union windows, row spans.
+static size_t geometry_bytes(int B, int nparts, int rows) {
+  const int ep = nparts < kExclParts ? nparts : kExclParts;
+  return align_up((size_t)B * nparts * sizeof(Win16), 256) + align_up((size_t)B * sizeof(Win16), 256) +
+         align_up((size_t)B * ep * rows * sizeof(RowSpan), 256);
+}
+
+// LDS words behind the window of k_window_scatter (see there)
+static size_t excl_table_bytes(int nparts, int max_rows_sum, int max_h) {
+  return 4 * ((size_t)nparts * (48 + 4 + 1) + max_rows_sum + 2 * (size_t)max_h) + 16;
 }
 
 static constexpr size_t kSlabBudget = (size_t)256 << 20;   // slab bytes per channel group
 
 size_t window_workspace_bytes(const dm_params& p) {
-  // frames | windows + unions | slabs of one channel group.  Sized for up to 4x the
-  // default number of parts (run_window splits further only when windows do not fit
-  // in LDS, and falls back to the generic path if the workspace cannot hold that).
+  // slabs of one channel group (+ the scratch mask of the height pass).  Sized for up
+  // to 4x the default number of parts (run_window splits further only when windows do
+  // not fit in LDS, and falls back to the generic path if the workspace cannot hold that).
   size_t cap = (size_t)p.mh * p.mw;
   if (cap > kMaxLdsBytes / 4) cap = kMaxLdsBytes / 4;
   const Parts d = choose_parts(p, 1);
@@ -811,8 +1233,7 @@ size_t window_workspace_bytes(const dm_params& p) {
   size_t slabs = one * oc;
   if (slabs > kSlabBudget) slabs = one > kSlabBudget ? one : kSlabBudget;
   const size_t height_mask = p.vc ? align_up((size_t)p.B * p.dc * p.mh * p.mw, 256) : 0;
-  return align_up((size_t)p.B * sizeof(dm_frame), 256) +
-         align_up((size_t)p.B * (128 + 1) * sizeof(Window), 256) + slabs + height_mask;
+  return geometry_bytes(p.B, 128, p.mh) + slabs + height_mask;
 }
 
 namespace {
@@ -820,16 +1241,31 @@ namespace {
 struct Staged {                 // what run_window keeps between its passes
   Parts parts;
   int nparts, slab_stride, max_union;
-  size_t frames_bytes, win_bytes;
+  int max_h, max_rows_sum;      // tallest window; most window rows of one frame
+  bool excl;                    // exclusive row spans
+  Win16* g_wins;                // device copies (workspace head)
+  Win16* g_unions;
+  RowSpan* g_rows;
+  size_t geom_bytes;
   bool fast, fast_div;
   float res_inv, fx_inv, fy_inv;
+  const FrameRec* frames;       // (B)            host, thread-local storage
+  const Win16* wins;            // (B, nparts)
+  const Win16* unions;          // (B)
 };
 
+template <class K, class... Args>
+inline hipError_t launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s,
+                         const Args&... args) {
+  hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+  return hipGetLastError();
+}
+
 // One pass: scatter `value` (or the heights when NULL) of channels [0, oc_total)
-// into out/mask, channel group by channel group.
+// into out/mask, channel group by channel group, chunk of frames by chunk of frames.
 // With `fused` set, the per-frame maps are skipped (out/mask NULL) and every channel
 // group's slabs are reduced straight into the (oc_total, mh, mw) fused map.
-hipError_t window_pass(const dm_params& p, const Staged& st, unsigned char* base,
+hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
                        const float* depth, const float* value, const uint8_t* valid, float* out,
                        uint8_t* mask, int oc_total, float fill, bool is_max, size_t slab_bytes,
                        hipStream_t s, float* fused = nullptr, uint8_t* fused_mask = nullptr,
@@ -849,19 +1285,26 @@ hipError_t window_pass(const dm_params& p, const Staged& st, unsigned char* base
   sa.oc_total = oc_total;
   sa.slab_stride = st.slab_stride;
   sa.fill = fill;
-  sa.frames = reinterpret_cast<const dm_frame*>(base);
-  sa.windows = reinterpret_cast<const Window*>(base + st.frames_bytes);
   sa.depth = depth; sa.value = value; sa.valid = valid;
-  sa.slabs = reinterpret_cast<float*>(base + st.frames_bytes + st.win_bytes);
-  sa.unions = sa.windows + (size_t)p.B * st.nparts;
+  sa.slabs = slabs;
   sa.out = out; sa.mask = mask; sa.mh = p.mh; sa.mw = p.mw;
 
   const bool has_valid = valid != nullptr, has_value = value != nullptr;
   const bool vec4 = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(depth) % 16 == 0) &&
                     (!value || reinterpret_cast<uintptr_t>(value) % 16 == 0) &&
                     (st.parts.wp % 4 == 0);
-  const size_t lds_bytes = align_up((size_t)st.slab_stride * 4, 16) + 64 * 4;   // + dummy cells
-  using Kernel = void (*)(ScatterArgs);
+  // per-frame maps with few parts: exclusive row spans (see RowSpan)
+  const bool excl = st.excl && out != nullptr && !fused;
+  sa.excl = excl;
+  sa.tab_off = (int)align_up((size_t)st.slab_stride, 4) + 64;
+  sa.max_rows_sum = st.max_rows_sum; sa.max_h = st.max_h;
+  sa.g_wins = st.g_wins; sa.g_unions = st.g_unions; sa.g_rows = st.g_rows;
+#ifdef DM_STAMPS
+  sa.stamps = g_stamp_buffer;
+#endif
+  size_t lds_bytes = align_up((size_t)st.slab_stride * 4, 16) + 64 * 4;   // + dummy cells
+  if (excl) lds_bytes += excl_table_bytes(st.nparts, st.max_rows_sum, st.max_h);
+  using Kernel = void (*)(ScatterArgs, ScatterTables);
 #define DM_K(M, F, V, S) {k_window_scatter<M, F, V, S, 1>, k_window_scatter<M, F, V, S, 4>}
   // [is_max][fast][has_valid][has_value][vec4]
   static const Kernel table[2][2][2][2][2] = {
@@ -907,73 +1350,86 @@ hipError_t window_pass(const dm_params& p, const Staged& st, unsigned char* base
     }
   }
 
+  // frames per launch: what the kernel-argument tables hold
+  const int win_stride = st.nparts <= kExclParts ? kExclParts : st.nparts;
+  int chunk = kChunkWins / win_stride;
+  if (chunk > kChunkFrames) chunk = kChunkFrames;
   // channel groups: the slabs of one group fit the workspace's slab region
   const size_t per_channel = (size_t)p.B * st.nparts * st.slab_stride * 4;
   int group = (int)(slab_bytes / (per_channel ? per_channel : 1));
   if (group < 1) group = 1;
   if (group > oc_total) group = oc_total;
-  while ((long)p.B * group > 65535) --group;
+  if (group > 65535 / chunk) group = 65535 / chunk;       // merge grid.y = frames * channels
+  static thread_local ScatterTables tab;     // (kernel arguments are copied at launch)
   for (int ch0 = 0; ch0 < oc_total; ch0 += group) {
     const int oc = oc_total - ch0 < group ? oc_total - ch0 : group;
     sa.oc = oc; sa.ch0 = ch0;
-    hipLaunchKernelGGL(kfn, dim3(st.nparts, oc, p.B), dim3(kScatterThreads), lds_bytes, s, sa);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (fused) {
+    for (int b0 = 0; b0 < p.B; b0 += chunk) {
+      const int nb = p.B - b0 < chunk ? p.B - b0 : chunk;
+      memcpy(tab.frames, st.frames + b0, (size_t)nb * sizeof(FrameRec));
+      for (int i = 0; i < nb; ++i)
+        memcpy(tab.wins + (size_t)i * win_stride, st.wins + (size_t)(b0 + i) * st.nparts,
+               (size_t)st.nparts * sizeof(Win16));
+      memcpy(tab.unions, st.unions + b0, (size_t)nb * sizeof(Win16));
+      sa.b0 = b0;
+      e = launch(kfn, dim3(st.nparts, oc, nb), dim3(kScatterThreads), lds_bytes, s, sa, tab);
+      if (e != hipSuccess) return e;
+      if (!fused && st.max_union > 0) {
+        MergeArgs ma;
+        ma.b0 = b0; ma.oc = oc; ma.ch0 = ch0; ma.oc_total = oc_total; ma.mh = p.mh; ma.mw = p.mw;
+        ma.nparts = st.nparts; ma.slab_stride = st.slab_stride; ma.fill = fill;
+        ma.wins = st.g_wins; ma.unions = st.g_unions; ma.rows = st.g_rows;
+        ma.slabs = slabs; ma.out = out; ma.mask = mask;
+        const dim3 g((unsigned)((st.max_union / 4 + kMergeThreads - 1) / kMergeThreads), nb * oc);
+        if (excl) {
+          static thread_local MergeUnions mu;
+          memcpy(mu.u, tab.unions, (size_t)nb * sizeof(Win16));
+          const int per_block = kMergeThreads * kMergeExclGroups;
+          const dim3 g((unsigned)((st.max_union / 4 + per_block - 1) / per_block), nb * oc);
+          e = is_max ? launch(k_window_merge_excl<true>, g, dim3(kMergeThreads), 0, s, ma, mu)
+                     : launch(k_window_merge_excl<false>, g, dim3(kMergeThreads), 0, s, ma, mu);
+        } else {
+          e = is_max ? launch(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma)
+                     : launch(k_window_merge<false>, g, dim3(kMergeThreads), 0, s, ma);
+        }
+        if (e != hipSuccess) return e;
+      }
+    }
+    if (fused) {     // every frame's slabs of this channel group are in place
       FuseWinArgs fa;
-      fa.nwin = p.B * st.nparts; fa.nparts = st.nparts; fa.oc = oc; fa.ch0 = ch0;
+      fa.nwin = p.B * st.nparts; fa.b0 = 0; fa.nparts = st.nparts; fa.oc = oc; fa.ch0 = ch0;
       fa.oc_total = oc_total; fa.mh = p.mh; fa.mw = p.mw; fa.slab_stride = st.slab_stride;
       fa.accumulate = accumulate; fa.fill = fill;
-      fa.windows = sa.windows; fa.slabs = sa.slabs; fa.fused = fused; fa.fused_mask = fused_mask;
-      dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kFuseGroups - 1) / kFuseGroups), oc);
+      fa.wins = st.g_wins; fa.slabs = slabs; fa.fused = fused; fa.fused_mask = fused_mask;
+      const dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kFuseGroups - 1) / kFuseGroups), oc);
       const dim3 blk(kFuseGroups * kFuseLanes);
-      if (is_max) hipLaunchKernelGGL(k_fuse_windows<true>, g, blk, 0, s, fa);
-      else hipLaunchKernelGGL(k_fuse_windows<false>, g, blk, 0, s, fa);
-      e = hipGetLastError();
-      if (e != hipSuccess) return e;
-    } else if (st.max_union > 0) {
-      MergeArgs ma;
-      ma.B = p.B; ma.oc = oc; ma.ch0 = ch0; ma.oc_total = oc_total; ma.mh = p.mh; ma.mw = p.mw;
-      ma.nparts = st.nparts; ma.slab_stride = st.slab_stride; ma.fill = fill;
-      ma.windows = sa.windows; ma.unions = sa.unions; ma.slabs = sa.slabs;
-      ma.out = out; ma.mask = mask;
-      const int per_block = kMergeThreads * kMergeGroups;          // float4 groups
-      dim3 g((unsigned)((st.max_union / 4 + per_block - 1) / per_block), p.B * oc);
-      if (is_max) hipLaunchKernelGGL(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma);
-      else hipLaunchKernelGGL(k_window_merge<false>, g, dim3(kMergeThreads), 0, s, ma);
-      e = hipGetLastError();
+      e = is_max ? launch(k_fuse_windows<true>, g, blk, 0, s, fa)
+                 : launch(k_fuse_windows<false>, g, blk, 0, s, fa);
       if (e != hipSuccess) return e;
     }
   }
   return hipSuccess;
 }
 
-}  // namespace
-
-// Returns hipErrorNotSupported when the windows cannot be made to fit in LDS (the
-// caller then takes the generic path); nothing has been enqueued in that case.
-static hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* ws,
-                                size_t ws_bytes, Staged& st, size_t& slab_bytes, hipStream_t s) {
+// Host-side geometry of a call: parts, part windows, frame records.  Returns
+// hipErrorNotSupported when the windows cannot be made to fit in LDS (the caller then
+// takes the generic path); nothing has been enqueued in that case.
+hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* ws,
+                         size_t ws_bytes, Staged& st, size_t& slab_bytes) {
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return hipErrorNotSupported;
-  // host staging (thread-local: hipMemcpyAsync from pageable memory has copied
-  // the bytes out by the time it returns)
-  thread_local std::vector<unsigned char> staging;
-  st.frames_bytes = align_up((size_t)p.B * sizeof(dm_frame), 256);
+  thread_local std::vector<FrameRec> recs;
+  thread_local std::vector<Win16> wins;      // (B, nparts) then (B) unions
   // more, narrower parts until every window fits in LDS
   int max_area = 0;
-  Window* wins = nullptr;
-  Window* unions = nullptr;
   for (int min_parts = 1;; min_parts *= 2) {
     st.parts = choose_parts(p, min_parts);
     st.nparts = st.parts.pc * st.parts.pr;
     if (st.nparts > 128) return hipErrorNotSupported;
-    st.win_bytes = align_up((size_t)p.B * (st.nparts + 1) * sizeof(Window), 256);
-    staging.resize(st.frames_bytes + st.win_bytes);
-    wins = reinterpret_cast<Window*>(staging.data() + st.frames_bytes);
-    unions = wins + (size_t)p.B * st.nparts;     // (B): bounding box of a frame's windows
-    max_area = 0; st.max_union = 0;
+    wins.resize((size_t)p.B * (st.nparts + 1));
+    Win16* unions = wins.data() + (size_t)p.B * st.nparts;
+    max_area = 0; st.max_union = 0; st.max_h = 0; st.max_rows_sum = 0;
     for (int b = 0; b < p.B; ++b) {
-      int ux0 = p.mw, ux1 = 0, uz0 = p.mh, uz1 = 0;
+      int ux0 = p.mw, ux1 = 0, uz0 = p.mh, uz1 = 0, rows_sum = 0;
       const FrameAffine fa = frame_affine(p, frames_host[b]);
       for (int pr = 0; pr < st.parts.pr; ++pr)
         for (int pc = 0; pc < st.parts.pc; ++pc) {
@@ -981,17 +1437,21 @@ static hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host,
           const int q1 = q0 + st.parts.wp < p.W ? q0 + st.parts.wp : p.W;
           const int r1 = r0 + st.parts.hp < p.H ? r0 + st.parts.hp : p.H;
           const Window w = part_window(p, fa, q0, q1, r0, r1);
-          wins[(size_t)b * st.nparts + pr * st.parts.pc + pc] = w;
+          wins[(size_t)b * st.nparts + pr * st.parts.pc + pc] = narrow(w);
           if (w.w * w.h > max_area) max_area = w.w * w.h;
           if (w.w > 0) {
+            rows_sum += w.h;
+            if (w.h > st.max_h) st.max_h = w.h;
             if (w.x0 < ux0) ux0 = w.x0;
             if (w.x0 + w.w > ux1) ux1 = w.x0 + w.w;
             if (w.z0 < uz0) uz0 = w.z0;
             if (w.z0 + w.h > uz1) uz1 = w.z0 + w.h;
           }
         }
-      unions[b] = ux1 > ux0 ? Window{ux0, uz0, ux1 - ux0, uz1 - uz0} : Window{0, 0, 0, 0};
-      if (unions[b].w * unions[b].h > st.max_union) st.max_union = unions[b].w * unions[b].h;
+      const Window U = ux1 > ux0 ? Window{ux0, uz0, ux1 - ux0, uz1 - uz0} : Window{0, 0, 0, 0};
+      unions[b] = narrow(U);
+      if (U.w * U.h > st.max_union) st.max_union = U.w * U.h;
+      if (rows_sum > st.max_rows_sum) st.max_rows_sum = rows_sum;
     }
     if ((size_t)max_area * 4 + 64 * 4 + 16 <= (size_t)kMaxLdsBytes) break;
     // a window that is the whole map cannot shrink by splitting the image
@@ -1000,17 +1460,42 @@ static hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host,
       return hipErrorNotSupported;
   }
   st.slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 4);
-  const size_t fixed = st.frames_bytes + st.win_bytes;
-  if (ws_bytes < fixed + (size_t)p.B * st.nparts * st.slab_stride * 4) return hipErrorNotSupported;
-  slab_bytes = ws_bytes - fixed;
+  if (st.max_h < 1) st.max_h = 1;
+  // exclusive row spans: a few parts per frame, a proper frustum slab, tables that fit
+  // (work in progress: off unless DM_EXCL is set -- the per-workgroup table phase still
+  // costs more than the smaller merge gains)
+  static const bool no_excl = getenv("DM_EXCL") == nullptr;
+  st.excl = !no_excl && st.nparts > 1 && st.nparts <= kExclParts && p.has_dmin && p.has_dmax &&
+            p.dmin >= 0.0f && p.dmax >= p.dmin && isfinite(p.dmax) &&
+            align_up((size_t)st.slab_stride * 4, 16) + 64 * 4 +
+                    excl_table_bytes(st.nparts, st.max_rows_sum, st.max_h) <= (size_t)kMaxLdsBytes;
+  st.geom_bytes = geometry_bytes(p.B, st.nparts, st.excl ? p.mh : 0);
+  if (ws_bytes < st.geom_bytes + (size_t)p.B * st.nparts * st.slab_stride * 4)
+    return hipErrorNotSupported;
+  slab_bytes = ws_bytes - st.geom_bytes;
+  {
+    unsigned char* base = static_cast<unsigned char*>(ws);
+    st.g_wins = reinterpret_cast<Win16*>(base);
+    base += align_up((size_t)p.B * st.nparts * sizeof(Win16), 256);
+    st.g_unions = reinterpret_cast<Win16*>(base);
+    base += align_up((size_t)p.B * sizeof(Win16), 256);
+    st.g_rows = reinterpret_cast<RowSpan*>(base);
+  }
 
-  memcpy(staging.data(), frames_host, (size_t)p.B * sizeof(dm_frame));
-  if (!p.to_global) {     // local map: neutral yaw, no translation (exact: x*1 + z*0 + 0)
-    dm_frame* fr = reinterpret_cast<dm_frame*>(staging.data());
-    static const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    for (int b = 0; b < p.B; ++b) {
-      memcpy(fr[b].Ry, eye, sizeof(eye));
-      fr[b].tx = 0.0f; fr[b].tz = 0.0f;
+  recs.resize(p.B);
+  for (int b = 0; b < p.B; ++b) {
+    const dm_frame& f = frames_host[b];
+    FrameRec& r = recs[b];
+    memcpy(r.p, f.Rp, sizeof(r.p));
+    r.cam_h = f.cam_height;
+    r.wo = f.width_offset; r.ho = f.height_offset; r.pad = 0.0f;
+    if (p.to_global) {
+      memcpy(r.y, f.Ry, sizeof(r.y));
+      r.tx = f.tx; r.tz = f.tz;
+    } else {              // local map: neutral yaw, no translation (exact: x*1 + z*0 + 0)
+      static const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      memcpy(r.y, eye, sizeof(eye));
+      r.tx = 0.0f; r.tz = 0.0f;
     }
   }
   // branch-free exact division needs exactly rounded reciprocals and sane magnitudes
@@ -1018,10 +1503,14 @@ static hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host,
                 exact_reciprocal(p.fy, &st.fy_inv) && p.res >= 1e-6f && p.res <= 1e6f &&
                 p.fx >= 1e-6f && p.fx <= 1e6f && p.fy >= 1e-6f && p.fy <= 1e6f;
   if (!st.fast_div) st.res_inv = st.fx_inv = st.fy_inv = 0.0f;
-  st.fast = st.fast_div && axis_aligned(reinterpret_cast<const dm_frame*>(staging.data()), p.B);
-
-  return hipMemcpyAsync(ws, staging.data(), fixed, hipMemcpyHostToDevice, s);
+  st.fast = st.fast_div && axis_aligned(recs.data(), p.B);
+  st.frames = recs.data();
+  st.wins = wins.data();
+  st.unions = wins.data() + (size_t)p.B * st.nparts;
+  return hipSuccess;
 }
+
+}  // namespace
 
 hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const float* depth,
                       const float* value, const uint8_t* valid, float* out, uint8_t* mask,
@@ -1035,12 +1524,13 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     return hipErrorNotSupported;
   Staged st;
   size_t slab_bytes = 0;
-  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s);
+  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes);
   if (e != hipSuccess) return e;
   unsigned char* base = static_cast<unsigned char*>(ws);
+  float* slabs = reinterpret_cast<float*>(base + st.geom_bytes);
 
   const bool is_max = p.reduction == DM_REDUCE_MAX;
-  e = window_pass(p, st, base, depth, value, valid, out, mask, oc_total, p.fill, is_max,
+  e = window_pass(p, st, slabs, depth, value, valid, out, mask, oc_total, p.fill, is_max,
                   slab_bytes, s);
   if (e != hipSuccess) return e;
   if (height && value) {      // maps.py:332-350: second projection, NINF fill, max
@@ -1048,7 +1538,7 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     const size_t hm = (size_t)p.B * p.dc * p.mh * p.mw;
     if (slab_bytes < hm + (size_t)p.B * st.nparts * st.slab_stride * 4) return hipErrorNotSupported;
     uint8_t* scratch_mask = base + ws_bytes - hm;
-    e = window_pass(p, st, base, depth, nullptr, valid, height, scratch_mask, p.dc, -INFINITY, true,
+    e = window_pass(p, st, slabs, depth, nullptr, valid, height, scratch_mask, p.dc, -INFINITY, true,
                     slab_bytes - hm, s);
     if (e != hipSuccess) return e;
   }
@@ -1058,15 +1548,16 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
   }
   if (fused) {
     FuseArgs fa;
-    fa.B = p.B; fa.dc = oc_total; fa.mh = p.mh; fa.mw = p.mw; fa.fill = p.fill;
-    fa.unions = reinterpret_cast<const Window*>(base + st.frames_bytes) + (size_t)p.B * st.nparts;
-    fa.maps = out; fa.fused = fused; fa.fused_mask = fused_mask;
-    dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kFuseGroups - 1) / kFuseGroups), oc_total);
+    fa.B = p.B; fa.b0 = 0; fa.accumulate = 0;
+    fa.dc = oc_total; fa.mh = p.mh; fa.mw = p.mw; fa.fill = p.fill;
+    fa.unions = st.g_unions; fa.maps = out; fa.fused = fused; fa.fused_mask = fused_mask;
+    const dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kFuseGroups - 1) / kFuseGroups), oc_total);
     const dim3 blk(kFuseGroups * kFuseLanes);
-    if (is_max) hipLaunchKernelGGL(k_fuse_unions<true>, g, blk, 0, s, fa);
-    else hipLaunchKernelGGL(k_fuse_unions<false>, g, blk, 0, s, fa);
+    e = is_max ? launch(k_fuse_unions<true>, g, blk, 0, s, fa)
+               : launch(k_fuse_unions<false>, g, blk, 0, s, fa);
+    if (e != hipSuccess) return e;
   }
-  return hipGetLastError();
+  return hipSuccess;
 }
 
 // dm_orth_project_fused_f32: scatter into the LDS windows, then reduce the slabs of
@@ -1078,11 +1569,18 @@ hipError_t run_window_fused(const dm_params& p, const dm_frame* frames_host, con
     return hipErrorNotSupported;
   Staged st;
   size_t slab_bytes = 0;
-  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s);
+  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes);
   if (e != hipSuccess) return e;
-  return window_pass(p, st, static_cast<unsigned char*>(ws), depth, value, valid, nullptr, nullptr,
+  return window_pass(p, st, reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + st.geom_bytes),
+                     depth, value, valid, nullptr, nullptr,
                      p.vc ? p.vc : p.dc, p.fill, p.reduction == DM_REDUCE_MAX, slab_bytes, s, out,
                      mask, accumulate);
 }
 
 }  // namespace dm
+
+#ifdef DM_STAMPS
+extern "C" __attribute__((visibility("default"))) void dm_debug_stamp_buffer(long long* dev) {
+  dm::g_stamp_buffer = dev;
+}
+#endif

@@ -1,0 +1,94 @@
+"""Host model of the exclusive row spans of dm_window.hip (double precision), to size
+what each kernel writes for a given workload geometry.  Not part of the product."""
+import numpy as np
+
+def corners(q0, q1, r0, r1, dmin, dmax, P):
+  W, H, cx, cy, fx, fy, pitch, camh, yaw, tx, tz, res, wo, ho, mh, flip = P
+  out = []
+  for ci in range(8):
+    z = dmax if ci & 1 else dmin
+    r = (r1 - 1) if ci & 2 else r0
+    q = (q1 - 1) if ci & 4 else q0
+    yr = (H - 1 - r) if flip else r
+    ax, ay = (q - cx) / fx, (yr - cy) / fy
+    X, Y, Z = ax * z, ay * z, z
+    c, s = np.cos(pitch), np.sin(pitch)
+    # rotate about x by pitch (row-vector convention of utils.rotate)
+    Rx = np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    v = np.array([X, Y, Z]) @ Rx
+    v[1] += camh
+    c, s = np.cos(yaw), np.sin(yaw)
+    Ry = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    v = v @ Ry + np.array([tx, 0, tz])
+    xf = v[0] / res + wo
+    zf = v[2] / res + ho
+    if flip: zf = (mh - 1) - zf
+    out.append((xf + 0.5, zf + 0.5))
+  return np.array(out)
+
+def spans(cor, mh, mw):
+  edges = []
+  for axis in range(3):
+    for k in range(4):
+      low = (1 << axis) - 1
+      ia = ((k & ~low) << 1) | (k & low)
+      edges.append((ia, ia | (1 << axis)))
+  x0 = max(0, int(np.floor(cor[:, 0].min())) - 2) & ~3
+  x1 = min(mw, (int(np.floor(cor[:, 0].max())) + 3 + 3) & ~3)
+  z0 = max(0, int(np.floor(cor[:, 1].min())) - 2)
+  z1 = min(mh, int(np.floor(cor[:, 1].max())) + 3)
+  res = {}
+  for z in range(z0, z1):
+    blo, bhi = z - 1, z + 2
+    lo, hi = np.inf, -np.inf
+    for a, b in edges:
+      xa, za = cor[a]; xb, zb = cor[b]
+      dz = zb - za
+      if abs(dz) < 1e-6:
+        if not (blo <= za <= bhi): continue
+        t0, t1 = 0., 1.
+      else:
+        ta, tb = (blo - za) / dz, (bhi - za) / dz
+        t0, t1 = max(min(ta, tb), 0.), min(max(ta, tb), 1.)
+        if t0 > t1: continue
+      for t in (t0, t1):
+        x = xa + t * (xb - xa); lo = min(lo, x); hi = max(hi, x)
+    if lo <= hi:
+      l = max(int(np.floor(lo)) - 2, x0) & ~3
+      r = (min(int(np.floor(hi)) + 3, x1) + 3) & ~3
+      if l < r: res[z] = (l, r)
+  return (x0, z0, x1 - x0, z1 - z0), res
+
+def main():
+  W, H, mh, mw = 640, 480, 512, 512
+  hfov = np.radians(70.)
+  cx, cy = W / 2., H / 2.
+  fx = cx / np.tan(hfov / 2.); fy = fx
+  rng = np.random.default_rng(0)
+  tot = dict(bbox=0, span=0, excl=0, ubox=0)
+  nf = 16
+  for f in range(nf):
+    tx, tz = rng.uniform(-1, 1, 2); yaw = rng.uniform(-np.pi, np.pi)
+    P = (W, H, cx, cy, fx, fy, np.radians(-20.), 0.88, yaw, tx, tz, 0.03, mw / 2., mh / 2., mh, True)
+    parts = []
+    for pc in range(4):
+      cor = corners(pc * 160, pc * 160 + 160, 0, H, 0.15, 5.05, P)
+      parts.append(spans(cor, mh, mw))
+    ux0 = min(p[0][0] for p in parts); ux1 = max(p[0][0] + p[0][2] for p in parts)
+    uz0 = min(p[0][1] for p in parts); uz1 = max(p[0][1] + p[0][3] for p in parts)
+    tot['ubox'] += (ux1 - ux0) * (uz1 - uz0)
+    for i, (win, sp) in enumerate(parts):
+      tot['bbox'] += win[2] * win[3]
+      for z, (l, r) in sp.items():
+        tot['span'] += r - l
+        e0, e1 = l, r
+        for j, (_, sq) in enumerate(parts):
+          if j == i or z not in sq: continue
+          lq, rq = sq[z]
+          if rq <= e0 or lq >= e1: continue
+          if lq <= e0: e0 = min(rq, e1)
+          else: e1 = lq
+        if e0 < e1: tot['excl'] += e1 - e0
+  for k, v in tot.items(): print(k, v / nf, "cells per frame")
+
+main()

@@ -266,6 +266,8 @@ def main():
           "algorithmic_bytes_per_launch": alg,
           "launch_us": kernel_s * 1e6,
           "launch_us_min": float(proj_ms.min()) * 1e3,
+          "launch_us_median": float(np.median(proj_ms)) * 1e3,
+          "launch_us_p90": float(np.percentile(proj_ms, 90)) * 1e3,
       },
   }
 

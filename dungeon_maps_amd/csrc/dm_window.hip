@@ -23,6 +23,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
 #include <type_traits>
 #include <vector>
 
@@ -73,11 +75,12 @@ struct ScatterTables {
   Win16 unions[kChunkFrames];             // bounding box of a frame's windows, x aligned to 4
 };
 
-// Row r of a part's window: the part can only reach cells [l, r) of it (its "span":
-// the frustum slab is convex), and [e0, e1) of those belong to no other part's span --
-// the scatter kernel writes them to the map itself; everything else inside the frame's
-// union window is k_window_merge's.  Absolute map columns, multiples of 4.
-struct RowSpan { short l, r, e0, e1; };
+// Exclusive row spans (k_window_scatter<..., EXCL>): row z of a part's window can only be
+// reached in cells [l, r) (its "span": the frustum slab of the part is convex), and the
+// piece [e0, e1) of the span that lies in no other part's span belongs to this part alone
+// -- its workgroup writes it to the map itself.  The rest of the hull of the spans of a
+// row (the "border") is merged by the frame's last workgroup.  Absolute map columns,
+// multiples of 4, packed as lo | hi << 16.
 
 __device__ __host__ inline Window widen(Win16 w) { return Window{w.x0, w.z0, w.w, w.h}; }
 __host__ inline Win16 narrow(Window w) {
@@ -244,9 +247,14 @@ __host__ Window part_window(const dm_params& p, const FrameAffine& fa, int q0, i
 #define DM_STAMP(k) do { long long t_; \
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     stamp[k] = t_; } while (0)
+#define DM_STAMPS_OUT() do { if (threadIdx.x == 0 && a.stamps) \
+    for (int k_ = 0; k_ < 12; ++k_) \
+      a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 12 + k_] = stamp[k_]; \
+  } while (0)
 static long long* g_stamp_buffer = nullptr;
 #else
 #define DM_STAMP(k) do { } while (0)
+#define DM_STAMPS_OUT() do { } while (0)
 #endif
 
 struct ScatterArgs {
@@ -268,13 +276,13 @@ struct ScatterArgs {
   long long* stamps;
 #endif
   int b0;                     // first frame of this launch's chunk
-  int excl;                   // exclusive row spans (<= kExclParts parts, finite depth bounds)
   int tab_off;                // LDS word offset of the span tables (behind window + dummy cells)
   int max_rows_sum;           // most window rows of one frame, all parts together
-  int max_h;                  // tallest window: row stride of g_rows
+  int max_h, max_uh;          // tallest part window / union window
   Win16* g_wins;              // (B, nparts)  device copies for the kernels that follow
   Win16* g_unions;            // (B)
-  RowSpan* g_rows;            // (B, mh, nparts), excl only: row z of part p's window
+  unsigned long long* tickets;  // (B, oc_total), EXCL only: epoch << 8 | workgroups done
+  unsigned long long epoch;   // unique per launch
   const float* depth;
   const float* value;         // (B, oc_total, H, W) or NULL: project the heights
   const uint8_t* valid;
@@ -307,6 +315,46 @@ __device__ inline void lds_reduce(float* cell, float v) {
   else __hip_atomic_fetch_min(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Span of map row z in every part of the frame (0: none).
+__device__ __forceinline__ void gather_spans(int (&sl)[kExclParts], int z, int nparts, const int* winl,
+                                    const int* sp, const int (&row_off)[kExclParts + 1]) {
+#pragma unroll
+  for (int q = 0; q < kExclParts; ++q) {
+    sl[q] = 0;
+    if (q < nparts) {                                              // wave-uniform
+      const int z0 = winl[4 * q + 1], ww = winl[4 * q + 2], wh = winl[4 * q + 3];
+      const unsigned uq = (unsigned)(z - z0);
+      if (ww > 0 && uq < (unsigned)wh) sl[q] = sp[row_off[q] + (int)uq];
+    }
+  }
+}
+
+// The piece of part p's span that no other part's span touches (0: none).  Every
+// workgroup of a frame evaluates this on the same spans, so they agree on the owners.
+__device__ __forceinline__ int exclusive_interval(const int (&sl)[kExclParts], int p, int nparts) {
+  int mine = 0;
+#pragma unroll
+  for (int q = 0; q < kExclParts; ++q) mine = q == p ? sl[q] : mine;
+  int e0 = mine & 0xffff, e1 = mine >> 16;
+#pragma unroll
+  for (int q = 0; q < kExclParts; ++q) {
+    const int lq = sl[q] & 0xffff, rq = sl[q] >> 16;
+    const bool cut = q < nparts && q != p && lq < rq && rq > e0 && lq < e1;
+    const bool left = lq <= e0;                // covers the left end (or everything)
+    const int ne0 = rq < e1 ? rq : e1;
+    e0 = cut && left ? ne0 : e0;
+    e1 = cut && !left ? lq : e1;               // covers the right end, or lies inside: keep the left piece
+  }
+  return e0 < e1 ? (e0 | (e1 << 16)) : 0;
+}
+
+// 16-byte store that is written through to memory (another XCD reads it in this launch)
+__device__ inline void store_through(float* p, float4 v) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(d) : "memory");
+}
+
 // FAST: every frame's rotations have the exact 0/1 pattern of rotate([1,0,0],.)
 //       and rotate([0,1,0],.) AND the Markstein reciprocals are usable
 //       (dm_pixel.hpp).  !FAST: full FMA chains and IEEE division.
@@ -316,7 +364,9 @@ __device__ inline void lds_reduce(float* cell, float v) {
 //       (no border clip, no valid map): a non-finite or out-of-range pixel is then
 //       already rejected by the two depth compares, so the ordered-compare and the
 //       height compare are dropped.  (Pipeline-tail rows are poisoned through z.)
-template <bool IS_MAX, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC, bool LEAN = false>
+// EXCL: exclusive row spans (see Win16) -- the kernel then also writes the cells of the
+//       union window and no merge kernel follows.
+template <bool IS_MAX, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC, bool LEAN, bool EXCL>
 __global__ void __launch_bounds__(kScatterThreads)
 k_window_scatter(ScatterArgs a, ScatterTables t) {
   extern __shared__ float lds[];
@@ -345,14 +395,16 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
   }
 
   // Fill duty, interleaved with the scatter so that these stores ride under the
-  // VALU-bound projection: map rows part, part + nparts, ... of (b, ch), minus the
-  // frame's union window U (k_window_merge writes U).  One float4 (+ 4 mask bytes)
-  // per thread and step, ALWAYS executed: an element that needs no store (inside U,
-  // or past the end) is redirected to `alt`, a cell of this workgroup's share that
-  // does get the fill value, so the stores are unconditional straight-line code and
-  // the compiler can count the pipelined loop's waits exactly.
+  // projection: map rows row_first, row_first + row_step, ... of (b, ch), minus what other
+  // code writes -- the frame's union window U (k_window_merge), or with exclusive spans
+  // the hull [min l, max r) of the parts' spans of each row.  One float4 (+ 4 mask bytes)
+  // per thread and step, ALWAYS executed: an element that needs no store is redirected to
+  // `alt`, a cell of this workgroup's share that does get the fill value, so the stores
+  // are unconditional straight-line code and the compiler can count the pipelined loop's
+  // waits exactly.
   const Window U = widen(t.unions[bl]);
   const int g4 = a.mw >> 2;
+  const int row_first = part, row_step = nparts;
   const int fill_rows = (a.mh - part + nparts - 1) / nparts;
   const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
   // where redirected stores go: a cell of this share outside U if there is one (it gets
@@ -361,20 +413,35 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
   // spans other workgroups store into U concurrently, so the fill is then done with
   // conditional stores after the scatter instead (alt_safe == false; only when U spans
   // the whole map width and this share's first and last rows).
-  int alt_cell = part * a.mw;
+  int alt_cell = row_first * a.mw;
   bool alt_safe = true;
   if (fill_rows > 0 && U.w > 0 && U.h > 0 && U.x0 == 0) {
-    const int last_row = part + (fill_rows - 1) * nparts;
-    if (U.x0 + U.w < a.mw) alt_cell = part * a.mw + U.x0 + U.w;                  // right of U
+    const int last_row = row_first + (fill_rows - 1) * row_step;
+    if (U.x0 + U.w < a.mw) alt_cell = row_first * a.mw + U.x0 + U.w;             // right of U
     else if (last_row >= U.z0 + U.h) alt_cell = last_row * a.mw;                 // below U
-    else alt_safe = part < U.z0;                                                 // above U
+    else alt_safe = row_first < U.z0;                                            // above U
   }
-  const bool excl = a.excl != 0;
-  const bool cond_fill = excl && !alt_safe;                                      // wave-uniform
+  const bool cond_fill = EXCL && !alt_safe;                                     // wave-uniform
   const bool do_fill = a.out != nullptr && fill_rows > 0;                       // wave-uniform
   const int fill_total = do_fill ? fill_rows * g4 : 0;
   const int fill_steps = (fill_total + kScatterThreads - 1) / kScatterThreads;
   const float g4_inv = 1.0f / (float)g4;
+  // LDS behind the window and its dummy cells (EXCL only):
+  //   edges  (nparts, 12, 4) float   lower end x, z, upper end z, dx/dz of the slab's edges
+  //   winl   (nparts, 4)     int     the frame's part windows x0, z0, w, h
+  //   bad    (nparts)        int     a corner of the part is not finite: no spans
+  //   sp     (rows of all parts of the frame) int   span l | r << 16
+  //   ex     (w.h)           int     exclusive interval e0 | e1 << 16 of this part's rows
+  //   hull   (U.h)           int     min l | max r << 16 over the parts, per row of U
+  //   flag   (4)             int     last-arriver flag, border list length
+  int* const tabs = reinterpret_cast<int*>(lds) + a.tab_off;
+  float* const edges = reinterpret_cast<float*>(tabs);
+  int* const winl = tabs + nparts * 48;
+  int* const bad = winl + nparts * 4;
+  int* const sp = bad + nparts;
+  int* const ex = sp + a.max_rows_sum;
+  int* const hull = ex + a.max_h;
+  int* const flag = hull + a.max_uh;
   int fs = 0;
   auto fill_step = [&]() {
     const int i = fs * kScatterThreads + (int)threadIdx.x;     // < 2^24
@@ -383,9 +450,14 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
     k -= (k * g4 > i);
     k += ((k + 1) * g4 <= i);
     const int g = i - k * g4;
-    const int r = part + k * nparts, x = g << 2;
-    const bool skip = i >= fill_total || ((unsigned)(r - U.z0) < (unsigned)U.h &&
-                                          (unsigned)(x - U.x0) < (unsigned)U.w);
+    const int r = row_first + k * row_step, x = g << 2;
+    const bool in_rows = (unsigned)(r - U.z0) < (unsigned)U.h;
+    int lo = U.x0, hi = U.x0 + U.w;
+    if (EXCL) {
+      const int hb = hull[in_rows ? r - U.z0 : 0];
+      lo = hb & 0xffff; hi = hb >> 16;
+    }
+    const bool skip = i >= fill_total || (in_rows && x >= lo && x < hi);
     int cell = r * a.mw + x;
     asm("" : "+v"(cell));                      // keep the select a v_cndmask
     cell = skip ? alt_cell : cell;
@@ -399,20 +471,28 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
     }
     for (int i = fs * kScatterThreads + (int)threadIdx.x; i < fill_total; i += kScatterThreads) {
       const int k = i / g4, g = i - k * g4;
-      const int r = part + k * nparts, x = g << 2;
-      if ((unsigned)(r - U.z0) < (unsigned)U.h && (unsigned)(x - U.x0) < (unsigned)U.w) continue;
+      const int r = row_first + k * row_step, x = g << 2;
+      if ((unsigned)(r - U.z0) < (unsigned)U.h) {
+        const int hb = hull[r - U.z0];
+        if (x >= (hb & 0xffff) && x < (hb >> 16)) continue;
+      }
       const size_t cell = map_base + (size_t)r * a.mw + x;
       *reinterpret_cast<float4*>(a.out + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
       *reinterpret_cast<uint32_t*>(a.mask + cell) = 0u;
     }
     fs = fill_steps;
   };
+  // fill steps that may run before the hull table exists: rows of this share above U
+  int rows_above = (U.z0 - row_first + row_step - 1) / row_step;
+  rows_above = U.h > 0 ? (rows_above < 0 ? 0 : (rows_above > fill_rows ? fill_rows : rows_above)) : fill_rows;
+  const bool fill_ahead = EXCL && do_fill && !cond_fill && rows_above * g4 >= kFillAhead * kScatterThreads;
   // device copies of the geometry for the kernels that follow
   if (chl == 0 && threadIdx.x == 0) {
     a.g_wins[(size_t)b * nparts + part] = t.wins[bl * win_stride + part];
     if (part == 0) a.g_unions[b] = t.unions[bl];
   }
-  if (area == 0) {                             // wave-uniform
+  const bool has_px = area > 0;                // wave-uniform
+  if (!EXCL && !has_px) {
     fill_rest();
     return;
   }
@@ -429,20 +509,9 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
   const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
 
   // ---- exclusive row spans -------------------------------------------------------
-  // LDS behind the window and its dummy cells:
-  //   edges  (nparts, 12, 4) float   xa, za, xb - xa, 1 / (zb - za) of the slab's edges
-  //   winl   (nparts, 4)     int     the frame's part windows x0, z0, w, h
-  //   bad    (nparts)        int     a corner of the part is not finite: no spans
-  //   sp     (rows of all parts of the frame) int   l | r << 16
-  //   own    (w.h, 2)        int     l | r << 16, e0 | e1 << 16 of this part
-  int* const tabs = reinterpret_cast<int*>(lds) + a.tab_off;
-  float* const edges = reinterpret_cast<float*>(tabs);
-  int* const winl = tabs + nparts * 48;
-  int* const bad = winl + nparts * 4;
-  int* const sp = bad + nparts;
-  int* const own = sp + a.max_rows_sum;
   int row_off[kExclParts + 1];                 // first sp entry of each part (wave-uniform)
-  if (excl) {
+  int my_off = 0;
+  if (EXCL) {
     row_off[0] = 0;
 #pragma unroll
     for (int q = 0; q < kExclParts; ++q) {
@@ -456,13 +525,14 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
         }
       }
       row_off[q + 1] = row_off[q] + hq;
+      my_off = q == part ? row_off[q] : my_off;
     }
   }
   lds_barrier();
   DM_STAMP(1);
   // (run by every thread once its first depth rows are requested: the table arithmetic
   // hides the latency of those loads)
-  auto build_tables = [&]() {
+  auto build_tables = [&]() __attribute__((always_inline)) {
     // the frustum slab of a part (its pixel rectangle x [dmin, dmax]) is convex, so its
     // footprint is the hull of its 8 projected corners and the hull's boundary is made
     // of the projections of the slab's 12 edges: one thread per (part, edge)
@@ -557,41 +627,30 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
     }
     lds_barrier();
     DM_STAMP(9);
-    // this part's rows: span minus every other part's span
-    int my_off = 0;
-#pragma unroll
-    for (int j = 0; j < kExclParts; ++j) my_off = j == part ? row_off[j] : my_off;
+    // this part's rows: span minus every other part's span; every row of U: hull of the spans
     for (int uz = tid; uz < w.h; uz += kScatterThreads) {
-      const int z = w.z0 + uz;
-      const int mine = sp[my_off + uz];
-      const int l = mine & 0xffff, r = mine >> 16;
-      int e0 = l, e1 = r;
+      int sl[kExclParts];
+      gather_spans(sl, w.z0 + uz, nparts, winl, sp, row_off);
+      ex[uz] = exclusive_interval(sl, part, nparts);
+    }
+    for (int ur = tid; ur < U.h; ur += kScatterThreads) {
+      int sl[kExclParts];
+      gather_spans(sl, U.z0 + ur, nparts, winl, sp, row_off);
+      int lo = 0x7fff, hi = 0;
 #pragma unroll
       for (int q = 0; q < kExclParts; ++q) {
-        if (q >= nparts || q == part) continue;                  // wave-uniform
-        const Window wq = {winl[4 * q], winl[4 * q + 1], winl[4 * q + 2], winl[4 * q + 3]};
-        const unsigned uq = (unsigned)(z - wq.z0);
-        if (wq.w <= 0 || uq >= (unsigned)wq.h) continue;
-        const int other = sp[row_off[q] + (int)uq];
-        const int lq = other & 0xffff, rq = other >> 16;
-        if (lq >= rq || rq <= e0 || lq >= e1) continue;
-        if (lq <= e0) e0 = rq < e1 ? rq : e1;  // covers the left end (or everything)
-        else e1 = lq;                          // covers the right end, or lies inside: keep the left piece
+        const int l = sl[q] & 0xffff, r = sl[q] >> 16;
+        if (l < r) { lo = l < lo ? l : lo; hi = r > hi ? r : hi; }
       }
-      if (e0 >= e1) e0 = e1 = 0;
-      own[2 * uz] = mine;
-      own[2 * uz + 1] = e0 | (e1 << 16);
-      if (chl == 0) {
-        RowSpan rs;
-        rs.l = (short)l; rs.r = (short)r; rs.e0 = (short)e0; rs.e1 = (short)e1;
-        a.g_rows[((size_t)b * a.mh + z) * nparts + part] = rs;
-      }
+      hull[ur] = hi > lo ? (lo | (hi << 16)) : 0;
     }
-    // (own[] is read after the scatter loop's barrier)
+    lds_barrier();
   };
-  bool tables_due = excl;
-
-
+  bool tables_due = EXCL;
+  if (EXCL && !has_px) {                       // no pixel can land: tables for the fill duty only
+    build_tables();
+    tables_due = false;
+  }
   const int q0 = pcx * a.parts.wp;
   int q1 = q0 + a.parts.wp; if (q1 > a.W) q1 = a.W;
   const int r0 = pry * a.parts.hp;
@@ -609,7 +668,7 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
   const unsigned dummy = (unsigned)area + (threadIdx.x & 63u);   // 64 scratch cells after the window
 
   {
-    for (int g = gx; g < nx; g += ntx) {       // one trip unless the strip is wider than the block
+    for (int g = gx; has_px && g < nx; g += ntx) {   // one trip unless the strip is wider than the block
       const int q = q0 + g * VEC;
       // ray slope of each column (maps.py:677); border columns are poisoned with
       // NaN, which flows through X to the cell coordinates (maps.py:48-70)
@@ -774,7 +833,7 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
         load_rows(za, va, r);
         DM_STAMP(2);
         if (tables_due) {                      // wave-uniform, first trip only
-          if (kFill) {
+          if (kFill && fill_ahead) {
 #pragma unroll
             for (int t = 0; t < kFillAhead; ++t) fill_step();
           }
@@ -839,26 +898,24 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
   DM_STAMP(5);
   const int pid = (b * a.oc + chl) * nparts + part;      // slabs are per channel group
   float* slab = a.slabs + (size_t)pid * a.slab_stride;
-  if (!excl) {
+  if (!EXCL) {
     for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
       *reinterpret_cast<float4*>(slab + i) = *reinterpret_cast<const float4*>(lds + i);
-#ifdef DM_STAMPS
     DM_STAMP(6);
-    if (threadIdx.x == 0 && a.stamps)
-      for (int k = 0; k < 12; ++k) a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 12 + k] = stamp[k];
-#endif
+    DM_STAMPS_OUT();
     return;
   }
-  // exclusive cells go to the map, the rest of the span to the slab (for k_window_merge);
-  // cells outside the span were never touched
+  // Exclusive cells go to the map, the rest of the span to the slab; cells outside the
+  // span were never touched.  The slab stores are write-through (sc0 sc1): the frame's
+  // last workgroup reads them from another XCD below.
   const int wg4 = w.w >> 2;
-  const float wg4_inv = 1.0f / (float)wg4;
+  const float wg4_inv = 1.0f / (float)(wg4 > 0 ? wg4 : 1);
   for (int i = threadIdx.x; i < (area >> 2); i += kScatterThreads) {
     int uz = (int)((float)i * wg4_inv);
     uz -= (uz * wg4 > i);
     uz += ((uz + 1) * wg4 <= i);
     const int x = w.x0 + ((i - uz * wg4) << 2);
-    const int s0 = own[2 * uz], s1 = own[2 * uz + 1];
+    const int s0 = sp[my_off + uz], s1 = ex[uz];
     if (x < (s0 & 0xffff) || x >= (s0 >> 16)) continue;
     const float4 v = *reinterpret_cast<const float4*>(lds + 4 * i);
     if (x >= (s1 & 0xffff) && x < (s1 >> 16)) {
@@ -869,14 +926,118 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
                           ((uint32_t)mask_of(v.w, a.fill) << 24);
       *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
     } else {
-      *reinterpret_cast<float4*>(slab + 4 * i) = v;
+      store_through(slab + 4 * i, v);
     }
   }
-#ifdef DM_STAMPS
   DM_STAMP(6);
-  if (threadIdx.x == 0 && a.stamps)
-    for (int k = 0; k < 12; ++k) a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 12 + k] = stamp[k];
-#endif
+  // ---- the frame's last workgroup merges the border -------------------------------
+  // Every workgroup of (frame, channel) takes a ticket once its stores have completed;
+  // the one whose ticket is the last knows that all border slabs are in memory.  The
+  // ticket word carries the launch's epoch, so it needs no initialisation.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();
+  if (threadIdx.x == 0) {
+    unsigned long long* tk = a.tickets + ((size_t)b * a.oc_total + ch);
+    unsigned long long old = __hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long nv;
+    do {
+      nv = (old >> 8) == a.epoch ? old + 1 : ((a.epoch << 8) | 1ull);
+    } while (!__hip_atomic_compare_exchange_strong(tk, &old, nv, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT));
+    flag[0] = (int)(nv & 0xffull) == nparts;
+    flag[1] = 0;
+  }
+  lds_barrier();
+  DM_STAMP(10);
+  if (!flag[0]) {
+    DM_STAMPS_OUT();
+    return;
+  }
+  // 1. one thread per row of U lists the float4 groups of the hull that no part owns
+  //    alone (the window cells are free now: they hold the list)
+  int* const list = reinterpret_cast<int*>(lds);
+  const int list_cap = a.tab_off - 64;
+  for (int ur = threadIdx.x; ur < U.h; ur += kScatterThreads) {
+    const int hb = hull[ur];
+    const int hlo = hb & 0xffff, hhi = hb >> 16;
+    if (hlo >= hhi) continue;
+    int sl[kExclParts], el[kExclParts];
+    gather_spans(sl, U.z0 + ur, nparts, winl, sp, row_off);
+#pragma unroll
+    for (int q = 0; q < kExclParts; ++q) el[q] = q < nparts ? exclusive_interval(sl, q, nparts) : 0;
+    // the gaps between the exclusive intervals: [hull lo, first e0), [e1, next e0), ...
+#pragma unroll
+    for (int k = 0; k <= kExclParts; ++k) {
+      int g0;
+      if (k == 0) {
+        g0 = hlo;
+      } else {
+        if (k > nparts) continue;
+        const int e0 = el[k - 1] & 0xffff, e1 = el[k - 1] >> 16;
+        if (e0 >= e1) continue;
+        g0 = e1;
+      }
+      int g1 = hhi;
+#pragma unroll
+      for (int q = 0; q < kExclParts; ++q) {
+        const int e0 = el[q] & 0xffff, e1 = el[q] >> 16;
+        if (e0 < e1 && e0 >= g0 && e0 < g1) g1 = e0;
+      }
+      const int n = (g1 - g0) >> 2;
+      if (n <= 0) continue;
+      const int at = atomicAdd(&flag[1], n);
+      for (int j = 0; j < n; ++j)
+        if (at + j < list_cap) list[at + j] = (ur << 16) | ((g0 >> 2) + j);
+    }
+  }
+  lds_barrier();
+  // 2. one listed group per thread and trip: max/min over the slabs of the parts whose
+  //    span covers it
+  const int nlist = flag[1] < list_cap ? flag[1] : list_cap;
+  const float* slab0 = a.slabs + (size_t)(b * a.oc + chl) * nparts * a.slab_stride;
+  for (int i = threadIdx.x; i < nlist; i += kScatterThreads) {
+    const int ent = list[i];
+    const int z = U.z0 + (ent >> 16), x = (ent & 0xffff) << 2;
+    int sl[kExclParts];
+    gather_spans(sl, z, nparts, winl, sp, row_off);
+    bool rd[kExclParts];
+    int4 v[kExclParts];
+#pragma unroll
+    for (int q = 0; q < kExclParts; ++q) {
+      rd[q] = false;
+      if (q < nparts) {
+        rd[q] = x >= (sl[q] & 0xffff) && x < (sl[q] >> 16);
+        const int off = rd[q] ? (z - winl[4 * q + 1]) * winl[4 * q + 2] + (x - winl[4 * q]) : 0;
+        const int* src = reinterpret_cast<const int*>(slab0 + (size_t)q * a.slab_stride + off);
+        v[q].x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[q].y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[q].z = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[q].w = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+#pragma unroll
+    for (int q = 0; q < kExclParts; ++q) {
+      if (q < nparts) {
+        const float sx = __int_as_float(v[q].x), sy = __int_as_float(v[q].y),
+                    sz = __int_as_float(v[q].z), sw = __int_as_float(v[q].w);
+        const float mx = IS_MAX ? fmaxf(acc.x, sx) : fminf(acc.x, sx);
+        const float my = IS_MAX ? fmaxf(acc.y, sy) : fminf(acc.y, sy);
+        const float mz = IS_MAX ? fmaxf(acc.z, sz) : fminf(acc.z, sz);
+        const float mw = IS_MAX ? fmaxf(acc.w, sw) : fminf(acc.w, sw);
+        acc.x = rd[q] ? mx : acc.x; acc.y = rd[q] ? my : acc.y;
+        acc.z = rd[q] ? mz : acc.z; acc.w = rd[q] ? mw : acc.w;
+      }
+    }
+    const size_t cell = map_base + (size_t)z * a.mw + x;
+    *reinterpret_cast<float4*>(a.out + cell) = acc;
+    const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+                        ((uint32_t)mask_of(acc.z, a.fill) << 16) |
+                        ((uint32_t)mask_of(acc.w, a.fill) << 24);
+    *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+  }
+  DM_STAMP(11);
+  DM_STAMPS_OUT();
 }
 
 struct MergeArgs {
@@ -886,7 +1047,6 @@ struct MergeArgs {
   float fill;
   const Win16* wins;          // (B, nparts)   written by k_window_scatter
   const Win16* unions;        // (B)
-  const RowSpan* rows;        // (B, mh, nparts), exclusive spans only
   const float* slabs;
   float* out;
   uint8_t* mask;
@@ -930,87 +1090,6 @@ k_window_merge(MergeArgs a) {
                       ((uint32_t)mask_of(acc.z, a.fill) << 16) |
                       ((uint32_t)mask_of(acc.w, a.fill) << 24);
   *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
-}
-
-// The same with exclusive spans: U minus the cells some part owns alone (already in the
-// map); a part's slab only holds its span.  The kernel is a chain of dependent loads
-// (row spans -> slabs -> store), so everything a thread may need is requested at once:
-// the union windows come with the kernel arguments, the spans of all parts of a map row
-// sit side by side, and the slab loads are unconditional (a thread that needs none reads
-// the slab's first cells).
-struct MergeUnions { Win16 u[kChunkFrames]; };
-
-constexpr int kMergeExclGroups = 2;   // float4 groups per thread
-
-template <bool IS_MAX>
-__global__ void __launch_bounds__(kMergeThreads)
-k_window_merge_excl(MergeArgs a, MergeUnions mu) {
-  const int fcl = blockIdx.y;
-  const int bl = fcl / a.oc, b = a.b0 + bl;
-  const int fc = fcl + a.b0 * a.oc;
-  const size_t fo = (size_t)b * a.oc_total + a.ch0 + (fcl - bl * a.oc);
-  const Window U = widen(mu.u[bl]);
-  const int ug4 = U.w >> 2;
-  const int total = ug4 * U.h;
-  const int first = blockIdx.x * (kMergeThreads * kMergeExclGroups) + threadIdx.x;
-  if (blockIdx.x * (kMergeThreads * kMergeExclGroups) >= total) return;
-  int zb[kMergeExclGroups], x[kMergeExclGroups];
-  bool live[kMergeExclGroups];
-  int2 rs[kMergeExclGroups][kExclParts];       // RowSpan as two words: l | r << 16, e0 | e1 << 16
-#pragma unroll
-  for (int j = 0; j < kMergeExclGroups; ++j) {
-    int i = first + j * kMergeThreads;
-    live[j] = i < total;
-    i = live[j] ? i : total - 1;
-    const int row = i / ug4;
-    zb[j] = U.z0 + row;
-    x[j] = U.x0 + ((i - row * ug4) << 2);
-    const int2* rowp = reinterpret_cast<const int2*>(a.rows + ((size_t)b * a.mh + zb[j]) * a.nparts);
-#pragma unroll
-    for (int p = 0; p < kExclParts; ++p) rs[j][p] = p < a.nparts ? rowp[p] : make_int2(0, 0);
-  }
-  bool rd[kMergeExclGroups][kExclParts];
-  float4 v[kMergeExclGroups][kExclParts];
-#pragma unroll
-  for (int p = 0; p < kExclParts; ++p) {
-    if (p < a.nparts) {                                          // wave-uniform
-      const Window w = widen(a.wins[(size_t)b * a.nparts + p]);
-      const float* slab = a.slabs + ((size_t)fc * a.nparts + p) * a.slab_stride;
-#pragma unroll
-      for (int j = 0; j < kMergeExclGroups; ++j) {
-        const unsigned uz = (unsigned)(zb[j] - w.z0);
-        const bool in = w.w > 0 && uz < (unsigned)w.h;           // else: the entry is stale
-        // a cell some part owns alone is already in the map
-        live[j] = live[j] && !(in && x[j] >= (rs[j][p].y & 0xffff) && x[j] < (rs[j][p].y >> 16));
-        rd[j][p] = in && x[j] >= (rs[j][p].x & 0xffff) && x[j] < (rs[j][p].x >> 16);
-        size_t off = (size_t)uz * w.w + (unsigned)(x[j] - w.x0);
-        off = rd[j][p] ? off : 0;
-        v[j][p] = *reinterpret_cast<const float4*>(slab + off);
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < kMergeExclGroups; ++j) {
-    if (!live[j]) continue;
-    float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
-#pragma unroll
-    for (int p = 0; p < kExclParts; ++p) {
-      if (p < a.nparts) {
-        const float4 m = make_float4(IS_MAX ? fmaxf(acc.x, v[j][p].x) : fminf(acc.x, v[j][p].x),
-                                     IS_MAX ? fmaxf(acc.y, v[j][p].y) : fminf(acc.y, v[j][p].y),
-                                     IS_MAX ? fmaxf(acc.z, v[j][p].z) : fminf(acc.z, v[j][p].z),
-                                     IS_MAX ? fmaxf(acc.w, v[j][p].w) : fminf(acc.w, v[j][p].w));
-        acc.x = rd[j][p] ? m.x : acc.x; acc.y = rd[j][p] ? m.y : acc.y;
-        acc.z = rd[j][p] ? m.z : acc.z; acc.w = rd[j][p] ? m.w : acc.w;
-      }
-    }
-    const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb[j] * a.mw + x[j];
-    *reinterpret_cast<float4*>(a.out + cell) = acc;
-    const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
-                        ((uint32_t)mask_of(acc.z, a.fill) << 16) |
-                        ((uint32_t)mask_of(acc.w, a.fill) << 24);
-    *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
-  }
 }
 
 // Batch fuse (north_star "projected+fused"): fused[c] = max/min over the frames
@@ -1205,16 +1284,15 @@ bool window_path_supported(const dm_params& p) {
 }
 
 // Device copies of the call's geometry, written by k_window_scatter for the kernels that
-// follow it: part windows, union windows, row spans.
-static size_t geometry_bytes(int B, int nparts, int rows) {
-  const int ep = nparts < kExclParts ? nparts : kExclParts;
+// follow it (part windows, union windows), and the tickets of its workgroups.
+static size_t geometry_bytes(int B, int nparts, int channels) {
   return align_up((size_t)B * nparts * sizeof(Win16), 256) + align_up((size_t)B * sizeof(Win16), 256) +
-         align_up((size_t)B * ep * rows * sizeof(RowSpan), 256);
+         align_up((size_t)B * channels * sizeof(unsigned long long), 256);
 }
 
-// LDS words behind the window of k_window_scatter (see there)
-static size_t excl_table_bytes(int nparts, int max_rows_sum, int max_h) {
-  return 4 * ((size_t)nparts * (48 + 4 + 1) + max_rows_sum + 2 * (size_t)max_h) + 16;
+// LDS words behind the window of k_window_scatter<..., EXCL> (see there)
+static size_t excl_table_bytes(int nparts, int max_rows_sum, int max_h, int max_uh) {
+  return 4 * ((size_t)nparts * (48 + 4 + 1) + max_rows_sum + (size_t)max_h + max_uh + 4) + 16;
 }
 
 static constexpr size_t kSlabBudget = (size_t)256 << 20;   // slab bytes per channel group
@@ -1233,7 +1311,7 @@ size_t window_workspace_bytes(const dm_params& p) {
   size_t slabs = one * oc;
   if (slabs > kSlabBudget) slabs = one > kSlabBudget ? one : kSlabBudget;
   const size_t height_mask = p.vc ? align_up((size_t)p.B * p.dc * p.mh * p.mw, 256) : 0;
-  return geometry_bytes(p.B, 128, p.mh) + slabs + height_mask;
+  return geometry_bytes(p.B, 128, (int)oc) + slabs + height_mask;
 }
 
 namespace {
@@ -1241,11 +1319,11 @@ namespace {
 struct Staged {                 // what run_window keeps between its passes
   Parts parts;
   int nparts, slab_stride, max_union;
-  int max_h, max_rows_sum;      // tallest window; most window rows of one frame
+  int max_h, max_uh, max_rows_sum;   // tallest part / union window; most window rows of one frame
   bool excl;                    // exclusive row spans
   Win16* g_wins;                // device copies (workspace head)
   Win16* g_unions;
-  RowSpan* g_rows;
+  unsigned long long* tickets;
   size_t geom_bytes;
   bool fast, fast_div;
   float res_inv, fx_inv, fy_inv;
@@ -1259,6 +1337,30 @@ inline hipError_t launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
                          const Args&... args) {
   hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
   return hipGetLastError();
+}
+
+using Kernel = void (*)(ScatterArgs, ScatterTables);
+
+template <bool EXCL>
+Kernel pick_kernel(bool is_max, bool fast, bool has_valid, bool has_value, bool vec4, bool lean) {
+#define DM_K(M, F, V, S) {k_window_scatter<M, F, V, S, 1, false, EXCL>, k_window_scatter<M, F, V, S, 4, false, EXCL>}
+  // [is_max][fast][has_valid][has_value][vec4]
+  static const Kernel table[2][2][2][2][2] = {
+      {{{DM_K(false, false, false, false), DM_K(false, false, false, true)},
+        {DM_K(false, false, true, false), DM_K(false, false, true, true)}},
+       {{DM_K(false, true, false, false), DM_K(false, true, false, true)},
+        {DM_K(false, true, true, false), DM_K(false, true, true, true)}}},
+      {{{DM_K(true, false, false, false), DM_K(true, false, false, true)},
+        {DM_K(true, false, true, false), DM_K(true, false, true, true)}},
+       {{DM_K(true, true, false, false), DM_K(true, true, false, true)},
+        {DM_K(true, true, true, false), DM_K(true, true, true, true)}}}};
+#undef DM_K
+  static const Kernel lean_table[2][2] = {
+      {k_window_scatter<false, true, false, false, 4, true, EXCL>,
+       k_window_scatter<false, true, false, true, 4, true, EXCL>},
+      {k_window_scatter<true, true, false, false, 4, true, EXCL>,
+       k_window_scatter<true, true, false, true, 4, true, EXCL>}};
+  return lean ? lean_table[is_max][has_value] : table[is_max][fast][has_valid][has_value][vec4];
 }
 
 // One pass: scatter `value` (or the heights when NULL) of channels [0, oc_total)
@@ -1293,42 +1395,26 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
   const bool vec4 = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(depth) % 16 == 0) &&
                     (!value || reinterpret_cast<uintptr_t>(value) % 16 == 0) &&
                     (st.parts.wp % 4 == 0);
-  // per-frame maps with few parts: exclusive row spans (see RowSpan)
+  // per-frame maps with few parts: exclusive row spans, no merge kernel
   const bool excl = st.excl && out != nullptr && !fused;
-  sa.excl = excl;
   sa.tab_off = (int)align_up((size_t)st.slab_stride, 4) + 64;
-  sa.max_rows_sum = st.max_rows_sum; sa.max_h = st.max_h;
-  sa.g_wins = st.g_wins; sa.g_unions = st.g_unions; sa.g_rows = st.g_rows;
+  sa.max_rows_sum = st.max_rows_sum; sa.max_h = st.max_h; sa.max_uh = st.max_uh;
+  sa.g_wins = st.g_wins; sa.g_unions = st.g_unions; sa.tickets = st.tickets;
+  {   // tickets carry the launch's epoch: unique per process run and launch
+    static std::atomic<unsigned long long> epoch_counter{
+        ((unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0xffffffffffull) << 8};
+    sa.epoch = (epoch_counter.fetch_add(1) + 1) & 0x00ffffffffffffffull;
+  }
 #ifdef DM_STAMPS
   sa.stamps = g_stamp_buffer;
 #endif
   size_t lds_bytes = align_up((size_t)st.slab_stride * 4, 16) + 64 * 4;   // + dummy cells
-  if (excl) lds_bytes += excl_table_bytes(st.nparts, st.max_rows_sum, st.max_h);
-  using Kernel = void (*)(ScatterArgs, ScatterTables);
-#define DM_K(M, F, V, S) {k_window_scatter<M, F, V, S, 1>, k_window_scatter<M, F, V, S, 4>}
-  // [is_max][fast][has_valid][has_value][vec4]
-  static const Kernel table[2][2][2][2][2] = {
-      {{{DM_K(false, false, false, false), DM_K(false, false, false, true)},
-        {DM_K(false, false, true, false), DM_K(false, false, true, true)}},
-       {{DM_K(false, true, false, false), DM_K(false, true, false, true)},
-        {DM_K(false, true, true, false), DM_K(false, true, true, true)}}},
-      {{{DM_K(true, false, false, false), DM_K(true, false, false, true)},
-        {DM_K(true, false, true, false), DM_K(true, false, true, true)}},
-       {{DM_K(true, true, false, false), DM_K(true, true, false, true)},
-        {DM_K(true, true, true, false), DM_K(true, true, true, true)}}}};
-#undef DM_K
-  Kernel kfn = table[is_max][st.fast][has_valid][has_value][vec4];
+  if (excl) lds_bytes += excl_table_bytes(st.nparts, st.max_rows_sum, st.max_h, st.max_uh);
   // lean variant: both depth bounds finite, no height truncation, no border, no valid map
   const bool lean = st.fast && vec4 && !has_valid && p.has_dmin && p.has_dmax &&
                     isfinite(p.dmin) && isfinite(p.dmax) && !p.has_hmax && p.clip_border <= 0;
-  if (lean) {
-    static const Kernel lean_table[2][2] = {
-        {k_window_scatter<false, true, false, false, 4, true>,
-         k_window_scatter<false, true, false, true, 4, true>},
-        {k_window_scatter<true, true, false, false, 4, true>,
-         k_window_scatter<true, true, false, true, 4, true>}};
-    kfn = lean_table[is_max][has_value];
-  }
+  const Kernel kfn = excl ? pick_kernel<true>(is_max, st.fast, has_valid, has_value, vec4, lean)
+                          : pick_kernel<false>(is_max, st.fast, has_valid, has_value, vec4, lean);
   hipError_t e = hipSuccess;
   {   // raise the dynamic-LDS limit once per kernel variant and device
     static thread_local const void* done[64][8] = {};
@@ -1374,24 +1460,15 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
       sa.b0 = b0;
       e = launch(kfn, dim3(st.nparts, oc, nb), dim3(kScatterThreads), lds_bytes, s, sa, tab);
       if (e != hipSuccess) return e;
-      if (!fused && st.max_union > 0) {
+      if (!fused && !excl && st.max_union > 0) {
         MergeArgs ma;
         ma.b0 = b0; ma.oc = oc; ma.ch0 = ch0; ma.oc_total = oc_total; ma.mh = p.mh; ma.mw = p.mw;
         ma.nparts = st.nparts; ma.slab_stride = st.slab_stride; ma.fill = fill;
-        ma.wins = st.g_wins; ma.unions = st.g_unions; ma.rows = st.g_rows;
+        ma.wins = st.g_wins; ma.unions = st.g_unions;
         ma.slabs = slabs; ma.out = out; ma.mask = mask;
         const dim3 g((unsigned)((st.max_union / 4 + kMergeThreads - 1) / kMergeThreads), nb * oc);
-        if (excl) {
-          static thread_local MergeUnions mu;
-          memcpy(mu.u, tab.unions, (size_t)nb * sizeof(Win16));
-          const int per_block = kMergeThreads * kMergeExclGroups;
-          const dim3 g((unsigned)((st.max_union / 4 + per_block - 1) / per_block), nb * oc);
-          e = is_max ? launch(k_window_merge_excl<true>, g, dim3(kMergeThreads), 0, s, ma, mu)
-                     : launch(k_window_merge_excl<false>, g, dim3(kMergeThreads), 0, s, ma, mu);
-        } else {
-          e = is_max ? launch(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma)
-                     : launch(k_window_merge<false>, g, dim3(kMergeThreads), 0, s, ma);
-        }
+        e = is_max ? launch(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma)
+                   : launch(k_window_merge<false>, g, dim3(kMergeThreads), 0, s, ma);
         if (e != hipSuccess) return e;
       }
     }
@@ -1427,7 +1504,7 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
     if (st.nparts > 128) return hipErrorNotSupported;
     wins.resize((size_t)p.B * (st.nparts + 1));
     Win16* unions = wins.data() + (size_t)p.B * st.nparts;
-    max_area = 0; st.max_union = 0; st.max_h = 0; st.max_rows_sum = 0;
+    max_area = 0; st.max_union = 0; st.max_h = 0; st.max_uh = 0; st.max_rows_sum = 0;
     for (int b = 0; b < p.B; ++b) {
       int ux0 = p.mw, ux1 = 0, uz0 = p.mh, uz1 = 0, rows_sum = 0;
       const FrameAffine fa = frame_affine(p, frames_host[b]);
@@ -1451,16 +1528,20 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
       const Window U = ux1 > ux0 ? Window{ux0, uz0, ux1 - ux0, uz1 - uz0} : Window{0, 0, 0, 0};
       unions[b] = narrow(U);
       if (U.w * U.h > st.max_union) st.max_union = U.w * U.h;
+      if (U.h > st.max_uh) st.max_uh = U.h;
       if (rows_sum > st.max_rows_sum) st.max_rows_sum = rows_sum;
     }
-    if ((size_t)max_area * 4 + 64 * 4 + 16 <= (size_t)kMaxLdsBytes) break;
+    if (align_up((size_t)max_area, 32) * 4 + 64 * 4 <= (size_t)kMaxLdsBytes) break;
     // a window that is the whole map cannot shrink by splitting the image
     if (!p.has_dmin || !p.has_dmax || st.nparts >= 64 ||
         st.parts.pc * st.parts.pr == choose_parts(p, min_parts * 2).pc * choose_parts(p, min_parts * 2).pr)
       return hipErrorNotSupported;
   }
-  st.slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 4);
+  // (whole 128-byte lines per slab: a line is then written and read through by the
+  // workgroups of ONE part only)
+  st.slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 32);
   if (st.max_h < 1) st.max_h = 1;
+  if (st.max_uh < 1) st.max_uh = 1;
   // exclusive row spans: a few parts per frame, a proper frustum slab, tables that fit
   // (work in progress: off unless DM_EXCL is set -- the per-workgroup table phase still
   // costs more than the smaller merge gains)
@@ -1468,8 +1549,9 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
   st.excl = !no_excl && st.nparts > 1 && st.nparts <= kExclParts && p.has_dmin && p.has_dmax &&
             p.dmin >= 0.0f && p.dmax >= p.dmin && isfinite(p.dmax) &&
             align_up((size_t)st.slab_stride * 4, 16) + 64 * 4 +
-                    excl_table_bytes(st.nparts, st.max_rows_sum, st.max_h) <= (size_t)kMaxLdsBytes;
-  st.geom_bytes = geometry_bytes(p.B, st.nparts, st.excl ? p.mh : 0);
+                    excl_table_bytes(st.nparts, st.max_rows_sum, st.max_h, st.max_uh) <=
+                (size_t)kMaxLdsBytes;
+  st.geom_bytes = geometry_bytes(p.B, st.nparts, p.vc ? p.vc : p.dc);
   if (ws_bytes < st.geom_bytes + (size_t)p.B * st.nparts * st.slab_stride * 4)
     return hipErrorNotSupported;
   slab_bytes = ws_bytes - st.geom_bytes;
@@ -1479,7 +1561,7 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
     base += align_up((size_t)p.B * st.nparts * sizeof(Win16), 256);
     st.g_unions = reinterpret_cast<Win16*>(base);
     base += align_up((size_t)p.B * sizeof(Win16), 256);
-    st.g_rows = reinterpret_cast<RowSpan*>(base);
+    st.tickets = reinterpret_cast<unsigned long long*>(base);
   }
 
   recs.resize(p.B);

@@ -23,9 +23,14 @@ torch.cuda.synchronize()
 raw = buf.cpu().numpy().reshape(-1, 12)
 raw = raw[raw[:, 0] != 0]
 if raw[:, 7].any():     # exclusive spans: stamps 7..9 sit between 2 and 3
-  st = raw[:, [0, 1, 2, 7, 8, 9, 3, 4, 5, 6]]
-  names = ["lds init", "first loads", "fill-ahead", "edges + barrier", "spans + barrier", "own rows",
-           "scatter loop", "fill rest + barrier", "flush"]
+  st = raw[:, [0, 1, 2, 7, 8, 9, 3, 4, 5, 6, 10]]
+  names = ["lds init", "first loads", "fill-ahead", "edges + barrier", "spans + barrier", "own rows + hull",
+           "scatter loop", "fill rest + barrier", "flush", "drain + ticket"]
+  last = raw[raw[:, 11] != 0]
+  if len(last):
+    d11 = (last[:, 11] - last[:, 10]) * 0.01
+    print("last arrivers: %d   border merge us median %.2f max %.2f" % (len(last), np.median(d11), d11.max()))
+    print("kernel span incl. border merge us: %.2f" % ((raw[:, [10, 11]].max() - raw[:, 0].min()) * 0.01))
 else:
   st = raw[:, :7]
   names = ["lds init", "first loads", "(tables)", "scatter loop", "fill rest + barrier", "flush"]

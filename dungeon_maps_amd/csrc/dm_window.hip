@@ -23,8 +23,6 @@
 #include <math.h>
 #include <string.h>
 
-#include <atomic>
-#include <chrono>
 #include <type_traits>
 #include <vector>
 
@@ -37,7 +35,6 @@ namespace {
 constexpr int kScatterThreads = 1024;
 constexpr int kRowsInFlight = 4;
 constexpr int kFillPerHalf = 2;       // fill steps per pipeline half-iteration
-constexpr int kFillAhead = 4;         // fill steps issued before the span tables are built
 constexpr int kMaxLdsBytes = 160 * 1024;
 
 
@@ -51,9 +48,11 @@ struct Window {
   int x0, z0, w, h;
 };
 
-// Tables the kernels read travel in the kernel-argument segment (one launch per chunk
-// of frames): no staging copy, no extra stream operation, and every access is a
-// scalar load of wave-uniform data.
+// Tables of the scatter kernel, one per chunk of frames (= launch), staged into the
+// workspace by ONE hipMemcpyAsync per call.  Every access is a scalar load of
+// wave-uniform data.  (Passing them as kernel arguments instead saves the copy but
+// costs as much at the head of the kernel, and the runtime's kernel-argument pool then
+// stalls the host every few dozen launches.)
 struct FrameRec {        // what the scatter kernel reads of a dm_frame
   float p[9];            // pitch rotation (row-major)
   float cam_h;
@@ -65,22 +64,15 @@ struct Win16 { short x0, z0, w, h; };     // map sides <= 32767
 
 constexpr int kChunkFrames = 64;          // frames per scatter launch
 constexpr int kChunkWins = 512;           // part windows per scatter launch
-constexpr int kExclParts = 8;             // most parts per frame with exclusive row spans
+constexpr int kFewParts = 8;              // window-table row stride for frames of up to 8 parts
 
 struct ScatterTables {
   FrameRec frames[kChunkFrames];
-  // (frame, part): row stride kExclParts when a frame has at most kExclParts parts (a
+  // (frame, part): row stride kFewParts when a frame has at most kFewParts parts (a
   // workgroup then finds its window without first loading the part count), else nparts
   Win16 wins[kChunkWins];
   Win16 unions[kChunkFrames];             // bounding box of a frame's windows, x aligned to 4
 };
-
-// Exclusive row spans (k_window_scatter<..., EXCL>): row z of a part's window can only be
-// reached in cells [l, r) (its "span": the frustum slab of the part is convex), and the
-// piece [e0, e1) of the span that lies in no other part's span belongs to this part alone
-// -- its workgroup writes it to the map itself.  The rest of the hull of the spans of a
-// row (the "border") is merged by the frame's last workgroup.  Absolute map columns,
-// multiples of 4, packed as lo | hi << 16.
 
 __device__ __host__ inline Window widen(Win16 w) { return Window{w.x0, w.z0, w.w, w.h}; }
 __host__ inline Win16 narrow(Window w) {
@@ -276,13 +268,8 @@ struct ScatterArgs {
   long long* stamps;
 #endif
   int b0;                     // first frame of this launch's chunk
-  int tab_off;                // LDS word offset of the span tables (behind window + dummy cells)
-  int max_rows_sum;           // most window rows of one frame, all parts together
-  int max_h, max_uh;          // tallest part window / union window
   Win16* g_wins;              // (B, nparts)  device copies for the kernels that follow
   Win16* g_unions;            // (B)
-  unsigned long long* tickets;  // (B, oc_total), EXCL only: epoch << 8 | workgroups done
-  unsigned long long epoch;   // unique per launch
   const float* depth;
   const float* value;         // (B, oc_total, H, W) or NULL: project the heights
   const uint8_t* valid;
@@ -315,46 +302,6 @@ __device__ inline void lds_reduce(float* cell, float v) {
   else __hip_atomic_fetch_min(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Span of map row z in every part of the frame (0: none).
-__device__ __forceinline__ void gather_spans(int (&sl)[kExclParts], int z, int nparts, const int* winl,
-                                    const int* sp, const int (&row_off)[kExclParts + 1]) {
-#pragma unroll
-  for (int q = 0; q < kExclParts; ++q) {
-    sl[q] = 0;
-    if (q < nparts) {                                              // wave-uniform
-      const int z0 = winl[4 * q + 1], ww = winl[4 * q + 2], wh = winl[4 * q + 3];
-      const unsigned uq = (unsigned)(z - z0);
-      if (ww > 0 && uq < (unsigned)wh) sl[q] = sp[row_off[q] + (int)uq];
-    }
-  }
-}
-
-// The piece of part p's span that no other part's span touches (0: none).  Every
-// workgroup of a frame evaluates this on the same spans, so they agree on the owners.
-__device__ __forceinline__ int exclusive_interval(const int (&sl)[kExclParts], int p, int nparts) {
-  int mine = 0;
-#pragma unroll
-  for (int q = 0; q < kExclParts; ++q) mine = q == p ? sl[q] : mine;
-  int e0 = mine & 0xffff, e1 = mine >> 16;
-#pragma unroll
-  for (int q = 0; q < kExclParts; ++q) {
-    const int lq = sl[q] & 0xffff, rq = sl[q] >> 16;
-    const bool cut = q < nparts && q != p && lq < rq && rq > e0 && lq < e1;
-    const bool left = lq <= e0;                // covers the left end (or everything)
-    const int ne0 = rq < e1 ? rq : e1;
-    e0 = cut && left ? ne0 : e0;
-    e1 = cut && !left ? lq : e1;               // covers the right end, or lies inside: keep the left piece
-  }
-  return e0 < e1 ? (e0 | (e1 << 16)) : 0;
-}
-
-// 16-byte store that is written through to memory (another XCD reads it in this launch)
-__device__ inline void store_through(float* p, float4 v) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const f4 d = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(d) : "memory");
-}
-
 // FAST: every frame's rotations have the exact 0/1 pattern of rotate([1,0,0],.)
 //       and rotate([0,1,0],.) AND the Markstein reciprocals are usable
 //       (dm_pixel.hpp).  !FAST: full FMA chains and IEEE division.
@@ -364,11 +311,10 @@ __device__ inline void store_through(float* p, float4 v) {
 //       (no border clip, no valid map): a non-finite or out-of-range pixel is then
 //       already rejected by the two depth compares, so the ordered-compare and the
 //       height compare are dropped.  (Pipeline-tail rows are poisoned through z.)
-// EXCL: exclusive row spans (see Win16) -- the kernel then also writes the cells of the
-//       union window and no merge kernel follows.
-template <bool IS_MAX, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC, bool LEAN, bool EXCL>
+template <bool IS_MAX, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC, bool LEAN>
 __global__ void __launch_bounds__(kScatterThreads)
-k_window_scatter(ScatterArgs a, ScatterTables t) {
+k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
+  const ScatterTables& t = *tables;            // this launch's chunk of frames
   extern __shared__ float lds[];
   const int part = blockIdx.x;                 // pr-major, pc-minor
   const int chl = blockIdx.y;                  // channel within this launch's group
@@ -377,9 +323,9 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
   const int dch = a.dc == 1 ? 0 : ch;          // depth / cell-index channel (utils.py:475-477)
   const int nparts = a.parts.pc * a.parts.pr;
   const int pcx = part % a.parts.pc, pry = part / a.parts.pc;
-  const Win16 w_few = t.wins[bl * kExclParts + (part & (kExclParts - 1))];
-  const int win_stride = nparts <= kExclParts ? kExclParts : nparts;
-  const Window w = nparts <= kExclParts ? widen(w_few) : widen(t.wins[bl * nparts + part]);
+  const Win16 w_few = t.wins[bl * kFewParts + (part & (kFewParts - 1))];
+  const int win_stride = nparts <= kFewParts ? kFewParts : nparts;
+  const Window w = nparts <= kFewParts ? widen(w_few) : widen(t.wins[bl * nparts + part]);
   const int area = w.w * w.h;                  // 0: nothing of this part can land
 #ifdef DM_STAMPS
   long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -395,53 +341,29 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
   }
 
   // Fill duty, interleaved with the scatter so that these stores ride under the
-  // projection: map rows row_first, row_first + row_step, ... of (b, ch), minus what other
-  // code writes -- the frame's union window U (k_window_merge), or with exclusive spans
-  // the hull [min l, max r) of the parts' spans of each row.  One float4 (+ 4 mask bytes)
-  // per thread and step, ALWAYS executed: an element that needs no store is redirected to
-  // `alt`, a cell of this workgroup's share that does get the fill value, so the stores
-  // are unconditional straight-line code and the compiler can count the pipelined loop's
-  // waits exactly.
+  // projection: map rows part, part + nparts, ... of (b, ch), minus the frame's union
+  // window U (k_window_merge writes U).  One float4 (+ 4 mask bytes) per thread and step,
+  // ALWAYS executed: an element that needs no store (inside U, or past the end) is
+  // redirected to `alt`, a cell of this workgroup's share that does get the fill value,
+  // so the stores are unconditional straight-line code and the compiler can count the
+  // pipelined loop's waits exactly.
   const Window U = widen(t.unions[bl]);
   const int g4 = a.mw >> 2;
-  const int row_first = part, row_step = nparts;
   const int fill_rows = (a.mh - part + nparts - 1) / nparts;
   const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
   // where redirected stores go: a cell of this share outside U if there is one (it gets
-  // the fill value anyway), else the share's first cell.  That one lies inside U: fine
-  // when k_window_merge, which runs after this kernel, rewrites all of U; with exclusive
-  // spans other workgroups store into U concurrently, so the fill is then done with
-  // conditional stores after the scatter instead (alt_safe == false; only when U spans
-  // the whole map width and this share's first and last rows).
-  int alt_cell = row_first * a.mw;
-  bool alt_safe = true;
+  // the fill value anyway), else the share's first cell (inside U: k_window_merge,
+  // which runs after this kernel, overwrites it)
+  int alt_cell = part * a.mw;
   if (fill_rows > 0 && U.w > 0 && U.h > 0 && U.x0 == 0) {
-    const int last_row = row_first + (fill_rows - 1) * row_step;
-    if (U.x0 + U.w < a.mw) alt_cell = row_first * a.mw + U.x0 + U.w;             // right of U
-    else if (last_row >= U.z0 + U.h) alt_cell = last_row * a.mw;                 // below U
-    else alt_safe = row_first < U.z0;                                            // above U
+    const int last_row = part + (fill_rows - 1) * nparts;
+    if (U.x0 + U.w < a.mw) alt_cell = part * a.mw + U.x0 + U.w;                  // right of U
+    else if (part >= U.z0 && last_row >= U.z0 + U.h) alt_cell = last_row * a.mw; // below U
   }
-  const bool cond_fill = EXCL && !alt_safe;                                     // wave-uniform
   const bool do_fill = a.out != nullptr && fill_rows > 0;                       // wave-uniform
   const int fill_total = do_fill ? fill_rows * g4 : 0;
   const int fill_steps = (fill_total + kScatterThreads - 1) / kScatterThreads;
   const float g4_inv = 1.0f / (float)g4;
-  // LDS behind the window and its dummy cells (EXCL only):
-  //   edges  (nparts, 12, 4) float   lower end x, z, upper end z, dx/dz of the slab's edges
-  //   winl   (nparts, 4)     int     the frame's part windows x0, z0, w, h
-  //   bad    (nparts)        int     a corner of the part is not finite: no spans
-  //   sp     (rows of all parts of the frame) int   span l | r << 16
-  //   ex     (w.h)           int     exclusive interval e0 | e1 << 16 of this part's rows
-  //   hull   (U.h)           int     min l | max r << 16 over the parts, per row of U
-  //   flag   (4)             int     last-arriver flag, border list length
-  int* const tabs = reinterpret_cast<int*>(lds) + a.tab_off;
-  float* const edges = reinterpret_cast<float*>(tabs);
-  int* const winl = tabs + nparts * 48;
-  int* const bad = winl + nparts * 4;
-  int* const sp = bad + nparts;
-  int* const ex = sp + a.max_rows_sum;
-  int* const hull = ex + a.max_h;
-  int* const flag = hull + a.max_uh;
   int fs = 0;
   auto fill_step = [&]() {
     const int i = fs * kScatterThreads + (int)threadIdx.x;     // < 2^24
@@ -450,50 +372,22 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
     k -= (k * g4 > i);
     k += ((k + 1) * g4 <= i);
     const int g = i - k * g4;
-    const int r = row_first + k * row_step, x = g << 2;
-    const bool in_rows = (unsigned)(r - U.z0) < (unsigned)U.h;
-    int lo = U.x0, hi = U.x0 + U.w;
-    if (EXCL) {
-      const int hb = hull[in_rows ? r - U.z0 : 0];
-      lo = hb & 0xffff; hi = hb >> 16;
-    }
-    const bool skip = i >= fill_total || (in_rows && x >= lo && x < hi);
+    const int r = part + k * nparts, x = g << 2;
+    const bool skip = i >= fill_total || ((unsigned)(r - U.z0) < (unsigned)U.h &&
+                                          (unsigned)(x - U.x0) < (unsigned)U.w);
     int cell = r * a.mw + x;
     asm("" : "+v"(cell));                      // keep the select a v_cndmask
     cell = skip ? alt_cell : cell;
     *reinterpret_cast<float4*>(a.out + map_base + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
     *reinterpret_cast<uint32_t*>(a.mask + map_base + cell) = 0u;
   };
-  auto fill_rest = [&]() {
-    if (!cond_fill) {
-      while (fs < fill_steps) fill_step();
-      return;
-    }
-    for (int i = fs * kScatterThreads + (int)threadIdx.x; i < fill_total; i += kScatterThreads) {
-      const int k = i / g4, g = i - k * g4;
-      const int r = row_first + k * row_step, x = g << 2;
-      if ((unsigned)(r - U.z0) < (unsigned)U.h) {
-        const int hb = hull[r - U.z0];
-        if (x >= (hb & 0xffff) && x < (hb >> 16)) continue;
-      }
-      const size_t cell = map_base + (size_t)r * a.mw + x;
-      *reinterpret_cast<float4*>(a.out + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
-      *reinterpret_cast<uint32_t*>(a.mask + cell) = 0u;
-    }
-    fs = fill_steps;
-  };
-  // fill steps that may run before the hull table exists: rows of this share above U
-  int rows_above = (U.z0 - row_first + row_step - 1) / row_step;
-  rows_above = U.h > 0 ? (rows_above < 0 ? 0 : (rows_above > fill_rows ? fill_rows : rows_above)) : fill_rows;
-  const bool fill_ahead = EXCL && do_fill && !cond_fill && rows_above * g4 >= kFillAhead * kScatterThreads;
   // device copies of the geometry for the kernels that follow
   if (chl == 0 && threadIdx.x == 0) {
     a.g_wins[(size_t)b * nparts + part] = t.wins[bl * win_stride + part];
     if (part == 0) a.g_unions[b] = t.unions[bl];
   }
-  const bool has_px = area > 0;                // wave-uniform
-  if (!EXCL && !has_px) {
-    fill_rest();
+  if (area == 0) {                             // wave-uniform
+    while (fs < fill_steps) fill_step();
     return;
   }
   for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
@@ -507,150 +401,8 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
   const float cam_h = f.cam_h, tx = f.tx, tz = f.tz;
   const float wo = f.wo, ho = f.ho;
   const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
-
-  // ---- exclusive row spans -------------------------------------------------------
-  int row_off[kExclParts + 1];                 // first sp entry of each part (wave-uniform)
-  int my_off = 0;
-  if (EXCL) {
-    row_off[0] = 0;
-#pragma unroll
-    for (int q = 0; q < kExclParts; ++q) {
-      int hq = 0;
-      if (q < nparts) {
-        const Win16 wq = t.wins[bl * kExclParts + q];
-        hq = wq.w > 0 ? wq.h : 0;
-        if (threadIdx.x == 0) {
-          winl[4 * q] = wq.x0; winl[4 * q + 1] = wq.z0; winl[4 * q + 2] = wq.w; winl[4 * q + 3] = wq.h;
-          bad[q] = 0;
-        }
-      }
-      row_off[q + 1] = row_off[q] + hq;
-      my_off = q == part ? row_off[q] : my_off;
-    }
-  }
   lds_barrier();
   DM_STAMP(1);
-  // (run by every thread once its first depth rows are requested: the table arithmetic
-  // hides the latency of those loads)
-  auto build_tables = [&]() __attribute__((always_inline)) {
-    // the frustum slab of a part (its pixel rectangle x [dmin, dmax]) is convex, so its
-    // footprint is the hull of its 8 projected corners and the hull's boundary is made
-    // of the projections of the slab's 12 edges: one thread per (part, edge)
-    // (the asm keeps this arithmetic under its guards: hoisted in front of the pixel
-    // loop it would be executed by every wave)
-    int tid = (int)threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    if (tid < nparts * 12) {
-      const int q = tid / 12, e = tid - q * 12;
-      // corner index: bit 0 = depth, bit 1 = image row, bit 2 = image column
-      const int axis = e >> 2, k = e & 3;      // the bit that differs along the edge
-      const int lowmask = (1 << axis) - 1;
-      const int ia = ((k & ~lowmask) << 1) | (k & lowmask), ib = ia | (1 << axis);
-      const int qc = q % a.parts.pc, qr = q / a.parts.pc;
-      const int cq0 = qc * a.parts.wp, cr0 = qr * a.parts.hp;
-      int cq1 = cq0 + a.parts.wp; if (cq1 > a.W) cq1 = a.W;
-      int cr1 = cr0 + a.parts.hp; if (cr1 > a.H) cr1 = a.H;
-      float px[2], pz[2];
-      const float rfx = __builtin_amdgcn_rcpf(a.fx), rfy = __builtin_amdgcn_rcpf(a.fy),
-                  rres = __builtin_amdgcn_rcpf(a.res);
-      auto corner = [&](int ci, float& cxo, float& czo) {
-        const float zz = (ci & 1) ? a.dmax : a.dmin;
-        float yr = (float)((ci & 2) ? cr1 - 1 : cr0);
-        yr = a.flip_h ? a.Hm1 - yr : yr;
-        // (reciprocal multiplies: the spans carry 2 cells of slack)
-        const float ax = ((float)((ci & 4) ? cq1 - 1 : cq0) - a.cx) * rfx;
-        const float ay = (yr - a.cy) * rfy;
-        const float X = ax * zz, Y = ay * zz;
-        const float x1 = __builtin_fmaf(zz, p6, __builtin_fmaf(Y, p3, X * p0));
-        const float h1 = __builtin_fmaf(zz, p7, __builtin_fmaf(Y, p4, X * p1)) + cam_h;
-        const float z1 = __builtin_fmaf(zz, p8, __builtin_fmaf(Y, p5, X * p2));
-        const float x2 = __builtin_fmaf(z1, y6, __builtin_fmaf(h1, y3, x1 * y0)) + tx;
-        const float z2 = __builtin_fmaf(z1, y8, __builtin_fmaf(h1, y5, x1 * y2r)) + tz;
-        const float xf = x2 * rres + wo;
-        const float zf = __builtin_fmaf(z2 * rres + ho, flip_s, flip_c);
-        cxo = xf + 0.5f; czo = zf + 0.5f;
-      };
-      corner(ia, px[0], pz[0]);
-      corner(ib, px[1], pz[1]);
-      // edge record: x and z of the lower end, z of the upper end, dx/dz.  An edge along
-      // a map row is dropped (empty z range): its ends are ends of other edges too.
-      const bool up = pz[1] >= pz[0];
-      const float xa = up ? px[0] : px[1], za = up ? pz[0] : pz[1], zb = up ? pz[1] : pz[0];
-      const float dz = zb - za;
-      const bool flat = !(dz > 1e-6f);
-      float* ed = edges + tid * 4;
-      ed[0] = xa; ed[1] = flat ? 3e38f : za; ed[2] = flat ? -3e38f : zb;
-      ed[3] = flat ? 0.0f : ((up ? px[1] : px[0]) - xa) * __builtin_amdgcn_rcpf(dz);
-      const float lim = 1e6f;
-      if (!(fabsf(px[0]) < lim && fabsf(px[1]) < lim && fabsf(pz[0]) < lim && fabsf(pz[1]) < lim))
-        atomicOr(&bad[q], 1);
-    }
-    lds_barrier();
-    DM_STAMP(8);
-    // span of every row of every part's window
-    for (int idx = tid; idx < row_off[kExclParts]; idx += kScatterThreads) {
-      int q = 0, first = 0;                    // (static indices: row_off stays in registers)
-#pragma unroll
-      for (int j = 1; j < kExclParts; ++j) {
-        const bool past = row_off[j] <= idx;
-        q += past;
-        first = past ? row_off[j] : first;
-      }
-      const Window wq = {winl[4 * q], winl[4 * q + 1], winl[4 * q + 2], winl[4 * q + 3]};
-      const int z = wq.z0 + (idx - first);
-      int l = wq.x0, r = wq.x0 + wq.w;         // no usable corners: the whole window row
-      if (!bad[q]) {
-        // a pixel of row z has its centre coordinate in [z, z + 1): one row of margin
-        const float blo = (float)(z - 1), bhi = (float)(z + 2);
-        float lo = INFINITY, hi = -INFINITY;
-        const float4* ed = reinterpret_cast<const float4*>(edges + q * 48);
-#pragma unroll 4                       // (fully unrolled it spills: the first depth rows are live)
-        for (int e = 0; e < 12; ++e) {
-          const float4 g = ed[e];                                 // xa, za, zb, slope
-          const float c0 = fmaxf(blo, g.y), c1 = fminf(bhi, g.z); // the edge inside the band
-          const float xs = __builtin_fmaf(c0 - g.y, g.w, g.x), xe = __builtin_fmaf(c1 - g.y, g.w, g.x);
-          const bool hit = c0 <= c1;
-          lo = hit ? fminf(lo, fminf(xs, xe)) : lo;
-          hi = hit ? fmaxf(hi, fmaxf(xs, xe)) : hi;
-        }
-        if (lo <= hi) {
-          // 2 cells of slack for the float32 rounding of the pixel arithmetic
-          int l2 = floor_to_int(lo) - 2, r2 = floor_to_int(hi) + 3;
-          l2 = l2 < l ? l : l2; r2 = r2 > r ? r : r2;
-          l = l2 & ~3; r = (r2 + 3) & ~3;      // window sides are multiples of 4
-          if (l >= r) l = r = 0;
-        } else {
-          l = r = 0;
-        }
-      }
-      sp[idx] = l | (r << 16);
-    }
-    lds_barrier();
-    DM_STAMP(9);
-    // this part's rows: span minus every other part's span; every row of U: hull of the spans
-    for (int uz = tid; uz < w.h; uz += kScatterThreads) {
-      int sl[kExclParts];
-      gather_spans(sl, w.z0 + uz, nparts, winl, sp, row_off);
-      ex[uz] = exclusive_interval(sl, part, nparts);
-    }
-    for (int ur = tid; ur < U.h; ur += kScatterThreads) {
-      int sl[kExclParts];
-      gather_spans(sl, U.z0 + ur, nparts, winl, sp, row_off);
-      int lo = 0x7fff, hi = 0;
-#pragma unroll
-      for (int q = 0; q < kExclParts; ++q) {
-        const int l = sl[q] & 0xffff, r = sl[q] >> 16;
-        if (l < r) { lo = l < lo ? l : lo; hi = r > hi ? r : hi; }
-      }
-      hull[ur] = hi > lo ? (lo | (hi << 16)) : 0;
-    }
-    lds_barrier();
-  };
-  bool tables_due = EXCL;
-  if (EXCL && !has_px) {                       // no pixel can land: tables for the fill duty only
-    build_tables();
-    tables_due = false;
-  }
   const int q0 = pcx * a.parts.wp;
   int q1 = q0 + a.parts.wp; if (q1 > a.W) q1 = a.W;
   const int r0 = pry * a.parts.hp;
@@ -668,7 +420,7 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
   const unsigned dummy = (unsigned)area + (threadIdx.x & 63u);   // 64 scratch cells after the window
 
   {
-    for (int g = gx; has_px && g < nx; g += ntx) {   // one trip unless the strip is wider than the block
+    for (int g = gx; g < nx; g += ntx) {       // one trip unless the strip is wider than the block
       const int q = q0 + g * VEC;
       // ray slope of each column (maps.py:677); border columns are poisoned with
       // NaN, which flows through X to the cell coordinates (maps.py:48-70)
@@ -687,9 +439,6 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
       const int step = rows_per_iter * kRowsInFlight;
       float za[kRowsInFlight][VEC], zb_[kRowsInFlight][VEC];
       float va[HAS_VALUE ? kRowsInFlight : 1][VEC], vb_[HAS_VALUE ? kRowsInFlight : 1][VEC];
-#ifdef DM_TRIPLE
-      float zc_[kRowsInFlight][VEC], vc_[HAS_VALUE ? kRowsInFlight : 1][VEC];
-#endif
       auto load_rows = [&](float (&z)[kRowsInFlight][VEC],
                            float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
 #pragma unroll
@@ -832,45 +581,7 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
         int r = r0 + gy;
         load_rows(za, va, r);
         DM_STAMP(2);
-        if (tables_due) {                      // wave-uniform, first trip only
-          if (kFill && fill_ahead) {
-#pragma unroll
-            for (int t = 0; t < kFillAhead; ++t) fill_step();
-          }
-          DM_STAMP(7);
-          build_tables();
-          tables_due = false;
-        }
         DM_STAMP(3);
-#ifdef DM_TRIPLE
-        load_rows(zb_, vb_, r + step);
-        for (int it = 0; it < niter; it += 3) {
-          load_rows(zc_, vc_, r + 2 * step);
-          if (kFill) {
-#pragma unroll
-            for (int t = 0; t < kFillPerHalf; ++t) fill_step();
-          }
-          project_rows(za, va, r);
-          if (it + 1 < niter) {
-            load_rows(za, va, r + 3 * step);
-            if (kFill) {
-#pragma unroll
-              for (int t = 0; t < kFillPerHalf; ++t) fill_step();
-            }
-            project_rows(zb_, vb_, r + step);
-          }
-          if (it + 2 < niter) {
-            load_rows(zb_, vb_, r + 4 * step);
-            if (kFill) {
-#pragma unroll
-              for (int t = 0; t < kFillPerHalf; ++t) fill_step();
-            }
-            project_rows(zc_, vc_, r + 2 * step);
-          }
-          r += 3 * step;
-        }
-        return;
-#endif
         for (int it = 0; it < niter; it += 2) {
           load_rows(zb_, vb_, r + step);
           if (kFill) {
@@ -889,154 +600,18 @@ k_window_scatter(ScatterArgs a, ScatterTables t) {
           r += 2 * step;
         }
       };
-      if (do_fill && !cond_fill) pipeline(std::true_type{}); else pipeline(std::false_type{});
+      if (do_fill) pipeline(std::true_type{}); else pipeline(std::false_type{});
     }
   }
   DM_STAMP(4);
-  fill_rest();
+  while (fs < fill_steps) fill_step();
   lds_barrier();
   DM_STAMP(5);
   const int pid = (b * a.oc + chl) * nparts + part;      // slabs are per channel group
   float* slab = a.slabs + (size_t)pid * a.slab_stride;
-  if (!EXCL) {
-    for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
-      *reinterpret_cast<float4*>(slab + i) = *reinterpret_cast<const float4*>(lds + i);
-    DM_STAMP(6);
-    DM_STAMPS_OUT();
-    return;
-  }
-  // Exclusive cells go to the map, the rest of the span to the slab; cells outside the
-  // span were never touched.  The slab stores are write-through (sc0 sc1): the frame's
-  // last workgroup reads them from another XCD below.
-  const int wg4 = w.w >> 2;
-  const float wg4_inv = 1.0f / (float)(wg4 > 0 ? wg4 : 1);
-  for (int i = threadIdx.x; i < (area >> 2); i += kScatterThreads) {
-    int uz = (int)((float)i * wg4_inv);
-    uz -= (uz * wg4 > i);
-    uz += ((uz + 1) * wg4 <= i);
-    const int x = w.x0 + ((i - uz * wg4) << 2);
-    const int s0 = sp[my_off + uz], s1 = ex[uz];
-    if (x < (s0 & 0xffff) || x >= (s0 >> 16)) continue;
-    const float4 v = *reinterpret_cast<const float4*>(lds + 4 * i);
-    if (x >= (s1 & 0xffff) && x < (s1 >> 16)) {
-      const size_t cell = map_base + (size_t)(w.z0 + uz) * a.mw + x;
-      *reinterpret_cast<float4*>(a.out + cell) = v;
-      const uint32_t mk = (uint32_t)mask_of(v.x, a.fill) | ((uint32_t)mask_of(v.y, a.fill) << 8) |
-                          ((uint32_t)mask_of(v.z, a.fill) << 16) |
-                          ((uint32_t)mask_of(v.w, a.fill) << 24);
-      *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
-    } else {
-      store_through(slab + 4 * i, v);
-    }
-  }
+  for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
+    *reinterpret_cast<float4*>(slab + i) = *reinterpret_cast<const float4*>(lds + i);
   DM_STAMP(6);
-  // ---- the frame's last workgroup merges the border -------------------------------
-  // Every workgroup of (frame, channel) takes a ticket once its stores have completed;
-  // the one whose ticket is the last knows that all border slabs are in memory.  The
-  // ticket word carries the launch's epoch, so it needs no initialisation.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  lds_barrier();
-  if (threadIdx.x == 0) {
-    unsigned long long* tk = a.tickets + ((size_t)b * a.oc_total + ch);
-    unsigned long long old = __hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long nv;
-    do {
-      nv = (old >> 8) == a.epoch ? old + 1 : ((a.epoch << 8) | 1ull);
-    } while (!__hip_atomic_compare_exchange_strong(tk, &old, nv, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT));
-    flag[0] = (int)(nv & 0xffull) == nparts;
-    flag[1] = 0;
-  }
-  lds_barrier();
-  DM_STAMP(10);
-  if (!flag[0]) {
-    DM_STAMPS_OUT();
-    return;
-  }
-  // 1. one thread per row of U lists the float4 groups of the hull that no part owns
-  //    alone (the window cells are free now: they hold the list)
-  int* const list = reinterpret_cast<int*>(lds);
-  const int list_cap = a.tab_off - 64;
-  for (int ur = threadIdx.x; ur < U.h; ur += kScatterThreads) {
-    const int hb = hull[ur];
-    const int hlo = hb & 0xffff, hhi = hb >> 16;
-    if (hlo >= hhi) continue;
-    int sl[kExclParts], el[kExclParts];
-    gather_spans(sl, U.z0 + ur, nparts, winl, sp, row_off);
-#pragma unroll
-    for (int q = 0; q < kExclParts; ++q) el[q] = q < nparts ? exclusive_interval(sl, q, nparts) : 0;
-    // the gaps between the exclusive intervals: [hull lo, first e0), [e1, next e0), ...
-#pragma unroll
-    for (int k = 0; k <= kExclParts; ++k) {
-      int g0;
-      if (k == 0) {
-        g0 = hlo;
-      } else {
-        if (k > nparts) continue;
-        const int e0 = el[k - 1] & 0xffff, e1 = el[k - 1] >> 16;
-        if (e0 >= e1) continue;
-        g0 = e1;
-      }
-      int g1 = hhi;
-#pragma unroll
-      for (int q = 0; q < kExclParts; ++q) {
-        const int e0 = el[q] & 0xffff, e1 = el[q] >> 16;
-        if (e0 < e1 && e0 >= g0 && e0 < g1) g1 = e0;
-      }
-      const int n = (g1 - g0) >> 2;
-      if (n <= 0) continue;
-      const int at = atomicAdd(&flag[1], n);
-      for (int j = 0; j < n; ++j)
-        if (at + j < list_cap) list[at + j] = (ur << 16) | ((g0 >> 2) + j);
-    }
-  }
-  lds_barrier();
-  // 2. one listed group per thread and trip: max/min over the slabs of the parts whose
-  //    span covers it
-  const int nlist = flag[1] < list_cap ? flag[1] : list_cap;
-  const float* slab0 = a.slabs + (size_t)(b * a.oc + chl) * nparts * a.slab_stride;
-  for (int i = threadIdx.x; i < nlist; i += kScatterThreads) {
-    const int ent = list[i];
-    const int z = U.z0 + (ent >> 16), x = (ent & 0xffff) << 2;
-    int sl[kExclParts];
-    gather_spans(sl, z, nparts, winl, sp, row_off);
-    bool rd[kExclParts];
-    int4 v[kExclParts];
-#pragma unroll
-    for (int q = 0; q < kExclParts; ++q) {
-      rd[q] = false;
-      if (q < nparts) {
-        rd[q] = x >= (sl[q] & 0xffff) && x < (sl[q] >> 16);
-        const int off = rd[q] ? (z - winl[4 * q + 1]) * winl[4 * q + 2] + (x - winl[4 * q]) : 0;
-        const int* src = reinterpret_cast<const int*>(slab0 + (size_t)q * a.slab_stride + off);
-        v[q].x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v[q].y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v[q].z = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v[q].w = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
-#pragma unroll
-    for (int q = 0; q < kExclParts; ++q) {
-      if (q < nparts) {
-        const float sx = __int_as_float(v[q].x), sy = __int_as_float(v[q].y),
-                    sz = __int_as_float(v[q].z), sw = __int_as_float(v[q].w);
-        const float mx = IS_MAX ? fmaxf(acc.x, sx) : fminf(acc.x, sx);
-        const float my = IS_MAX ? fmaxf(acc.y, sy) : fminf(acc.y, sy);
-        const float mz = IS_MAX ? fmaxf(acc.z, sz) : fminf(acc.z, sz);
-        const float mw = IS_MAX ? fmaxf(acc.w, sw) : fminf(acc.w, sw);
-        acc.x = rd[q] ? mx : acc.x; acc.y = rd[q] ? my : acc.y;
-        acc.z = rd[q] ? mz : acc.z; acc.w = rd[q] ? mw : acc.w;
-      }
-    }
-    const size_t cell = map_base + (size_t)z * a.mw + x;
-    *reinterpret_cast<float4*>(a.out + cell) = acc;
-    const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
-                        ((uint32_t)mask_of(acc.z, a.fill) << 16) |
-                        ((uint32_t)mask_of(acc.w, a.fill) << 24);
-    *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
-  }
-  DM_STAMP(11);
   DM_STAMPS_OUT();
 }
 
@@ -1045,8 +620,7 @@ struct MergeArgs {
   int nparts;                 // pc * pr
   int slab_stride;
   float fill;
-  const Win16* wins;          // (B, nparts)   written by k_window_scatter
-  const Win16* unions;        // (B)
+  const ScatterTables* tables;  // this chunk's staged table (already in every XCD's L2)
   const float* slabs;
   float* out;
   uint8_t* mask;
@@ -1064,7 +638,8 @@ k_window_merge(MergeArgs a) {
   const int bl = fcl / a.oc, b = a.b0 + bl;
   const int fc = fcl + a.b0 * a.oc;            // slab index of (frame, channel)
   const size_t fo = (size_t)b * a.oc_total + a.ch0 + (fcl - bl * a.oc);   // map index in `out`
-  const Window U = widen(a.unions[b]);
+  const Window U = widen(a.tables->unions[bl]);
+  const int win_stride = a.nparts <= kFewParts ? kFewParts : a.nparts;
   const int ug4 = U.w >> 2;                    // float4 groups per U row
   const int total = ug4 * U.h;
   const int i = blockIdx.x * kMergeThreads + threadIdx.x;
@@ -1073,7 +648,7 @@ k_window_merge(MergeArgs a) {
   const int zb = U.z0 + row, x = U.x0 + ((i - row * ug4) << 2);
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
   for (int p = 0; p < a.nparts; ++p) {
-    const Window w = widen(a.wins[(size_t)b * a.nparts + p]);
+    const Window w = widen(a.tables->wins[bl * win_stride + p]);
     if (w.w == 0) continue;
     const unsigned ux = (unsigned)(x - w.x0), uz = (unsigned)(zb - w.z0);
     if (ux >= (unsigned)w.w || uz >= (unsigned)w.h) continue;
@@ -1284,15 +859,17 @@ bool window_path_supported(const dm_params& p) {
 }
 
 // Device copies of the call's geometry, written by k_window_scatter for the kernels that
-// follow it (part windows, union windows), and the tickets of its workgroups.
-static size_t geometry_bytes(int B, int nparts, int channels) {
-  return align_up((size_t)B * nparts * sizeof(Win16), 256) + align_up((size_t)B * sizeof(Win16), 256) +
-         align_up((size_t)B * channels * sizeof(unsigned long long), 256);
+// follow it: part windows, union windows.
+static int frames_per_chunk(int nparts) {
+  const int win_stride = nparts <= kFewParts ? kFewParts : nparts;
+  const int chunk = kChunkWins / win_stride;
+  return chunk > kChunkFrames ? kChunkFrames : chunk;
 }
 
-// LDS words behind the window of k_window_scatter<..., EXCL> (see there)
-static size_t excl_table_bytes(int nparts, int max_rows_sum, int max_h, int max_uh) {
-  return 4 * ((size_t)nparts * (48 + 4 + 1) + max_rows_sum + (size_t)max_h + max_uh + 4) + 16;
+static size_t geometry_bytes(int B, int nparts) {
+  const int chunk = frames_per_chunk(nparts);
+  return align_up((size_t)B * nparts * sizeof(Win16), 256) + align_up((size_t)B * sizeof(Win16), 256) +
+         align_up((size_t)((B + chunk - 1) / chunk) * sizeof(ScatterTables), 256);
 }
 
 static constexpr size_t kSlabBudget = (size_t)256 << 20;   // slab bytes per channel group
@@ -1311,7 +888,7 @@ size_t window_workspace_bytes(const dm_params& p) {
   size_t slabs = one * oc;
   if (slabs > kSlabBudget) slabs = one > kSlabBudget ? one : kSlabBudget;
   const size_t height_mask = p.vc ? align_up((size_t)p.B * p.dc * p.mh * p.mw, 256) : 0;
-  return geometry_bytes(p.B, 128, (int)oc) + slabs + height_mask;
+  return geometry_bytes(p.B, 128) + slabs + height_mask;
 }
 
 namespace {
@@ -1319,11 +896,10 @@ namespace {
 struct Staged {                 // what run_window keeps between its passes
   Parts parts;
   int nparts, slab_stride, max_union;
-  int max_h, max_uh, max_rows_sum;   // tallest part / union window; most window rows of one frame
-  bool excl;                    // exclusive row spans
   Win16* g_wins;                // device copies (workspace head)
   Win16* g_unions;
-  unsigned long long* tickets;
+  const ScatterTables* d_tables;  // one per chunk of frames
+  int chunk;                    // frames per chunk
   size_t geom_bytes;
   bool fast, fast_div;
   float res_inv, fx_inv, fy_inv;
@@ -1339,11 +915,10 @@ inline hipError_t launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
   return hipGetLastError();
 }
 
-using Kernel = void (*)(ScatterArgs, ScatterTables);
+using Kernel = void (*)(ScatterArgs, const ScatterTables*);
 
-template <bool EXCL>
 Kernel pick_kernel(bool is_max, bool fast, bool has_valid, bool has_value, bool vec4, bool lean) {
-#define DM_K(M, F, V, S) {k_window_scatter<M, F, V, S, 1, false, EXCL>, k_window_scatter<M, F, V, S, 4, false, EXCL>}
+#define DM_K(M, F, V, S) {k_window_scatter<M, F, V, S, 1, false>, k_window_scatter<M, F, V, S, 4, false>}
   // [is_max][fast][has_valid][has_value][vec4]
   static const Kernel table[2][2][2][2][2] = {
       {{{DM_K(false, false, false, false), DM_K(false, false, false, true)},
@@ -1356,10 +931,10 @@ Kernel pick_kernel(bool is_max, bool fast, bool has_valid, bool has_value, bool 
         {DM_K(true, true, true, false), DM_K(true, true, true, true)}}}};
 #undef DM_K
   static const Kernel lean_table[2][2] = {
-      {k_window_scatter<false, true, false, false, 4, true, EXCL>,
-       k_window_scatter<false, true, false, true, 4, true, EXCL>},
-      {k_window_scatter<true, true, false, false, 4, true, EXCL>,
-       k_window_scatter<true, true, false, true, 4, true, EXCL>}};
+      {k_window_scatter<false, true, false, false, 4, true>,
+       k_window_scatter<false, true, false, true, 4, true>},
+      {k_window_scatter<true, true, false, false, 4, true>,
+       k_window_scatter<true, true, false, true, 4, true>}};
   return lean ? lean_table[is_max][has_value] : table[is_max][fast][has_valid][has_value][vec4];
 }
 
@@ -1395,26 +970,15 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
   const bool vec4 = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(depth) % 16 == 0) &&
                     (!value || reinterpret_cast<uintptr_t>(value) % 16 == 0) &&
                     (st.parts.wp % 4 == 0);
-  // per-frame maps with few parts: exclusive row spans, no merge kernel
-  const bool excl = st.excl && out != nullptr && !fused;
-  sa.tab_off = (int)align_up((size_t)st.slab_stride, 4) + 64;
-  sa.max_rows_sum = st.max_rows_sum; sa.max_h = st.max_h; sa.max_uh = st.max_uh;
-  sa.g_wins = st.g_wins; sa.g_unions = st.g_unions; sa.tickets = st.tickets;
-  {   // tickets carry the launch's epoch: unique per process run and launch
-    static std::atomic<unsigned long long> epoch_counter{
-        ((unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() & 0xffffffffffull) << 8};
-    sa.epoch = (epoch_counter.fetch_add(1) + 1) & 0x00ffffffffffffffull;
-  }
+  sa.g_wins = st.g_wins; sa.g_unions = st.g_unions;
 #ifdef DM_STAMPS
   sa.stamps = g_stamp_buffer;
 #endif
-  size_t lds_bytes = align_up((size_t)st.slab_stride * 4, 16) + 64 * 4;   // + dummy cells
-  if (excl) lds_bytes += excl_table_bytes(st.nparts, st.max_rows_sum, st.max_h, st.max_uh);
+  const size_t lds_bytes = align_up((size_t)st.slab_stride * 4, 16) + 64 * 4;   // + dummy cells
   // lean variant: both depth bounds finite, no height truncation, no border, no valid map
   const bool lean = st.fast && vec4 && !has_valid && p.has_dmin && p.has_dmax &&
                     isfinite(p.dmin) && isfinite(p.dmax) && !p.has_hmax && p.clip_border <= 0;
-  const Kernel kfn = excl ? pick_kernel<true>(is_max, st.fast, has_valid, has_value, vec4, lean)
-                          : pick_kernel<false>(is_max, st.fast, has_valid, has_value, vec4, lean);
+  const Kernel kfn = pick_kernel(is_max, st.fast, has_valid, has_value, vec4, lean);
   hipError_t e = hipSuccess;
   {   // raise the dynamic-LDS limit once per kernel variant and device
     static thread_local const void* done[64][8] = {};
@@ -1436,35 +1000,27 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
     }
   }
 
-  // frames per launch: what the kernel-argument tables hold
-  const int win_stride = st.nparts <= kExclParts ? kExclParts : st.nparts;
-  int chunk = kChunkWins / win_stride;
-  if (chunk > kChunkFrames) chunk = kChunkFrames;
+  const int chunk = st.chunk;                // frames per launch: what one table holds
   // channel groups: the slabs of one group fit the workspace's slab region
   const size_t per_channel = (size_t)p.B * st.nparts * st.slab_stride * 4;
   int group = (int)(slab_bytes / (per_channel ? per_channel : 1));
   if (group < 1) group = 1;
   if (group > oc_total) group = oc_total;
   if (group > 65535 / chunk) group = 65535 / chunk;       // merge grid.y = frames * channels
-  static thread_local ScatterTables tab;     // (kernel arguments are copied at launch)
   for (int ch0 = 0; ch0 < oc_total; ch0 += group) {
     const int oc = oc_total - ch0 < group ? oc_total - ch0 : group;
     sa.oc = oc; sa.ch0 = ch0;
     for (int b0 = 0; b0 < p.B; b0 += chunk) {
       const int nb = p.B - b0 < chunk ? p.B - b0 : chunk;
-      memcpy(tab.frames, st.frames + b0, (size_t)nb * sizeof(FrameRec));
-      for (int i = 0; i < nb; ++i)
-        memcpy(tab.wins + (size_t)i * win_stride, st.wins + (size_t)(b0 + i) * st.nparts,
-               (size_t)st.nparts * sizeof(Win16));
-      memcpy(tab.unions, st.unions + b0, (size_t)nb * sizeof(Win16));
       sa.b0 = b0;
-      e = launch(kfn, dim3(st.nparts, oc, nb), dim3(kScatterThreads), lds_bytes, s, sa, tab);
+      e = launch(kfn, dim3(st.nparts, oc, nb), dim3(kScatterThreads), lds_bytes, s, sa,
+                 st.d_tables + b0 / chunk);
       if (e != hipSuccess) return e;
-      if (!fused && !excl && st.max_union > 0) {
+      if (!fused && st.max_union > 0) {
         MergeArgs ma;
         ma.b0 = b0; ma.oc = oc; ma.ch0 = ch0; ma.oc_total = oc_total; ma.mh = p.mh; ma.mw = p.mw;
         ma.nparts = st.nparts; ma.slab_stride = st.slab_stride; ma.fill = fill;
-        ma.wins = st.g_wins; ma.unions = st.g_unions;
+        ma.tables = st.d_tables + b0 / chunk;
         ma.slabs = slabs; ma.out = out; ma.mask = mask;
         const dim3 g((unsigned)((st.max_union / 4 + kMergeThreads - 1) / kMergeThreads), nb * oc);
         e = is_max ? launch(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma)
@@ -1492,7 +1048,7 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
 // hipErrorNotSupported when the windows cannot be made to fit in LDS (the caller then
 // takes the generic path); nothing has been enqueued in that case.
 hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* ws,
-                         size_t ws_bytes, Staged& st, size_t& slab_bytes) {
+                         size_t ws_bytes, Staged& st, size_t& slab_bytes, hipStream_t s) {
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return hipErrorNotSupported;
   thread_local std::vector<FrameRec> recs;
   thread_local std::vector<Win16> wins;      // (B, nparts) then (B) unions
@@ -1504,9 +1060,9 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
     if (st.nparts > 128) return hipErrorNotSupported;
     wins.resize((size_t)p.B * (st.nparts + 1));
     Win16* unions = wins.data() + (size_t)p.B * st.nparts;
-    max_area = 0; st.max_union = 0; st.max_h = 0; st.max_uh = 0; st.max_rows_sum = 0;
+    max_area = 0; st.max_union = 0;
     for (int b = 0; b < p.B; ++b) {
-      int ux0 = p.mw, ux1 = 0, uz0 = p.mh, uz1 = 0, rows_sum = 0;
+      int ux0 = p.mw, ux1 = 0, uz0 = p.mh, uz1 = 0;
       const FrameAffine fa = frame_affine(p, frames_host[b]);
       for (int pr = 0; pr < st.parts.pr; ++pr)
         for (int pc = 0; pc < st.parts.pc; ++pc) {
@@ -1517,8 +1073,6 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
           wins[(size_t)b * st.nparts + pr * st.parts.pc + pc] = narrow(w);
           if (w.w * w.h > max_area) max_area = w.w * w.h;
           if (w.w > 0) {
-            rows_sum += w.h;
-            if (w.h > st.max_h) st.max_h = w.h;
             if (w.x0 < ux0) ux0 = w.x0;
             if (w.x0 + w.w > ux1) ux1 = w.x0 + w.w;
             if (w.z0 < uz0) uz0 = w.z0;
@@ -1528,30 +1082,15 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
       const Window U = ux1 > ux0 ? Window{ux0, uz0, ux1 - ux0, uz1 - uz0} : Window{0, 0, 0, 0};
       unions[b] = narrow(U);
       if (U.w * U.h > st.max_union) st.max_union = U.w * U.h;
-      if (U.h > st.max_uh) st.max_uh = U.h;
-      if (rows_sum > st.max_rows_sum) st.max_rows_sum = rows_sum;
     }
-    if (align_up((size_t)max_area, 32) * 4 + 64 * 4 <= (size_t)kMaxLdsBytes) break;
+    if ((size_t)max_area * 4 + 64 * 4 + 16 <= (size_t)kMaxLdsBytes) break;
     // a window that is the whole map cannot shrink by splitting the image
     if (!p.has_dmin || !p.has_dmax || st.nparts >= 64 ||
         st.parts.pc * st.parts.pr == choose_parts(p, min_parts * 2).pc * choose_parts(p, min_parts * 2).pr)
       return hipErrorNotSupported;
   }
-  // (whole 128-byte lines per slab: a line is then written and read through by the
-  // workgroups of ONE part only)
-  st.slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 32);
-  if (st.max_h < 1) st.max_h = 1;
-  if (st.max_uh < 1) st.max_uh = 1;
-  // exclusive row spans: a few parts per frame, a proper frustum slab, tables that fit
-  // (work in progress: off unless DM_EXCL is set -- the per-workgroup table phase still
-  // costs more than the smaller merge gains)
-  static const bool no_excl = getenv("DM_EXCL") == nullptr;
-  st.excl = !no_excl && st.nparts > 1 && st.nparts <= kExclParts && p.has_dmin && p.has_dmax &&
-            p.dmin >= 0.0f && p.dmax >= p.dmin && isfinite(p.dmax) &&
-            align_up((size_t)st.slab_stride * 4, 16) + 64 * 4 +
-                    excl_table_bytes(st.nparts, st.max_rows_sum, st.max_h, st.max_uh) <=
-                (size_t)kMaxLdsBytes;
-  st.geom_bytes = geometry_bytes(p.B, st.nparts, p.vc ? p.vc : p.dc);
+  st.slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 4);
+  st.geom_bytes = geometry_bytes(p.B, st.nparts);
   if (ws_bytes < st.geom_bytes + (size_t)p.B * st.nparts * st.slab_stride * 4)
     return hipErrorNotSupported;
   slab_bytes = ws_bytes - st.geom_bytes;
@@ -1561,7 +1100,7 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
     base += align_up((size_t)p.B * st.nparts * sizeof(Win16), 256);
     st.g_unions = reinterpret_cast<Win16*>(base);
     base += align_up((size_t)p.B * sizeof(Win16), 256);
-    st.tickets = reinterpret_cast<unsigned long long*>(base);
+    st.d_tables = reinterpret_cast<const ScatterTables*>(base);
   }
 
   recs.resize(p.B);
@@ -1589,7 +1128,25 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
   st.frames = recs.data();
   st.wins = wins.data();
   st.unions = wins.data() + (size_t)p.B * st.nparts;
-  return hipSuccess;
+  // the launches' tables (thread-local staging: hipMemcpyAsync from pageable memory has
+  // copied the bytes out by the time it returns)
+  thread_local std::vector<ScatterTables> tabs;
+  st.chunk = frames_per_chunk(st.nparts);
+  const int win_stride = st.nparts <= kFewParts ? kFewParts : st.nparts;
+  const int nchunks = (p.B + st.chunk - 1) / st.chunk;
+  tabs.resize(nchunks);
+  for (int c = 0; c < nchunks; ++c) {
+    ScatterTables& tab = tabs[c];
+    const int b0 = c * st.chunk;
+    const int nb = p.B - b0 < st.chunk ? p.B - b0 : st.chunk;
+    memcpy(tab.frames, st.frames + b0, (size_t)nb * sizeof(FrameRec));
+    for (int i = 0; i < nb; ++i)
+      memcpy(tab.wins + (size_t)i * win_stride, st.wins + (size_t)(b0 + i) * st.nparts,
+             (size_t)st.nparts * sizeof(Win16));
+    memcpy(tab.unions, st.unions + b0, (size_t)nb * sizeof(Win16));
+  }
+  return hipMemcpyAsync(const_cast<ScatterTables*>(st.d_tables), tabs.data(),
+                        (size_t)nchunks * sizeof(ScatterTables), hipMemcpyHostToDevice, s);
 }
 
 }  // namespace
@@ -1606,7 +1163,7 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     return hipErrorNotSupported;
   Staged st;
   size_t slab_bytes = 0;
-  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes);
+  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s);
   if (e != hipSuccess) return e;
   unsigned char* base = static_cast<unsigned char*>(ws);
   float* slabs = reinterpret_cast<float*>(base + st.geom_bytes);
@@ -1651,7 +1208,7 @@ hipError_t run_window_fused(const dm_params& p, const dm_frame* frames_host, con
     return hipErrorNotSupported;
   Staged st;
   size_t slab_bytes = 0;
-  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes);
+  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s);
   if (e != hipSuccess) return e;
   return window_pass(p, st, reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + st.geom_bytes),
                      depth, value, valid, nullptr, nullptr,

@@ -43,3 +43,12 @@ print("  total                  %8.2f %8.2f" % (np.median(tot), tot.max()))
 print("kernel span us: %.2f   start skew: %.2f   end skew: %.2f" % (
     (st[:, -1].max() - st[:, 0].min()) * 0.01, (st[:, 0].max() - st[:, 0].min()) * 0.01,
     (st[:, -1].max() - st[:, -1].min()) * 0.01))
+# is the end-time skew a per-frame effect (all parts of a frame late together)?
+end = (raw[:, 6] - raw[:, 0].min()) * 0.01
+if len(end) % 4 == 0:
+  pf = end.reshape(-1, 4)
+  print("end time us: overall std %.2f   between-frame std %.2f   within-frame std %.2f" % (
+      end.std(), pf.mean(axis=1).std(), np.sqrt(((pf - pf.mean(axis=1, keepdims=True)) ** 2).mean())))
+  print("by part index (mean end us):", np.round(pf.mean(axis=0), 2))
+  xcd = np.arange(len(end)) % 8
+  print("by XCD (mean end us):", np.round([end[xcd == i].mean() for i in range(8)], 2))

@@ -132,7 +132,7 @@ def main():
   # per-frame maps + masks (i.e. before the batch fuse).
   ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
   ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-  for e in ev_b:
+  for e in ev_a + ev_b:
     e.record()                 # materialise the hipEvent_t handles
   torch.cuda.synchronize()
   lib = _native.lib()
@@ -195,7 +195,7 @@ def main():
         flush_ring()
       return fused, fmask, fused, fmask
     if i is not None:
-      ev_a[i].record()
+      lib.dm_debug_record_before_projection(ev_a[i].cuda_event)
       lib.dm_debug_record_after_projection(ev_b[i].cuda_event)
     # per-frame maps + masks and this rank's partial global map, one launch sequence
     top, mask, fused, fmask = proj.orth_project_and_fuse(
@@ -235,6 +235,14 @@ def main():
   alg = algorithmic_bytes(B, H, W, mh, mw, C, fused_only)
   achieved = alg / kernel_s / 1e9
 
+  # HBM bytes of one launch sequence from the PMC counters: bench.py cannot run rocprofv3 on
+  # itself, so it quotes the committed PMC summary of this very command (profiles/)
+  traffic = None
+  tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+  if args.workload == "cfg2" and os.path.exists(tpath):
+    with open(tpath) as f:
+      traffic = json.load(f).get("launch_sequence_bytes")
+
   result = {
       "metric": "depth frames/sec projected+fused, B=64 640x480->512x512",
       "value": world * B * args.steps / elapsed,
@@ -264,7 +272,9 @@ def main():
           "peak": HBM_PEAK_GBS,
           "unit": "GB/s",
           "frac": achieved / HBM_PEAK_GBS,
-          "traffic": None,
+          "traffic": traffic,
+          "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this "
+                            "command, gfx950 correction applied; bytes per launch sequence)" if traffic else None,
           "kernel": "orth_project launch sequence of dm_orth_project_f32: frame-table copy + "
                     "k_window_scatter + k_window_merge (everything that produces the "
                     "per-frame maps and masks; the batch fuse that follows is excluded)",

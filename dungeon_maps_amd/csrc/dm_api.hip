@@ -10,6 +10,7 @@ namespace {
 thread_local char g_err[512] = "";
 thread_local int g_force_generic = 0;   // dm_debug_force_generic_path (tests)
 thread_local hipEvent_t g_mid_event = nullptr;   // dm_debug_record_after_projection (bench)
+thread_local hipEvent_t g_pre_event = nullptr;   // dm_debug_record_before_projection (bench)
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -81,13 +82,15 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
                 need);
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipErrorNotSupported;
-  const hipEvent_t mid = g_mid_event;
+  const hipEvent_t mid = g_mid_event, pre = g_pre_event;
   g_mid_event = nullptr;
+  g_pre_event = nullptr;
   if (dm::window_path_supported(*p) && !g_force_generic)
     e = dm::run_window(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
                        p->vc ? height_dev : nullptr, fused_dev, fused_mask_dev, workspace_dev,
-                       workspace_bytes, mid, s);
+                       workspace_bytes, pre, mid, s);
   if (e == hipErrorNotSupported) { // nothing enqueued: a window exceeds LDS, odd alignment, ...
+    if (pre) (void)hipEventRecord(pre, s);
     e = dm::run_generic(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
                         p->vc ? height_dev : nullptr, workspace_dev, s);
     if (e == hipSuccess && mid) e = hipEventRecord(mid, s);
@@ -208,6 +211,10 @@ int dm_scatter_f32(const float* values_dev, const int64_t* index_dev, float* can
                                  reduction, workspace_dev, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
   return DM_OK;
+}
+
+void dm_debug_record_before_projection(void* event) {
+  g_pre_event = static_cast<hipEvent_t>(event);
 }
 
 void dm_debug_record_after_projection(void* event) {

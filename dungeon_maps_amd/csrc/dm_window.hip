@@ -1048,7 +1048,8 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
 // hipErrorNotSupported when the windows cannot be made to fit in LDS (the caller then
 // takes the generic path); nothing has been enqueued in that case.
 hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* ws,
-                         size_t ws_bytes, Staged& st, size_t& slab_bytes, hipStream_t s) {
+                         size_t ws_bytes, Staged& st, size_t& slab_bytes, hipStream_t s,
+                         hipEvent_t before = nullptr) {
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return hipErrorNotSupported;
   thread_local std::vector<FrameRec> recs;
   thread_local std::vector<Win16> wins;      // (B, nparts) then (B) unions
@@ -1145,6 +1146,10 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
              (size_t)st.nparts * sizeof(Win16));
     memcpy(tab.unions, st.unions + b0, (size_t)nb * sizeof(Win16));
   }
+  if (before) {
+    const hipError_t e = hipEventRecord(before, s);
+    if (e != hipSuccess) return e;
+  }
   return hipMemcpyAsync(const_cast<ScatterTables*>(st.d_tables), tabs.data(),
                         (size_t)nchunks * sizeof(ScatterTables), hipMemcpyHostToDevice, s);
 }
@@ -1154,7 +1159,8 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
 hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const float* depth,
                       const float* value, const uint8_t* valid, float* out, uint8_t* mask,
                       float* height, float* fused, uint8_t* fused_mask, void* ws,
-                      size_t ws_bytes, hipEvent_t after_projection, hipStream_t s) {
+                      size_t ws_bytes, hipEvent_t before_projection, hipEvent_t after_projection,
+                      hipStream_t s) {
   const int oc_total = p.vc ? p.vc : p.dc;
   if (reinterpret_cast<uintptr_t>(out) % 16 != 0 || reinterpret_cast<uintptr_t>(mask) % 4 != 0 ||
       reinterpret_cast<uintptr_t>(fused) % 16 != 0 ||
@@ -1163,7 +1169,7 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     return hipErrorNotSupported;
   Staged st;
   size_t slab_bytes = 0;
-  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s);
+  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s, before_projection);
   if (e != hipSuccess) return e;
   unsigned char* base = static_cast<unsigned char*>(ws);
   float* slabs = reinterpret_cast<float*>(base + st.geom_bytes);

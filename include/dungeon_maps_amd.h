@@ -204,6 +204,9 @@ int dm_debug_force_generic_path(int on);
  * records `event` (a hipEvent_t) on its stream right after the kernels that
  * produce out/mask and before the optional batch fuse, then forgets it.
  */
+/* The same for the start of that sequence: the event is recorded right before the first
+ * operation the call enqueues (after its host-side geometry). */
+void dm_debug_record_before_projection(void* event);
 void dm_debug_record_after_projection(void* event);
 
 /*

@@ -46,6 +46,10 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dm_debug_force_generic_path": (ctypes.c_int, [ctypes.c_int]),
+    "dm_crop_nearest_f32": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+        ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dm_debug_record_after_projection": (None, [ctypes.c_void_p]),
     "dm_debug_record_before_projection": (None, [ctypes.c_void_p]),
     "dm_camera_affine_grid_f32": (ctypes.c_int, [

@@ -42,6 +42,9 @@ hipError_t run_map_quantize(const float* x, const float* z, const float* woff, c
                             long long* xb, long long* zb, hipStream_t s);
 hipError_t run_camera_affine_grid(const dm_params& p, const dm_frame* frames_host,
                                   const float* depth, float* grid, void* ws, hipStream_t s);
+hipError_t run_crop_nearest(const float* src, const uint8_t* src_mask, const float* center, int B,
+                            int C, int h, int w, int ch, int cw, float fill, int has_fill,
+                            float* dst, uint8_t* dst_mask, hipStream_t s);
 size_t scatter_workspace_bytes(size_t rows, size_t M, int has_fill, int reduction);
 hipError_t run_scatter(const float* values, const long long* index, float* canvas, uint8_t* mask,
                        int R, int C, int Ci, size_t N, size_t M, float fill, int has_fill,

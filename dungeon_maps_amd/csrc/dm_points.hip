@@ -240,4 +240,62 @@ hipError_t run_scatter(const float* values, const long long* index, float* canva
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// crop_topdown_map / TopdownMap.select (maps.py:1959-2037): generate_crop_grid
+// (utils.py:571-611) + image_sample(mode='nearest') (utils.py:613-652) as ONE gather.
+//
+// The reference pads the image by one pixel per side with the fill value, builds a
+// normalised grid and calls grid_sample(nearest, align_corners=True).  Per output pixel
+// (i, j) of frame b, float32, one rounding per operation, in the reference's order:
+//   c   = center[b] + 1                         pw = w + 2, ph = h + 2
+//   gx  = ((j - cw/2) + (c.x - pw/2)) / (pw/2)                         utils.py:603-609
+//   ix  = ((gx + 1) / 2) * (pw - 1)             grid_sample, align_corners=True
+//   has_fill: ix = clamp(ix, 0, pw - 1)         padding_mode='border'  utils.py:639
+//   ixn = nearbyint(ix)                         round half to even
+//   out = inside the padded image ? (inside the image ? src : fill) : 0   ('zeros')
+// and the same for y.  `mask` (bool image, fill False) rides on the same coordinates.
+__global__ void __launch_bounds__(256)
+k_crop_nearest(const float* __restrict__ src, const uint8_t* __restrict__ src_mask,
+               const float* __restrict__ center, int C, int h, int w, int ch, int cw, float fill,
+               int has_fill, float* __restrict__ dst, uint8_t* __restrict__ dst_mask) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ch * cw) return;
+  const int i = o / cw, j = o - i * cw;
+  const float pw = (float)(w + 2), ph = (float)(h + 2);
+  const float cxp = center[2 * b] + 1.0f, cyp = center[2 * b + 1] + 1.0f;
+  const float gx = (((float)j - (float)cw / 2.0f) + (cxp - pw / 2.0f)) / (pw / 2.0f);
+  const float gy = (((float)i - (float)ch / 2.0f) + (cyp - ph / 2.0f)) / (ph / 2.0f);
+  float ix = ((gx + 1.0f) / 2.0f) * (pw - 1.0f);
+  float iy = ((gy + 1.0f) / 2.0f) * (ph - 1.0f);
+  if (has_fill) {            // clip_coordinates: min(size - 1, max(coord, 0)); NaN -> 0
+    ix = fminf(pw - 1.0f, fmaxf(ix, 0.0f));
+    iy = fminf(ph - 1.0f, fmaxf(iy, 0.0f));
+  }
+  const float fx = nearbyintf(ix), fy = nearbyintf(iy);
+  const size_t plane = ((size_t)b * C + c);
+  float v = has_fill ? fill : 0.0f;
+  uint8_t m = 0;
+  // inside the original image (padded coordinates 1 .. w / 1 .. h)?
+  if (fx >= 1.0f && fx <= (float)w && fy >= 1.0f && fy <= (float)h) {
+    const size_t at = plane * h * w + (size_t)((int)fy - 1) * w + ((int)fx - 1);
+    v = src[at];
+    if (src_mask) m = src_mask[at];
+  } else if (!(fx >= 0.0f && fx <= pw - 1.0f && fy >= 0.0f && fy <= ph - 1.0f)) {
+    v = 0.0f;                // outside the padded image ('zeros' mode only; NaN coordinates)
+  }
+  const size_t to = plane * ch * cw + o;
+  dst[to] = v;
+  if (dst_mask) dst_mask[to] = m;
+}
+
+hipError_t run_crop_nearest(const float* src, const uint8_t* src_mask, const float* center, int B,
+                            int C, int h, int w, int ch, int cw, float fill, int has_fill,
+                            float* dst, uint8_t* dst_mask, hipStream_t s) {
+  const dim3 grid((unsigned)(((size_t)ch * cw + 255) / 256), C, B);
+  hipLaunchKernelGGL(k_crop_nearest, grid, dim3(256), 0, s, src, src_mask, center, C, h, w, ch, cw,
+                     fill, has_fill, dst, dst_mask);
+  return hipGetLastError();
+}
+
 }  // namespace dm

@@ -340,6 +340,35 @@ def mask_from_map(topdown: torch.Tensor, fill_value: Optional[float]) -> torch.T
   return mask
 
 
+def crop_nearest(image: torch.Tensor, center: torch.Tensor, crop_width: int, crop_height: int,
+                 fill_value: Optional[float] = None,
+                 mask: Optional[torch.Tensor] = None):
+  """generate_crop_grid + image_sample(mode='nearest') (reference utils.py:571-652) as one
+  HIP gather: ``image`` (b, c, h, w) float32 on the GPU, ``center`` (b, 2) crop centres in
+  pixels, optional bool ``mask`` of the same shape sampled on the same coordinates with
+  fill False.  Returns the crop (and the cropped mask)."""
+  if image.device.type != "cuda":
+    raise RuntimeError("crop_nearest runs on the GPU")
+  img = image.to(torch.float32).contiguous()
+  b, c, h, w = img.shape
+  ctr = utils.to_tensor(center, device=img.device).to(torch.float32).reshape(-1, 2)
+  if ctr.shape[0] == 1 and b > 1:
+    ctr = ctr.expand(b, 2)
+  assert ctr.shape[0] == b, (ctr.shape, b)
+  ctr = ctr.contiguous()
+  out = torch.empty((b, c, crop_height, crop_width), dtype=torch.float32, device=img.device)
+  msk = out_mask = None
+  if mask is not None:
+    msk = mask.to(device=img.device, dtype=torch.bool).expand(img.shape).contiguous()
+    out_mask = torch.empty(out.shape, dtype=torch.bool, device=img.device)
+  with torch.cuda.device(img.device):
+    _native.check(_native.lib().dm_crop_nearest_f32(
+        _ptr(img), _ptr(msk), _ptr(ctr), b, c, h, w, crop_height, crop_width,
+        0.0 if fill_value is None else float(fill_value), 0 if fill_value is None else 1,
+        _ptr(out), _ptr(out_mask), _stream_ptr(img.device)))
+  return (out, out_mask) if mask is not None else out
+
+
 # ---------------------------------------------------------------------------
 # Point-set helpers (small tensors; float32 formulas in the reference's order)
 # ---------------------------------------------------------------------------

@@ -154,6 +154,21 @@ int dm_camera_affine_grid_f32(const dm_params* p, const dm_frame* frames,
                               void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /*
+ * crop_topdown_map / TopdownMap.select (maps.py:1959-2037): generate_crop_grid
+ * (utils.py:571-611) + image_sample(mode='nearest') (utils.py:613-652) fused into one
+ * gather.  image_dev (B, C, h, w) f32; mask_dev (B, C, h, w) uint8/bool or NULL (the
+ * companion mask rides on the same coordinates with fill False); center_dev (B, 2) f32
+ * crop centres (x, y) in pixels; out_dev (B, C, crop_h, crop_w), out_mask_dev likewise.
+ * has_fill == 0 is fill_value=None: zero padding and padding_mode='zeros' (utils.py:634-637);
+ * otherwise the image is padded with `fill` and coordinates are clamped ('border').
+ * Pixel centres follow grid_sample(align_corners=True), nearest = round half to even.
+ */
+int dm_crop_nearest_f32(const float* image_dev, const uint8_t* mask_dev, const float* center_dev,
+                        int64_t B, int64_t C, int64_t h, int64_t w, int64_t crop_h, int64_t crop_w,
+                        float fill, int has_fill, float* out_dev, uint8_t* out_mask_dev,
+                        void* stream);
+
+/*
  * utils.rotate + utils.translate on materialised points (utils.py:229-330; used
  * by camera_to_local_space / local_to_global_space / global_to_local_space /
  * local_to_camera_space, maps.py:753-942).  pts_dev, out_dev (B, n, 3) f32;

@@ -92,3 +92,47 @@ def main():
   for k, v in tot.items(): print(k, v / nf, "cells per frame")
 
 main()
+
+
+def sheared_area(cor, mh, mw):
+  """Area (cells) of the tightest parallelogram window around the 8 corners, sheared along
+  z (rows shift in x) or along x (columns shift in z), 2 cells of slack, x aligned to 4."""
+  x, z = cor[:, 0], cor[:, 1]
+  best = None
+  for major in ("z", "x"):
+    a, b = (x, z) if major == "z" else (z, x)      # a = sheared coordinate, b = running coordinate
+    # candidate shears: slopes of the hull's long edges -> try all pairs
+    cands = [0.0]
+    for i in range(8):
+      for j in range(i + 1, 8):
+        if abs(b[j] - b[i]) > 1.0:
+          cands.append((a[j] - a[i]) / (b[j] - b[i]))
+    b0 = np.floor(b.min()) - 2
+    hb = np.floor(b.max()) + 3 - b0
+    for sh in cands:
+      d = a - sh * (b - b0)
+      w = np.floor(d.max()) + 3 - (np.floor(d.min()) - 2) + (3 if major == "z" else 0) + abs(sh)
+      area = w * hb
+      if best is None or area < best[0]:
+        best = (area, major, sh)
+  return best
+
+
+def shear_main():
+  W, H, mh, mw = 640, 480, 512, 512
+  hfov = np.radians(70.)
+  cx, cy = W / 2., H / 2.
+  fx = cx / np.tan(hfov / 2.); fy = fx
+  rng = np.random.default_rng(0)
+  tot_b = tot_s = 0; majors = {"z": 0, "x": 0}
+  for f in range(16):
+    tx, tz = rng.uniform(-1, 1, 2); yaw = rng.uniform(-np.pi, np.pi)
+    P = (W, H, cx, cy, fx, fy, np.radians(-20.), 0.88, yaw, tx, tz, 0.03, mw / 2., mh / 2., mh, True)
+    for pc in range(4):
+      cor = corners(pc * 160, pc * 160 + 160, 0, H, 0.15, 5.05, P)
+      bb = (np.floor(cor[:, 0].max()) + 3 - np.floor(cor[:, 0].min()) + 2 + 3) * (np.floor(cor[:, 1].max()) + 3 - np.floor(cor[:, 1].min()) + 2)
+      a, major, sh = sheared_area(cor, mh, mw)
+      tot_b += bb; tot_s += a; majors[major] += 1
+  print("unclipped bbox cells/part %.0f   sheared window cells/part %.0f   (%s)" % (tot_b / 64, tot_s / 64, majors))
+
+shear_main()

@@ -751,6 +751,7 @@ struct FuseWinArgs {
   int nparts, oc, ch0, oc_total, mh, mw;
   int slab_stride;
   int accumulate;
+  int gx0, gz0, gx1, gz1;     // bounding box of every window of the call (cells, half open)
   float fill;
   const Win16* wins;          // (B_total, nparts)   written by k_window_scatter
   const float* slabs;         // ((b * oc + chl) * nparts + p) * slab_stride
@@ -782,6 +783,22 @@ k_fuse_windows(FuseWinArgs a) {
   const int x_hi = z_lo == z_hi ? ((g_last - z_lo * g4) << 2) + 4 : a.mw;
   const size_t M = (size_t)a.mh * a.mw;
   const size_t cell = (size_t)ch * M + (size_t)z * a.mw + x;
+  // most of a large global map is out of reach of the whole call: such a block writes the
+  // fill value (or, accumulating, only refreshes the mask) without looking at any window
+  if (z_hi < a.gz0 || z_lo >= a.gz1 || x_hi <= a.gx0 || x_lo >= a.gx1) {      // block-uniform
+    if (lane == 0 && live) {
+      uint32_t mk = 0u;
+      if (a.accumulate) {
+        const float4 v = *reinterpret_cast<const float4*>(a.fused + cell);
+        mk = (uint32_t)mask_of(v.x, a.fill) | ((uint32_t)mask_of(v.y, a.fill) << 8) |
+             ((uint32_t)mask_of(v.z, a.fill) << 16) | ((uint32_t)mask_of(v.w, a.fill) << 24);
+      } else {
+        *reinterpret_cast<float4*>(a.fused + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
+      }
+      *reinterpret_cast<uint32_t*>(a.fused_mask + cell) = mk;
+    }
+    return;
+  }
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
   if (a.accumulate && lane == 0 && live) acc = *reinterpret_cast<const float4*>(a.fused + cell);
   for (int c0 = 0; c0 < a.nwin; c0 += kFuseChunk) {
@@ -896,6 +913,7 @@ namespace {
 struct Staged {                 // what run_window keeps between its passes
   Parts parts;
   int nparts, slab_stride, max_union;
+  int gx0, gz0, gx1, gz1;       // bounding box of all union windows (empty: gx1 <= gx0)
   Win16* g_wins;                // device copies (workspace head)
   Win16* g_unions;
   const ScatterTables* d_tables;  // one per chunk of frames
@@ -1033,6 +1051,7 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
       fa.nwin = p.B * st.nparts; fa.b0 = 0; fa.nparts = st.nparts; fa.oc = oc; fa.ch0 = ch0;
       fa.oc_total = oc_total; fa.mh = p.mh; fa.mw = p.mw; fa.slab_stride = st.slab_stride;
       fa.accumulate = accumulate; fa.fill = fill;
+      fa.gx0 = st.gx0; fa.gz0 = st.gz0; fa.gx1 = st.gx1; fa.gz1 = st.gz1;
       fa.wins = st.g_wins; fa.slabs = slabs; fa.fused = fused; fa.fused_mask = fused_mask;
       const dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kFuseGroups - 1) / kFuseGroups), oc);
       const dim3 blk(kFuseGroups * kFuseLanes);
@@ -1062,6 +1081,7 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
     wins.resize((size_t)p.B * (st.nparts + 1));
     Win16* unions = wins.data() + (size_t)p.B * st.nparts;
     max_area = 0; st.max_union = 0;
+    st.gx0 = p.mw; st.gz0 = p.mh; st.gx1 = 0; st.gz1 = 0;
     for (int b = 0; b < p.B; ++b) {
       int ux0 = p.mw, ux1 = 0, uz0 = p.mh, uz1 = 0;
       const FrameAffine fa = frame_affine(p, frames_host[b]);
@@ -1083,6 +1103,12 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
       const Window U = ux1 > ux0 ? Window{ux0, uz0, ux1 - ux0, uz1 - uz0} : Window{0, 0, 0, 0};
       unions[b] = narrow(U);
       if (U.w * U.h > st.max_union) st.max_union = U.w * U.h;
+      if (U.w > 0) {
+        if (U.x0 < st.gx0) st.gx0 = U.x0;
+        if (U.z0 < st.gz0) st.gz0 = U.z0;
+        if (U.x0 + U.w > st.gx1) st.gx1 = U.x0 + U.w;
+        if (U.z0 + U.h > st.gz1) st.gz1 = U.z0 + U.h;
+      }
     }
     if ((size_t)max_area * 4 + 64 * 4 + 16 <= (size_t)kMaxLdsBytes) break;
     // a window that is the whole map cannot shrink by splitting the image

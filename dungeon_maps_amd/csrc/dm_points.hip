@@ -165,6 +165,48 @@ k_camera_affine_grid(View v, int dc, const dm_frame* __restrict__ frames,
   reinterpret_cast<float2*>(grid)[k] = make_float2(u, w);
 }
 
+// The same, four pixels of a row per thread (W % 4 == 0, 16-byte aligned images): one
+// 16-byte depth load, two 16-byte grid stores, the row's ray slope computed once.
+__global__ void __launch_bounds__(256)
+k_camera_affine_grid4(View v, int dc, const dm_frame* __restrict__ frames,
+                      const float* __restrict__ depth, float* __restrict__ grid) {
+  const int b = blockIdx.z, ch = blockIdx.y;
+  const int W4 = v.W >> 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= v.H * W4) return;
+  const dm_frame* f = frames + b;
+  const float* rp = f->Rp; const float* ry = f->Ry; const float* ri = f->reserved;  // R(-pitch)
+  const int r = i / W4, q0 = (i - r * W4) << 2;
+  const size_t k = ((size_t)b * dc + ch) * ((size_t)v.H * v.W) + (size_t)r * v.W + q0;
+  const float4 zz = *reinterpret_cast<const float4*>(depth + k);
+  const float zs[4] = {zz.x, zz.y, zz.z, zz.w};
+  const float ay = ray_y(v, r);
+  float out[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float z = zs[j];
+    const float X = ray_x(v, q0 + j) * z, Y = ay * z;
+    const float x1 = __builtin_fmaf(z, rp[6], __builtin_fmaf(Y, rp[3], X * rp[0])) + 0.0f;
+    const float y1 = __builtin_fmaf(z, rp[7], __builtin_fmaf(Y, rp[4], X * rp[1])) + f->cam_height;
+    const float z1 = __builtin_fmaf(z, rp[8], __builtin_fmaf(Y, rp[5], X * rp[2])) + 0.0f;
+    const float x2 = __builtin_fmaf(z1, ry[6], __builtin_fmaf(y1, ry[3], x1 * ry[0])) + f->tx;
+    const float y2 = __builtin_fmaf(z1, ry[7], __builtin_fmaf(y1, ry[4], x1 * ry[1])) + 0.0f;
+    const float z2 = __builtin_fmaf(z1, ry[8], __builtin_fmaf(y1, ry[5], x1 * ry[2])) + f->tz;
+    const float x3 = x2 + 0.0f, y3 = y2 + (-f->cam_height), z3 = z2 + 0.0f;
+    const float xc = __builtin_fmaf(z3, ri[6], __builtin_fmaf(y3, ri[3], x3 * ri[0]));
+    const float yc = __builtin_fmaf(z3, ri[7], __builtin_fmaf(y3, ri[4], x3 * ri[1]));
+    const float zc = __builtin_fmaf(z3, ri[8], __builtin_fmaf(y3, ri[5], x3 * ri[2]));
+    const float z_eps = zc + 1e-7f;
+    const float u = xc / z_eps * v.fx + v.cx;
+    float w = yc / z_eps * v.fy + v.cy;
+    if (v.flip_h) w = v.Hm1 - w;
+    out[2 * j] = u; out[2 * j + 1] = w;
+  }
+  float4* dst = reinterpret_cast<float4*>(grid + 2 * k);
+  dst[0] = make_float4(out[0], out[1], out[2], out[3]);
+  dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+}
+
 inline int nblocks(size_t n, int cap = 8192) {
   size_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
@@ -198,9 +240,16 @@ hipError_t run_camera_affine_grid(const dm_params& p, const dm_frame* frames_hos
                                 hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return e;
   const View v = make_view(p);
-  dim3 g((unsigned)((p.H * p.W + 255) / 256), p.dc, p.B);
-  hipLaunchKernelGGL(k_camera_affine_grid, g, dim3(256), 0, s, v, p.dc,
-                     static_cast<const dm_frame*>(ws), depth, grid);
+  if (p.W % 4 == 0 && reinterpret_cast<uintptr_t>(depth) % 16 == 0 &&
+      reinterpret_cast<uintptr_t>(grid) % 16 == 0) {
+    dim3 g((unsigned)((p.H * (p.W / 4) + 255) / 256), p.dc, p.B);
+    hipLaunchKernelGGL(k_camera_affine_grid4, g, dim3(256), 0, s, v, p.dc,
+                       static_cast<const dm_frame*>(ws), depth, grid);
+  } else {
+    dim3 g((unsigned)((p.H * p.W + 255) / 256), p.dc, p.B);
+    hipLaunchKernelGGL(k_camera_affine_grid, g, dim3(256), 0, s, v, p.dc,
+                       static_cast<const dm_frame*>(ws), depth, grid);
+  }
   return hipGetLastError();
 }
 

@@ -75,6 +75,9 @@ struct ScatterTables {
 };
 
 __device__ __host__ inline Window widen(Win16 w) { return Window{w.x0, w.z0, w.w, w.h}; }
+__device__ inline Win16 narrow16(Window w) {
+  return Win16{(short)w.x0, (short)w.z0, (short)w.w, (short)w.h};
+}
 __host__ inline Win16 narrow(Window w) {
   return Win16{(short)w.x0, (short)w.z0, (short)w.w, (short)w.h};
 }
@@ -323,8 +326,28 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   const int dch = a.dc == 1 ? 0 : ch;          // depth / cell-index channel (utils.py:475-477)
   const int nparts = a.parts.pc * a.parts.pr;
   const int pcx = part % a.parts.pc, pry = part / a.parts.pc;
-  const Win16 w_few = t.wins[bl * kFewParts + (part & (kFewParts - 1))];
-  const int win_stride = nparts <= kFewParts ? kFewParts : nparts;
+  // Everything this workgroup reads from the staged table -- its window, the frame's union
+  // window and the frame record -- is requested in ONE batch of scalar loads and pinned
+  // (the asm makes the values opaque): left to the compiler these loads trickle in close
+  // to their first use, one dependent ~0.7-us round trip after the other.
+  int w_raw[2], u_raw[2];
+  float fr[23];
+  {
+    const int* tw = reinterpret_cast<const int*>(&t.wins[bl * kFewParts + (part & (kFewParts - 1))]);
+    const int* tu = reinterpret_cast<const int*>(&t.unions[bl]);
+    const float* tf = reinterpret_cast<const float*>(&t.frames[bl]);
+    w_raw[0] = tw[0]; w_raw[1] = tw[1]; u_raw[0] = tu[0]; u_raw[1] = tu[1];
+#pragma unroll
+    for (int i = 0; i < 23; ++i) fr[i] = tf[i];
+    asm volatile("" : "+s"(w_raw[0]), "+s"(w_raw[1]), "+s"(u_raw[0]), "+s"(u_raw[1]),
+                      "+s"(fr[0]), "+s"(fr[1]), "+s"(fr[2]), "+s"(fr[3]), "+s"(fr[4]), "+s"(fr[5]),
+                      "+s"(fr[6]), "+s"(fr[7]), "+s"(fr[8]), "+s"(fr[9]), "+s"(fr[10]), "+s"(fr[11]),
+                      "+s"(fr[12]), "+s"(fr[13]), "+s"(fr[14]), "+s"(fr[15]), "+s"(fr[16]),
+                      "+s"(fr[17]), "+s"(fr[18]), "+s"(fr[19]), "+s"(fr[20]), "+s"(fr[21]),
+                      "+s"(fr[22]));
+  }
+  const Win16 w_few = {(short)(w_raw[0] & 0xffff), (short)(w_raw[0] >> 16),
+                       (short)(w_raw[1] & 0xffff), (short)(w_raw[1] >> 16)};
   const Window w = nparts <= kFewParts ? widen(w_few) : widen(t.wins[bl * nparts + part]);
   const int area = w.w * w.h;                  // 0: nothing of this part can land
 #ifdef DM_STAMPS
@@ -347,7 +370,8 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   // redirected to `alt`, a cell of this workgroup's share that does get the fill value,
   // so the stores are unconditional straight-line code and the compiler can count the
   // pipelined loop's waits exactly.
-  const Window U = widen(t.unions[bl]);
+  const Window U = {(short)(u_raw[0] & 0xffff), (short)(u_raw[0] >> 16),
+                    (short)(u_raw[1] & 0xffff), (short)(u_raw[1] >> 16)};
   const int g4 = a.mw >> 2;
   const int fill_rows = (a.mh - part + nparts - 1) / nparts;
   const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
@@ -381,25 +405,29 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
     *reinterpret_cast<float4*>(a.out + map_base + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
     *reinterpret_cast<uint32_t*>(a.mask + map_base + cell) = 0u;
   };
-  // device copies of the geometry for the kernels that follow
-  if (chl == 0 && threadIdx.x == 0) {
-    a.g_wins[(size_t)b * nparts + part] = t.wins[bl * win_stride + part];
-    if (part == 0) a.g_unions[b] = t.unions[bl];
-  }
+  // device copies of the geometry for the kernels that follow (stored at the very end: a
+  // store in flight makes its wave wait before the first depth loads)
+  auto publish_geometry = [&]() {
+    if (chl == 0 && threadIdx.x == 0) {
+      a.g_wins[(size_t)b * nparts + part] = narrow16(w);
+      if (part == 0) a.g_unions[b] = narrow16(U);
+    }
+  };
   if (area == 0) {                             // wave-uniform
     while (fs < fill_steps) fill_step();
+    publish_geometry();
     return;
   }
   for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
     *reinterpret_cast<float4*>(lds + i) = make_float4(a.fill, a.fill, a.fill, a.fill);
-  const FrameRec& f = t.frames[bl];
+  // FrameRec: p[9], cam_h, y[9], tx, tz, wo, ho
   // pitch: rows 1,2 of R; yaw: rows 0,2 (the rest is 0/1 when FAST)
-  const float p0 = f.p[0], p1 = f.p[1], p2 = f.p[2], p3 = f.p[3], p4 = f.p[4],
-              p5 = f.p[5], p6 = f.p[6], p7 = f.p[7], p8 = f.p[8];
-  const float y0 = f.y[0], y1r = f.y[1], y2r = f.y[2], y3 = f.y[3], y4 = f.y[4],
-              y5 = f.y[5], y6 = f.y[6], y7 = f.y[7], y8 = f.y[8];
-  const float cam_h = f.cam_h, tx = f.tx, tz = f.tz;
-  const float wo = f.wo, ho = f.ho;
+  const float p0 = fr[0], p1 = fr[1], p2 = fr[2], p3 = fr[3], p4 = fr[4],
+              p5 = fr[5], p6 = fr[6], p7 = fr[7], p8 = fr[8];
+  const float y0 = fr[10], y1r = fr[11], y2r = fr[12], y3 = fr[13], y4 = fr[14],
+              y5 = fr[15], y6 = fr[16], y7 = fr[17], y8 = fr[18];
+  const float cam_h = fr[9], tx = fr[19], tz = fr[20];
+  const float wo = fr[21], ho = fr[22];
   const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
   lds_barrier();
   DM_STAMP(1);
@@ -611,6 +639,7 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   float* slab = a.slabs + (size_t)pid * a.slab_stride;
   for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
     *reinterpret_cast<float4*>(slab + i) = *reinterpret_cast<const float4*>(lds + i);
+  publish_geometry();
   DM_STAMP(6);
   DM_STAMPS_OUT();
 }

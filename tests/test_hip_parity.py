@@ -129,6 +129,52 @@ def test_random_depth_vs_oracle(dmap, oracle, B, H, W, mh, mw):
   np.testing.assert_array_equal(outs[0], want[0])
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations_vs_oracle(dmap, oracle, seed):
+  """Seeded sweep over the projector's parameter space (pitch of either sign, non-square
+  pixels, resolutions, offsets, flips, local/global, borders, truncations, valid maps,
+  per-frame pitch/height, min/max, scene-like and uniform depth, batch sizes that pick
+  different strip layouts): GPU == oracle bit for bit."""
+  rng = np.random.default_rng(1000 + seed)
+  B = int(rng.choice([1, 2, 5, 17, 40]))
+  H, W = [(48, 64), (60, 80), (96, 128), (50, 70)][int(rng.integers(4))]
+  mh, mw = [(64, 64), (96, 128), (128, 96), (160, 160)][int(rng.integers(4))]
+  scene = bool(rng.integers(2))
+  if scene:     # floor + walls: many pixels per cell
+    rows = np.arange(H, dtype=np.float64).reshape(1, 1, H, 1)
+    wall = rng.uniform(1.0, 6.0, size=(B, 1, 1, W // 8 + 1)).repeat(8, axis=3)[..., :W]
+    floor = 0.9 / np.maximum(0.05, (rows - H * 0.45) / (H * 0.9))
+    depth = np.minimum(floor, wall).astype(np.float32)
+    depth = np.broadcast_to(depth, (B, 1, H, W)).copy()
+  else:
+    depth = rng.uniform(0.1, 8.0, size=(B, 1, H, W)).astype(np.float32)
+  pose = np.stack([rng.uniform(-1, 1, B), rng.uniform(-1, 1, B), rng.uniform(-np.pi, np.pi, B)],
+                  axis=1).astype(np.float32)
+  per_frame = bool(rng.integers(2))
+  pitch = rng.uniform(-0.7, 0.4, size=B if per_frame else 1).astype(np.float32)
+  camh = rng.uniform(0.3, 1.5, size=B if per_frame else 1).astype(np.float32)
+  is_max = bool(rng.integers(4))           # mostly max
+  cfg = dict(width=W, height=H, hfov=float(rng.uniform(0.8, 1.7)),
+             vfov=None if rng.integers(2) else float(rng.uniform(0.7, 1.4)),
+             cam_pitch=pitch, cam_height=camh,
+             width_offset=float(mw / 2 + rng.uniform(-20, 20)),
+             height_offset=float(mh / 2 + rng.uniform(-20, 20)),
+             map_res=float(rng.choice([0.03, 0.05, 0.08, 0.1])), map_width=mw, map_height=mh,
+             trunc_depth_min=float(rng.choice([0.0, 0.15, 0.5])),
+             trunc_depth_max=float(rng.choice([2.5, 5.05, 7.0])),
+             trunc_height_max=None if rng.integers(3) else float(rng.uniform(0.2, 1.2)),
+             clip_border=int(rng.choice([0, 0, 3, 9])),
+             to_global=bool(rng.integers(2)), flip_h=bool(rng.integers(4)),
+             fill_value=(-np.inf if is_max else np.inf) if rng.integers(3) else float(rng.uniform(-1, 1)),
+             reduction="max" if is_max else "min")
+  valid = (rng.uniform(size=(B, 1, H, W)) > 0.1) if rng.integers(3) == 0 else None
+  outs = _run(dmap, cfg, depth, valid=valid, cam_pose=pose)
+  want = oracle.orth_project(depth, valid_map=valid,
+                             **dict(_oracle_kwargs(oracle, cfg), cam_pose=pose), nthreads=8)
+  np.testing.assert_array_equal(outs[1], want[1])
+  np.testing.assert_array_equal(outs[0], want[0])
+
+
 def test_semantic_40_classes_vs_oracle(dmap, oracle):
   """BASELINE configs[2] geometry at a small batch: 40-class one-hot, fill 0."""
   B, H, W, C = 2, 120, 160, 40

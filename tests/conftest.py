@@ -34,6 +34,24 @@ def load_golden(name):
   return arrays, cfg
 
 
+def load_sweep(name="g11_parameter_sweep_56x40"):
+  """The parameter-sweep fixture as a list of (arrays, cfg) pairs, one per configuration."""
+  z = np.load(os.path.join(GOLDEN, name + ".npz"))
+  out = {}
+  for key in z.files:
+    k, rest = key.split("_", 1)
+    arrays, cfg = out.setdefault(int(k[1:]), ({}, {}))
+    if rest.startswith("cfg_"):
+      v = z[key]
+      v = v.item() if v.ndim == 0 else v.tolist()
+      if isinstance(v, float) and np.isnan(v):
+        v = None
+      cfg[rest[4:]] = v
+    else:
+      arrays[rest] = z[key]
+  return [out[k] for k in sorted(out)]
+
+
 def project_kwargs(cfg, intrinsics_fn):
   """Split a MapProjector config into orth_project keyword arguments the way
   MapProjector.orth_project forwards them (reference maps.py:1438-1465)."""

@@ -480,6 +480,57 @@ def g10(dmap):
   save("g10_known_answers", **arrays)
 
 
+def g11(dmap):
+  """Seeded sweep over the projector's parameter space: 12 configurations x 2 frames,
+  each frame one B=1 reference call (pitch of either sign, non-square pixels, offsets,
+  flips, local/global, border, truncations, valid maps, min/max, finite fills)."""
+  rng = np.random.default_rng(1111)
+  arrays = {}
+  for k in range(12):
+    B, h, w = 2, 40, 56
+    mh, mw = [(48, 64), (64, 48), (56, 56)][k % 3]
+    hfov = float(rng.uniform(0.8, 1.7))
+    pitch = rng.uniform(-0.7, 0.4, size=B).astype(np.float32)
+    camh = rng.uniform(0.3, 1.5, size=B).astype(np.float32)
+    if k % 2:
+      depth = np.stack([scene_depth(rng, h, w, hfov, float(pitch[b]), float(camh[b]))
+                        for b in range(B)])[:, None]
+    else:
+      depth = rng.uniform(0.1, 8.0, size=(B, 1, h, w)).astype(np.float32)
+    pose = np.stack([rng.uniform(-1, 1, B), rng.uniform(-1, 1, B),
+                     rng.uniform(-np.pi, np.pi, B)], axis=1).astype(np.float32)
+    is_max = bool(k % 4 != 3)
+    cfg = dict(width=w, height=h, hfov=hfov,
+               vfov=None if k % 2 else float(rng.uniform(0.7, 1.4)),
+               map_res=float(rng.choice([0.05, 0.08, 0.1])), map_width=mw, map_height=mh,
+               trunc_depth_min=float(rng.choice([0.0, 0.15, 0.5])),
+               trunc_depth_max=float(rng.choice([2.5, 5.05, 7.0])),
+               trunc_height_max=None if k % 3 else float(rng.uniform(0.2, 1.2)),
+               clip_border=int(rng.choice([0, 0, 3])),
+               to_global=bool(k % 5 != 0), flip_h=bool(k % 6 != 1),
+               fill_value=(-np.inf if is_max else np.inf) if k % 3 else float(rng.uniform(-1, 1)),
+               reduction="max" if is_max else "min")
+    woff = (mw / 2 + rng.uniform(-10, 10, size=B)).astype(np.float32)
+    hoff = (mh / 2 + rng.uniform(-10, 10, size=B)).astype(np.float32)
+    valid = (rng.uniform(size=(B, 1, h, w)) > 0.1) if k % 4 == 2 else None
+    tops, masks = [], []
+    for b in range(B):
+      call = dict(cam_pose=pose[b], cam_pitch=pitch[b:b + 1], cam_height=camh[b:b + 1],
+                  width_offset=woff[b:b + 1], height_offset=hoff[b:b + 1])
+      r = run_orth(dmap, cfg, depth[b], valid=None if valid is None else valid[b],
+                   call_kwargs=call, intermediates=False)
+      tops.append(r["topdown"]); masks.append(r["mask"])
+    arrays.update({f"k{k}_depth": depth, f"k{k}_cam_pose": pose, f"k{k}_cam_pitch": pitch,
+                   f"k{k}_cam_height": camh, f"k{k}_width_offset": woff,
+                   f"k{k}_height_offset": hoff, f"k{k}_topdown": np.concatenate(tops, axis=0),
+                   f"k{k}_mask": np.concatenate(masks, axis=0)})
+    if valid is not None:
+      arrays[f"k{k}_valid_map"] = valid
+    for name, v in cfg.items():
+      arrays[f"k{k}_cfg_{name}"] = np.array(np.nan) if v is None else np.asarray(v)
+  save("g11_parameter_sweep_56x40", **arrays)
+
+
 def main():
   torch.set_num_threads(1)
   torch.manual_seed(0)
@@ -493,6 +544,7 @@ def main():
   g8(dmap)
   g9(dmap)
   g10(dmap)
+  g11(dmap)
 
 
 if __name__ == "__main__":

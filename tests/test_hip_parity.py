@@ -129,6 +129,17 @@ def test_random_depth_vs_oracle(dmap, oracle, B, H, W, mh, mw):
   np.testing.assert_array_equal(outs[0], want[0])
 
 
+@pytest.mark.parametrize("k", range(12))
+def test_golden_parameter_sweep(dmap, k):
+  """g11: 12 seeded configurations run by the reference itself; HIP path bit-equal."""
+  from conftest import load_sweep
+  g, cfg = load_sweep()[k]
+  call = {n: g[n] for n in ("cam_pose", "cam_pitch", "cam_height", "width_offset", "height_offset")}
+  outs = _run(dmap, cfg, g["depth"], valid=g.get("valid_map"), **call)
+  np.testing.assert_array_equal(outs[1], g["mask"])
+  np.testing.assert_array_equal(outs[0], g["topdown"])
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_configurations_vs_oracle(dmap, oracle, seed):
   """Seeded sweep over the projector's parameter space (pitch of either sign, non-square

@@ -8,7 +8,7 @@ relative for the order-dependent sum/mean/prod.
 import numpy as np
 import pytest
 
-from conftest import load_golden, project_kwargs
+from conftest import load_golden, load_sweep, project_kwargs
 
 
 def _check_debug(dbg, g):
@@ -126,3 +126,16 @@ def test_fused_equals_max_over_frames(oracle):
   fused = oracle.orth_project(g["depth"], fused=True, **kw)
   _same(fused[0], per_frame[0].max(axis=0))
   np.testing.assert_array_equal(fused[1], per_frame[1].any(axis=0))
+
+
+@pytest.mark.parametrize("k", range(12))
+def test_parameter_sweep(oracle, k):
+  """g11: 12 seeded configurations run by the reference (pitch of either sign, vfov,
+  offsets, flips, local/global, border, truncations, valid maps, min/max, finite fills)."""
+  g, cfg = load_sweep()[k]
+  kw = project_kwargs(cfg, oracle.camera_intrinsics)
+  for name in ("cam_pose", "cam_pitch", "cam_height", "width_offset", "height_offset"):
+    kw[name] = g[name]
+  top, mask = oracle.orth_project(g["depth"], valid_map=g.get("valid_map"), **kw)
+  np.testing.assert_array_equal(mask, g["mask"])
+  _same(top, g["topdown"])

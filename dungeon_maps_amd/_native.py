@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DUNGEON_MAPS_AMD_LIB") or os.path.join(
     HERE, "csrc", "libdungeon_maps_amd.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # dm_reduction
 REDUCE_MAX, REDUCE_MIN, REDUCE_SUM, REDUCE_MEAN, REDUCE_PROD = range(5)

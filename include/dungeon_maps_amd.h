@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 2
+#define DM_ABI_VERSION 3
 
 typedef enum dm_status {
   DM_OK = 0,

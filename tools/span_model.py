@@ -136,3 +136,42 @@ def shear_main():
   print("unclipped bbox cells/part %.0f   sheared window cells/part %.0f   (%s)" % (tot_b / 64, tot_s / 64, majors))
 
 shear_main()
+
+
+def bearing_main():
+  """Window (bounding box) sizes if the pixels are partitioned by top-down bearing instead of
+  by image column: each part's footprint is then an exact wedge."""
+  W, H, mh, mw = 640, 480, 512, 512
+  hfov = np.radians(70.); pitch = np.radians(-20.)
+  cx, cy = W / 2., H / 2.
+  fx = cx / np.tan(hfov / 2.); fy = fx
+  c, s = np.cos(pitch), np.sin(pitch)
+  # local z of a unit-depth pixel: z1 = p8 + p5*ay with (row-vector convention) p5 = -s ... use the model's matrices
+  ays = np.array([((H - 1 - r) - cy) / fy for r in (0, H - 1)])
+  Rx = np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+  den = np.array([(np.array([0, a, 1.0]) @ Rx)[2] for a in ays])
+  dmin, dmax, res = 0.15, 5.05, 0.03
+  axe = (np.array([0, W - 1]) - cx) / fx
+  kap_out = [axe[0] / den.min(), axe[1] / den.min()]
+  kaps = [kap_out[0], axe[0] / 2 / 1.0 * 0 + (160 - cx) / fx / den.mean(), 0.0, (480 - cx) / fx / den.mean(), kap_out[1]]
+  rng = np.random.default_rng(0)
+  tot = 0; n = 0; skew = 0
+  for f in range(16):
+    tx, tz = rng.uniform(-1, 1, 2); yaw = rng.uniform(-np.pi, np.pi)
+    cyw, syw = np.cos(yaw), np.sin(yaw)
+    for p in range(4):
+      pts = []
+      for k in (kaps[p], kaps[p + 1]):
+        for z1 in (dmin * den.min(), dmax * den.max()):
+          x1 = k * z1
+          v = np.array([x1, 0, z1]) @ np.array([[cyw, 0, syw], [0, 1, 0], [-syw, 0, cyw]]) + np.array([tx, 0, tz])
+          pts.append((v[0] / res + mw / 2 + 0.5, (mh - 1) - (v[2] / res + mh / 2) + 0.5))
+      pts = np.array(pts)
+      w = (np.floor(pts[:, 0].max()) + 3) - (np.floor(pts[:, 0].min()) - 2) + 3
+      h = (np.floor(pts[:, 1].max()) + 3) - (np.floor(pts[:, 1].min()) - 2)
+      tot += w * h; n += 1
+    for k in kaps[1:4]:
+      skew = max(skew, abs(fx * k * (den.max() - den.min())))
+  print("bearing-partition bbox cells/part %.0f (column strips: 21516); halo columns needed: %.0f" % (tot / n, skew))
+
+bearing_main()

@@ -146,7 +146,7 @@ def main():
   # once per RING steps ONE RCCL all-reduce(max) fuses the whole ring (fewer, larger
   # collectives: xGMI rings are latency bound at 1 MiB) on RCCL's own stream while the
   # next steps project; the masks of the reduced maps are recomputed afterwards.
-  RING = 8
+  RING = int(os.environ.get("DM_BENCH_RING", "32"))
   C_out = C if C else 1
   ring = ring_mask = None
   if dist is not None:

@@ -86,8 +86,14 @@ __host__ Parts choose_parts(const dm_params& p, int min_parts = 1) {
   // enough workgroups to fill 256 CUs (and at least min_parts, so that windows fit
   // in LDS), parts not smaller than 32 columns, strip boundaries on 128-byte lines
   // (32 floats) when W allows it
+  // ... but not more than pays: the scatter kernel of a small batch is latency bound
+  // (~6 us + 0.3 us per pixel and thread), the merge kernel visits every part per cell
+  // (~0.37 us per part), so the sum is smallest near sqrt(0.8 * pixels / 1024) parts
+  // (measured at B = 1, 320x240: 80 parts 43 us, 10 parts 15 us)
   const long frames = (long)p.B * (p.vc ? p.vc : p.dc);
   int want = (int)((256 + frames - 1) / frames);
+  const int pays = (int)lround(sqrt(0.8 * (double)p.H * p.W / 1024.0));
+  if (want > pays) want = pays;
   if (want < min_parts) want = min_parts;
   if (want < 1) want = 1;
   Parts s;

@@ -29,6 +29,21 @@ class Params(ctypes.Structure):
           "cx", "cy", "fx", "fy", "res", "fill", "dmin", "dmax", "hmax")]
 
 
+FUSE_MAX_BATCH = 8
+
+
+class FuseSrc(ctypes.Structure):
+  """dm_fuse_src"""
+  _fields_ = [("height_dev", ctypes.c_void_p), ("mask_dev", ctypes.c_void_p),
+              ("value_dev", ctypes.c_void_p)] + [
+      (n, ctypes.c_int32) for n in ("b", "c", "hc", "mc", "h", "w", "flip_h", "has_l2g",
+                                    "has_g2l")] + [
+      ("res", ctypes.c_float), ("target_res", ctypes.c_float),
+      ("woff", ctypes.c_float * FUSE_MAX_BATCH), ("hoff", ctypes.c_float * FUSE_MAX_BATCH),
+      ("l2g", (ctypes.c_float * 12) * FUSE_MAX_BATCH),
+      ("g2l", (ctypes.c_float * 12) * FUSE_MAX_BATCH)]
+
+
 class NativeError(RuntimeError):
   pass
 
@@ -46,6 +61,11 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dm_debug_force_generic_path": (ctypes.c_int, [ctypes.c_int]),
+    "dm_fuse_bbox_f32": (ctypes.c_int, [
+        ctypes.POINTER(FuseSrc), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "dm_fuse_scatter_f32": (ctypes.c_int, [
+        ctypes.POINTER(FuseSrc), ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int64,
+        ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dm_crop_nearest_f32": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
         ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int,

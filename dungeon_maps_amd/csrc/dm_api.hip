@@ -157,6 +157,50 @@ int dm_camera_affine_grid_f32(const dm_params* p, const dm_frame* frames, const 
   return DM_OK;
 }
 
+static int check_fuse_src(const dm_fuse_src* s) {
+  if (!s) return fail(DM_ERR_INVALID_ARGUMENT, "src is NULL");
+  if (s->b < 0 || s->b > DM_FUSE_MAX_BATCH || s->c < 0 || s->c > 65535 || s->h < 1 || s->w < 1 ||
+      (int64_t)s->h * s->w >= (1ll << 31) || (s->hc != 1 && s->hc != s->c) ||
+      (s->mc != 1 && s->mc != s->c))
+    return fail(DM_ERR_INVALID_ARGUMENT, "bad source map b=%d c=%d hc=%d mc=%d %dx%d", s->b, s->c,
+                s->hc, s->mc, s->h, s->w);
+  if (s->b && s->c && (!s->height_dev || !s->mask_dev))
+    return fail(DM_ERR_INVALID_ARGUMENT, "height/mask must not be NULL");
+  return DM_OK;
+}
+
+int dm_fuse_bbox_f32(const dm_fuse_src* src, int32_t* stats_dev, int init, void* stream) {
+  const int rc = check_fuse_src(src);
+  if (rc != DM_OK) return rc;
+  if (!stats_dev) return fail(DM_ERR_INVALID_ARGUMENT, "stats is NULL");
+  if (src->b == 0 || src->c == 0)
+    return fail(DM_ERR_INVALID_ARGUMENT, "empty source map");
+  const dm_fuse_src& s = *src;
+  hipError_t e = hipSuccess;
+  e = dm::run_fuse_bbox(s, stats_dev, init, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
+int dm_fuse_scatter_f32(const dm_fuse_src* src, float width_offset, float height_offset, int flip_h,
+                        int64_t map_height, int64_t map_width, int reduction, float* canvas_dev,
+                        float* height_canvas_dev, void* stream) {
+  const int rc = check_fuse_src(src);
+  if (rc != DM_OK) return rc;
+  if (reduction != DM_REDUCE_MAX && reduction != DM_REDUCE_MIN)
+    return fail(DM_ERR_UNSUPPORTED, "fused map scatter supports max/min only (got %d)", reduction);
+  if (map_height < 1 || map_width < 1 || map_height * map_width >= (1ll << 31))
+    return fail(DM_ERR_INVALID_ARGUMENT, "bad target size %lldx%lld", (long long)map_height,
+                (long long)map_width);
+  if (src->b == 0 || src->c == 0) return DM_OK;
+  if (!canvas_dev) return fail(DM_ERR_INVALID_ARGUMENT, "canvas is NULL");
+  hipError_t e = dm::run_fuse_scatter(*src, width_offset, height_offset, flip_h, (int)map_height,
+                                      (int)map_width, reduction == DM_REDUCE_MAX, canvas_dev,
+                                      height_canvas_dev, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
 int dm_crop_nearest_f32(const float* image_dev, const uint8_t* mask_dev, const float* center_dev,
                         int64_t B, int64_t C, int64_t h, int64_t w, int64_t crop_h, int64_t crop_w,
                         float fill, int has_fill, float* out_dev, uint8_t* out_mask_dev,

@@ -347,4 +347,126 @@ hipError_t run_crop_nearest(const float* src, const uint8_t* src_mask, const flo
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// fuse_topdown_maps (maps.py:2039-2287): see include/dungeon_maps_amd.h
+// ---------------------------------------------------------------------------
+namespace {
+
+// cell (row, col) of batch row bi -> its point in the target's frame
+__device__ inline void fuse_point(const dm_fuse_src& s, int bi, int row, int col, float y,
+                                  float& xo, float& yo, float& zo) {
+  float r = (float)row;
+  if (s.flip_h) r = (float)(s.h - 1) - r;                       // maps.py:1074-1076
+  float p0 = ((float)col - s.woff[bi]) * s.res;                  // maps.py:1078-1079
+  float p1 = y;
+  float p2 = (r - s.hoff[bi]) * s.res;
+  if (s.has_l2g) {                                               // rotate, then translate
+    const float* m = s.l2g[bi];
+    const float o0 = __builtin_fmaf(p2, m[6], __builtin_fmaf(p1, m[3], p0 * m[0])) + m[9];
+    const float o1 = __builtin_fmaf(p2, m[7], __builtin_fmaf(p1, m[4], p0 * m[1])) + m[10];
+    const float o2 = __builtin_fmaf(p2, m[8], __builtin_fmaf(p1, m[5], p0 * m[2])) + m[11];
+    p0 = o0; p1 = o1; p2 = o2;
+  }
+  if (s.has_g2l) {                                               // translate, then rotate
+    const float* m = s.g2l[bi];
+    p0 += m[9]; p1 += m[10]; p2 += m[11];
+    const float o0 = __builtin_fmaf(p2, m[6], __builtin_fmaf(p1, m[3], p0 * m[0]));
+    const float o1 = __builtin_fmaf(p2, m[7], __builtin_fmaf(p1, m[4], p0 * m[1]));
+    const float o2 = __builtin_fmaf(p2, m[8], __builtin_fmaf(p1, m[5], p0 * m[2]));
+    p0 = o0; p1 = o1; p2 = o2;
+  }
+  xo = p0; yo = p1; zo = p2;
+}
+
+__device__ inline int sat_i32(float f) {      // floor result -> int32, saturating; NaN -> INT_MIN
+  if (!(f == f)) return (int)0x80000000;
+  if (f >= 2147483520.0f) return 0x7fffffff;
+  if (f <= -2147483648.0f) return (int)0x80000000;
+  return (int)f;
+}
+
+__global__ void k_fuse_stats_init(int* stats) {
+  if (threadIdx.x == 0) {
+    stats[0] = 0x7fffffff; stats[1] = (int)0x80000000;
+    stats[2] = 0x7fffffff; stats[3] = (int)0x80000000; stats[4] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_fuse_bbox(dm_fuse_src s, int* __restrict__ stats) {
+  __shared__ int sh[5];
+  if (threadIdx.x < 5)
+    sh[threadIdx.x] = (threadIdx.x == 0 || threadIdx.x == 2) ? 0x7fffffff
+                    : (threadIdx.x == 4 ? 0 : (int)0x80000000);
+  __syncthreads();
+  const int bi = blockIdx.z, ci = blockIdx.y;
+  const int n = s.h * s.w;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const size_t plane = (size_t)s.h * s.w;
+    if (s.mask_dev[((size_t)bi * s.mc + (s.mc == 1 ? 0 : ci)) * plane + i]) {
+      const int row = i / s.w, col = i - row * s.w;
+      const float y = s.height_dev[((size_t)bi * s.hc + (s.hc == 1 ? 0 : ci)) * plane + i];
+      float x, yy, z;
+      fuse_point(s, bi, row, col, y, x, yy, z);
+      // map_quantize with zero offsets, unflipped (maps.py:2146-2160)
+      const int c0 = sat_i32(__builtin_floorf((x / s.target_res + 0.0f) + 0.5f));
+      const int r0 = sat_i32(__builtin_floorf((z / s.target_res + 0.0f) + 0.5f));
+      atomicMin(&sh[0], c0); atomicMax(&sh[1], c0);
+      atomicMin(&sh[2], r0); atomicMax(&sh[3], r0);
+      sh[4] = 1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && sh[4]) {
+    atomicMin(&stats[0], sh[0]); atomicMax(&stats[1], sh[1]);
+    atomicMin(&stats[2], sh[2]); atomicMax(&stats[3], sh[3]);
+    atomicOr(&stats[4], 1);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_fuse_scatter(dm_fuse_src s, float woff, float hoff, int flip, float mhm1, int mh, int mw,
+               int is_max, float* __restrict__ canvas, float* __restrict__ hcanvas) {
+  const int bi = blockIdx.z, ci = blockIdx.y;
+  const int n = s.h * s.w;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t plane = (size_t)s.h * s.w;
+  if (!s.mask_dev[((size_t)bi * s.mc + (s.mc == 1 ? 0 : ci)) * plane + i]) return;
+  const int row = i / s.w, col = i - row * s.w;
+  const float y = s.height_dev[((size_t)bi * s.hc + (s.hc == 1 ? 0 : ci)) * plane + i];
+  float x, yy, z;
+  fuse_point(s, bi, row, col, y, x, yy, z);
+  const float xf = x / s.target_res + woff;                     // maps.py:1004-1015
+  float zf = z / s.target_res + hoff;
+  if (flip) zf = mhm1 - zf;
+  const float cf = __builtin_floorf(xf + 0.5f), rf = __builtin_floorf(zf + 0.5f);
+  if (!(cf >= 0.0f && cf < (float)mw && rf >= 0.0f && rf < (float)mh)) return;   // maps.py:1150-1158
+  const size_t cell = (size_t)(int)rf * mw + (int)cf;
+  const size_t M = (size_t)mh * mw;
+  const float v = s.value_dev ? s.value_dev[((size_t)bi * s.c + ci) * plane + i] : yy;
+  float* dst = canvas + ((size_t)bi * s.c + ci) * M + cell;
+  if (is_max) atomic_max_f(dst, v); else atomic_min_f(dst, v);
+  // (per channel: a cell counts where THIS channel's mask is set, maps.py:2257-2272)
+  if (hcanvas) atomic_max_f(hcanvas + ((size_t)bi * s.c + ci) * M + cell, yy);
+}
+
+}  // namespace
+
+hipError_t run_fuse_bbox(const dm_fuse_src& s, int* stats, int init, hipStream_t st) {
+  if (init) hipLaunchKernelGGL(k_fuse_stats_init, dim3(1), dim3(64), 0, st, stats);
+  const dim3 g((unsigned)(((size_t)s.h * s.w + 255) / 256), s.c, s.b);
+  hipLaunchKernelGGL(k_fuse_bbox, g, dim3(256), 0, st, s, stats);
+  return hipGetLastError();
+}
+
+hipError_t run_fuse_scatter(const dm_fuse_src& s, float woff, float hoff, int flip, int mh, int mw,
+                            int is_max, float* canvas, float* hcanvas, hipStream_t st) {
+  const dim3 g((unsigned)(((size_t)s.h * s.w + 255) / 256), s.c, s.b);
+  hipLaunchKernelGGL(k_fuse_scatter, g, dim3(256), 0, st, s, woff, hoff, flip, (float)(mh - 1), mh,
+                     mw, is_max, canvas, hcanvas);
+  return hipGetLastError();
+}
+
 }  // namespace dm

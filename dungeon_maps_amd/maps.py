@@ -5,6 +5,7 @@ constructor keywords, properties and method names.  ``MapProjector`` is the
 configuration holder: every functional API is reachable as a method whose
 ``None`` arguments fall back to the projector's stored defaults.
 """
+import ctypes
 import inspect
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -247,6 +248,118 @@ def _map_points(source: TopdownMap):
   return points, mask, values
 
 
+def _unbroadcast_channels(t: torch.Tensor) -> torch.Tensor:
+  """(b, c, h, w) tensor; a channel-broadcast view (stride 0) goes back to (b, 1, h, w)."""
+  if t.dim() == 4 and t.shape[1] > 1 and t.stride(1) == 0:
+    t = t[:, :1]
+  return t.contiguous()
+
+
+def _pose_rows(pose, b: int) -> torch.Tensor:
+  p = utils.to_tensor(pose).to(torch.float32).reshape(-1, 3).cpu()
+  return p.expand(b, 3) if p.shape[0] == 1 and b > 1 else p
+
+
+def _fuse_source(m: TopdownMap, proj: MapProjector, dev):
+  """dm_fuse_src of one source map (reference maps.py:2039-2069, 2137-2144), or None if it
+  cannot go through the native path."""
+  from . import _native
+  sp = m.proj
+  hm = _unbroadcast_channels(m.height_map.to(dev, torch.float32))
+  b, hc, h, w = hm.shape
+  mk = _unbroadcast_channels(m.mask.to(dev, torch.bool))
+  val = None if m.is_height_map else m.topdown_map.to(dev, torch.float32).contiguous()
+  c = hc if val is None else val.shape[1]
+  if b > _native.FUSE_MAX_BATCH or mk.shape[1] not in (1, c) or hc not in (1, c):
+    return None
+  if sp.map_height != h:
+    return None
+  src = _native.FuseSrc()
+  src.height_dev, src.mask_dev = hm.data_ptr(), mk.data_ptr()
+  src.value_dev = None if val is None else val.data_ptr()
+  src.b, src.c, src.hc, src.mc, src.h, src.w = b, c, hc, mk.shape[1], h, w
+  src.flip_h = int(bool(sp.flip_h))
+  src.res, src.target_res = float(sp.map_res), float(proj.map_res)
+  woff = utils.to_tensor(sp.width_offset).to(torch.float32).reshape(-1).cpu()
+  hoff = utils.to_tensor(sp.height_offset).to(torch.float32).reshape(-1).cpu()
+  for i in range(b):
+    src.woff[i] = float(woff[i if woff.numel() > 1 else 0])
+    src.hoff[i] = float(hoff[i if hoff.numel() > 1 else 0])
+  src.has_l2g = int(sp.to_global is False)
+  if src.has_l2g:       # local_to_global_space: rotate by yaw, then + (x, 0, z)
+    pose = _pose_rows(sp.cam_pose, b)
+    rot = utils.rotation_matrix(torch.tensor([[0., 1., 0.]]), pose[:, 2].contiguous()).reshape(-1, 9)
+    for i in range(b):
+      row = rot[i].tolist() + [float(pose[i, 0]), 0.0, float(pose[i, 1])]
+      for k in range(12):
+        src.l2g[i][k] = row[k]
+  src.has_g2l = int(proj.to_global is False)
+  if src.has_g2l:       # global_to_local_space: - (x, 0, z), then rotate by -yaw
+    pose = _pose_rows(proj.cam_pose, b)
+    rot = utils.rotation_matrix(torch.tensor([[0., 1., 0.]]), (-pose[:, 2]).contiguous()).reshape(-1, 9)
+    for i in range(b):
+      row = rot[i].tolist() + [float(-pose[i, 0]), -0.0, float(-pose[i, 1])]
+      for k in range(12):
+        src.g2l[i][k] = row[k]
+  return src, (hm, mk, val)      # keep the tensors alive
+
+
+def _fuse_topdown_maps_native(maps, proj: MapProjector, fill_value, reduction):
+  """fuse_topdown_maps on dm_fuse_bbox_f32 / dm_fuse_scatter_f32 (two kernels per source
+  map and one copy of five ints instead of ~80 torch kernels); None if not applicable."""
+  from . import _native
+  red = utils.Reduction(get(reduction, proj.reduction, "max")).value
+  if red not in ("max", "min"):
+    return None
+  live = [m for m in maps if not m.is_empty]
+  dev = live[0].height_map.device
+  if dev.type != "cuda" or len({m.is_height_map for m in live}) != 1:
+    return None
+  is_height_map = live[0].is_height_map
+  srcs = [_fuse_source(m, proj, dev) for m in live]
+  if any(s is None for s in srcs):
+    return None
+  b, c = srcs[0][0].b, srcs[0][0].c
+  hc = max(s[0].hc for s in srcs)
+  if any((s[0].b, s[0].c) != (b, c) for s in srcs) or any(s[0].hc != hc for s in srcs):
+    return None
+  lib = _native.lib()
+  stream = F._stream_ptr(dev)
+  with torch.cuda.device(dev):
+    stats = torch.empty(5, dtype=torch.int32, device=dev)
+    for i, (src, _) in enumerate(srcs):
+      _native.check(lib.dm_fuse_bbox_f32(ctypes.byref(src), stats.data_ptr(), int(i == 0), stream))
+    min_x, max_x, min_z, max_z, any_valid = stats.cpu().tolist()        # the one host sync
+    if not any_valid:
+      last = maps[-1]
+      return TopdownMap(topdown_map=last.topdown_map, mask=last.mask, height_map=last.height_map,
+                        map_projector=proj)
+    map_width = int(max_x - min_x) + 2
+    map_height = int(max_z - min_z) + 2
+    f32 = np.float32
+    woff_v = f32(map_width / 2.) - f32(max_x + min_x) / f32(2.)
+    hoff_v = f32(map_height / 2.) - f32(max_z + min_z) / f32(2.)
+    fill = get(fill_value, proj.fill_value, NINF)
+    topdown = torch.full((b, c, map_height, map_width), float(fill), dtype=torch.float32, device=dev)
+    heights = None
+    if not is_height_map:
+      heights = torch.full((b, c, map_height, map_width), float(NINF), dtype=torch.float32, device=dev)
+    code = _native.REDUCE_MAX if red == "max" else _native.REDUCE_MIN
+    for src, _ in srcs:
+      _native.check(lib.dm_fuse_scatter_f32(
+          ctypes.byref(src), float(woff_v), float(hoff_v), int(bool(proj.flip_h)), map_height,
+          map_width, code, topdown.data_ptr(), None if heights is None else heights.data_ptr(),
+          stream))
+    new_mask = F.mask_from_map(topdown, fill)
+  height_map = topdown if is_height_map else heights
+  woff = torch.tensor([woff_v], dtype=torch.float32)
+  hoff = torch.tensor([hoff_v], dtype=torch.float32)
+  new_proj = proj.clone(width_offset=woff, height_offset=hoff, map_width=map_width,
+                        map_height=map_height)
+  return TopdownMap(topdown_map=topdown, mask=new_mask, height_map=height_map,
+                    map_projector=new_proj, is_height_map=is_height_map)
+
+
 def fuse_topdown_maps(*maps: TopdownMap, map_projector: Optional[MapProjector] = None,
                       fill_value: Optional[float] = None,
                       reduction: Optional[Reduction] = None) -> TopdownMap:
@@ -268,9 +381,12 @@ def fuse_topdown_maps(*maps: TopdownMap, map_projector: Optional[MapProjector] =
     map_projector = maps[0].proj
   proj = map_projector
   assert proj is not None, "map_projector is not provided"
-  clouds = [_map_points(m) for m in maps if not m.is_empty]
-  if not clouds:
+  if all(m.is_empty for m in maps):
     return TopdownMap(map_projector=map_projector)
+  fused = _fuse_topdown_maps_native(maps, proj, fill_value, reduction)
+  if fused is not None:
+    return fused
+  clouds = [_map_points(m) for m in maps if not m.is_empty]
   kinds = {c[2] is None for c in clouds}
   assert len(kinds) == 1, "All maps must be the same type of maps (height or value maps)"
   is_height_map = clouds[0][2] is None

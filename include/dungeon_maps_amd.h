@@ -154,6 +154,45 @@ int dm_camera_affine_grid_f32(const dm_params* p, const dm_frame* frames,
                               void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /*
+ * fuse_topdown_maps (maps.py:2039-2287) without materialised point clouds.  Every valid
+ * cell of a source map becomes a point at its cell centre (map_dequantize, maps.py:1021-1087:
+ * x = (col - woff) * res, z = ((flip ? (mh-1) - row : row) - hoff) * res, y = height), goes
+ * local -> global with the map's own pose (rotate, then translate; skipped if the map is
+ * already global) and global -> local with the target's (translate, then rotate; skipped
+ * for a global target), and is quantised in the target frame (map_quantize).
+ *   dm_fuse_bbox_f32     quantises with zero offsets, unflipped, and reduces the bounding
+ *                        box of the valid cells into stats_dev[5] = {min col, max col,
+ *                        min row, max row, any valid} (int32; init != 0 resets it first)
+ *                        -- the reference's two .item() syncs become one copy of 5 ints.
+ *   dm_fuse_scatter_f32  quantises with the final offsets / flip / size and reduces
+ *                        (max or min) the cell's value (value_dev, or its height) into
+ *                        canvas_dev (b, c, mh, mw) and, if height_canvas_dev is given, its
+ *                        height (max) into that (b, c, mh, mw) as well.  The canvases must hold
+ *                        their fill values; masks follow with dm_mask_from_map_f32.
+ * Rotations are row-major 3x3 as utils.py:326-327, applied as the reference's FMA chain.
+ */
+#define DM_FUSE_MAX_BATCH 8
+typedef struct dm_fuse_src {
+  const float* height_dev;    /* (b, hc, h, w) cell heights */
+  const uint8_t* mask_dev;    /* (b, mc, h, w) valid cells */
+  const float* value_dev;     /* (b, c, h, w) or NULL: the heights are the values */
+  int32_t b, c, hc, mc;       /* hc, mc in {1, c} */
+  int32_t h, w;
+  int32_t flip_h;             /* source map's flip_h */
+  int32_t has_l2g, has_g2l;
+  float res;                  /* source map_res */
+  float target_res;           /* target map_res */
+  float woff[DM_FUSE_MAX_BATCH], hoff[DM_FUSE_MAX_BATCH];       /* source offsets per batch row */
+  float l2g[DM_FUSE_MAX_BATCH][12];   /* R (9) | t (3): out = rotate(p) + t */
+  float g2l[DM_FUSE_MAX_BATCH][12];   /* R (9) | t (3): out = rotate(p + t) */
+} dm_fuse_src;
+
+int dm_fuse_bbox_f32(const dm_fuse_src* src, int32_t* stats_dev, int init, void* stream);
+int dm_fuse_scatter_f32(const dm_fuse_src* src, float width_offset, float height_offset,
+                        int flip_h, int64_t map_height, int64_t map_width, int reduction,
+                        float* canvas_dev, float* height_canvas_dev, void* stream);
+
+/*
  * crop_topdown_map / TopdownMap.select (maps.py:1959-2037): generate_crop_grid
  * (utils.py:571-611) + image_sample(mode='nearest') (utils.py:613-652) fused into one
  * gather.  image_dev (B, C, h, w) f32; mask_dev (B, C, h, w) uint8/bool or NULL (the

@@ -1,0 +1,69 @@
+"""One-off parity campaign (GPU box): the seeded parameter sweep of
+tests/test_hip_parity.py::test_random_configurations_vs_oracle for many more seeds, plus
+larger frames; prints every mismatch.  Usage: python tools/parity_campaign.py [first] [count]"""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import dungeon_maps_amd as dmap
+from oracle import oracle
+from conftest import project_kwargs
+
+def one(seed):
+  rng = np.random.default_rng(50_000 + seed)
+  B = int(rng.choice([1, 2, 3, 5, 9, 17, 33, 40, 64, 70]))
+  H, W = [(48, 64), (60, 80), (96, 128), (50, 70), (120, 160), (240, 320)][int(rng.integers(6))]
+  if B * H * W > 3_000_000:
+    B = max(1, 3_000_000 // (H * W))
+  mh, mw = [(64, 64), (96, 128), (128, 96), (160, 160), (256, 256), (300, 200)][int(rng.integers(6))]
+  if rng.integers(2):
+    rows = np.arange(H, dtype=np.float64).reshape(1, 1, H, 1)
+    wall = rng.uniform(1.0, 6.0, size=(B, 1, 1, W // 8 + 1)).repeat(8, axis=3)[..., :W]
+    floor = 0.9 / np.maximum(0.05, (rows - H * 0.45) / (H * 0.9))
+    depth = np.broadcast_to(np.minimum(floor, wall).astype(np.float32), (B, 1, H, W)).copy()
+  else:
+    depth = rng.uniform(0.1, 8.0, size=(B, 1, H, W)).astype(np.float32)
+  pose = np.stack([rng.uniform(-2, 2, B), rng.uniform(-2, 2, B), rng.uniform(-np.pi, np.pi, B)],
+                  axis=1).astype(np.float32)
+  per_frame = bool(rng.integers(2))
+  pitch = rng.uniform(-0.9, 0.5, size=B if per_frame else 1).astype(np.float32)
+  camh = rng.uniform(0.2, 2.0, size=B if per_frame else 1).astype(np.float32)
+  is_max = bool(rng.integers(4))
+  res = float(rng.choice([0.02, 0.03, 0.05, 0.08, 0.1, 1.0 / 3, 0.0625]))
+  cfg = dict(width=W, height=H, hfov=float(rng.uniform(0.6, 2.0)),
+             vfov=None if rng.integers(2) else float(rng.uniform(0.5, 1.6)),
+             cam_pitch=pitch, cam_height=camh,
+             width_offset=float(mw / 2 + rng.uniform(-40, 40)),
+             height_offset=float(mh / 2 + rng.uniform(-40, 40)),
+             map_res=res, map_width=mw, map_height=mh,
+             trunc_depth_min=float(rng.choice([0.0, 0.15, 0.5])),
+             trunc_depth_max=float(rng.choice([1.5, 2.5, 5.05, 7.0])),
+             trunc_height_max=None if rng.integers(3) else float(rng.uniform(0.2, 1.2)),
+             clip_border=int(rng.choice([0, 0, 3, 9])),
+             to_global=bool(rng.integers(2)), flip_h=bool(rng.integers(4)),
+             fill_value=(-np.inf if is_max else np.inf) if rng.integers(3) else float(rng.uniform(-1, 1)),
+             reduction="max" if is_max else "min")
+  valid = (rng.uniform(size=(B, 1, H, W)) > 0.1) if rng.integers(3) == 0 else None
+  proj = dmap.MapProjector(**cfg)
+  outs = proj.orth_project(torch.from_numpy(depth).cuda(),
+                           valid_map=None if valid is None else torch.from_numpy(valid).cuda(),
+                           cam_pose=pose)
+  kw = dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose)
+  want = oracle.orth_project(depth, valid_map=valid, nthreads=16, **kw)
+  got = [o.cpu().numpy() for o in outs]
+  bad_m = int((got[1] != want[1]).sum())
+  a, b = got[0], want[0]
+  bad_v = int((~((a == b) | (np.isnan(a) & np.isnan(b)))).sum())
+  return bad_m, bad_v, (B, H, W, mh, mw, res)
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+bad = 0
+for s in range(first, first + count):
+  bm, bv, shape = one(s)
+  if bm or bv:
+    bad += 1
+    print("MISMATCH seed", s, shape, "mask cells", bm, "map cells", bv, flush=True)
+  if (s - first) % 50 == 49:
+    print("  ... %d configurations, %d with mismatches" % (s - first + 1, bad), flush=True)
+print("done: %d configurations, %d with mismatches" % (count, bad))

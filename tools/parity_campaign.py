@@ -44,18 +44,30 @@ def one(seed):
              fill_value=(-np.inf if is_max else np.inf) if rng.integers(3) else float(rng.uniform(-1, 1)),
              reduction="max" if is_max else "min")
   valid = (rng.uniform(size=(B, 1, H, W)) > 0.1) if rng.integers(3) == 0 else None
+  value = None
+  C = int(rng.choice([0, 0, 3, 9])) if SEMANTIC else 0
+  if C and B * C * H * W <= 6_000_000:      # value maps: one-hot labels or random reals
+    if rng.integers(2):
+      value = np.eye(C, dtype=np.float32)[rng.integers(0, C, size=(B, H, W))].transpose(0, 3, 1, 2).copy()
+    else:
+      value = rng.normal(size=(B, C, H, W)).astype(np.float32)
   proj = dmap.MapProjector(**cfg)
+  get_h = value is not None
   outs = proj.orth_project(torch.from_numpy(depth).cuda(),
+                           value_map=None if value is None else torch.from_numpy(value).cuda(),
                            valid_map=None if valid is None else torch.from_numpy(valid).cuda(),
-                           cam_pose=pose)
+                           cam_pose=pose, get_height_map=get_h)
   kw = dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose)
-  want = oracle.orth_project(depth, valid_map=valid, nthreads=16, **kw)
+  want = oracle.orth_project(depth, value_map=value, valid_map=valid, get_height_map=get_h,
+                             nthreads=16, **kw)
   got = [o.cpu().numpy() for o in outs]
   bad_m = int((got[1] != want[1]).sum())
-  a, b = got[0], want[0]
-  bad_v = int((~((a == b) | (np.isnan(a) & np.isnan(b)))).sum())
-  return bad_m, bad_v, (B, H, W, mh, mw, res)
+  bad_v = 0
+  for a, b in ((got[0], want[0]),) + (((got[2], np.ascontiguousarray(want[2])),) if get_h else ()):
+    bad_v += int((~((a == b) | (np.isnan(a) & np.isnan(b)))).sum())
+  return bad_m, bad_v, (B, H, W, mh, mw, res, C)
 
+SEMANTIC = os.environ.get("DM_CAMPAIGN_SEMANTIC", "1") != "0"
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 bad = 0

@@ -23,6 +23,9 @@ def one(seed):
     depth = np.broadcast_to(np.minimum(floor, wall).astype(np.float32), (B, 1, H, W)).copy()
   else:
     depth = rng.uniform(0.1, 8.0, size=(B, 1, H, W)).astype(np.float32)
+  if EDGE and rng.integers(3) == 0:      # special values: never valid, never crash
+    idx = rng.integers(0, depth.size, 12)
+    depth.reshape(-1)[idx] = np.resize(np.array([np.nan, np.inf, -np.inf, 0.0, -1.0, 1e30], np.float32), 12)
   pose = np.stack([rng.uniform(-2, 2, B), rng.uniform(-2, 2, B), rng.uniform(-np.pi, np.pi, B)],
                   axis=1).astype(np.float32)
   per_frame = bool(rng.integers(2))
@@ -36,8 +39,8 @@ def one(seed):
              width_offset=float(mw / 2 + rng.uniform(-40, 40)),
              height_offset=float(mh / 2 + rng.uniform(-40, 40)),
              map_res=res, map_width=mw, map_height=mh,
-             trunc_depth_min=float(rng.choice([0.0, 0.15, 0.5])),
-             trunc_depth_max=float(rng.choice([1.5, 2.5, 5.05, 7.0])),
+             trunc_depth_min=None if EDGE and rng.integers(6) == 0 else float(rng.choice([0.0, 0.15, 0.5])),
+             trunc_depth_max=None if EDGE and rng.integers(6) == 0 else float(rng.choice([1.5, 2.5, 5.05, 7.0])),
              trunc_height_max=None if rng.integers(3) else float(rng.uniform(0.2, 1.2)),
              clip_border=int(rng.choice([0, 0, 3, 9])),
              to_global=bool(rng.integers(2)), flip_h=bool(rng.integers(4)),
@@ -68,6 +71,7 @@ def one(seed):
   return bad_m, bad_v, (B, H, W, mh, mw, res, C)
 
 SEMANTIC = os.environ.get("DM_CAMPAIGN_SEMANTIC", "1") != "0"
+EDGE = os.environ.get("DM_CAMPAIGN_EDGE", "1") != "0"      # NaN/inf depths, missing truncations
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 bad = 0

@@ -424,8 +424,6 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
     publish_geometry();
     return;
   }
-  for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
-    *reinterpret_cast<float4*>(lds + i) = make_float4(a.fill, a.fill, a.fill, a.fill);
   // FrameRec: p[9], cam_h, y[9], tx, tz, wo, ho
   // pitch: rows 1,2 of R; yaw: rows 0,2 (the rest is 0/1 when FAST)
   const float p0 = fr[0], p1 = fr[1], p2 = fr[2], p3 = fr[3], p4 = fr[4],
@@ -435,8 +433,8 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   const float cam_h = fr[9], tx = fr[19], tz = fr[20];
   const float wo = fr[21], ho = fr[22];
   const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
-  lds_barrier();
   DM_STAMP(1);
+  bool lds_ready = false;
   const int q0 = pcx * a.parts.wp;
   int q1 = q0 + a.parts.wp; if (q1 > a.W) q1 = a.W;
   const int r0 = pry * a.parts.hp;
@@ -615,6 +613,13 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
         int r = r0 + gy;
         load_rows(za, va, r);
         DM_STAMP(2);
+        // the LDS window is initialised while the first depth rows are in flight
+        if (!lds_ready) {                      // wave-uniform, first trip only
+          for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
+            *reinterpret_cast<float4*>(lds + i) = make_float4(a.fill, a.fill, a.fill, a.fill);
+          lds_barrier();
+          lds_ready = true;
+        }
         DM_STAMP(3);
         for (int it = 0; it < niter; it += 2) {
           load_rows(zb_, vb_, r + step);

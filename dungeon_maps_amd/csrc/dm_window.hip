@@ -332,6 +332,62 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   const int dch = a.dc == 1 ? 0 : ch;          // depth / cell-index channel (utils.py:475-477)
   const int nparts = a.parts.pc * a.parts.pr;
   const int pcx = part % a.parts.pc, pry = part / a.parts.pc;
+  // The part's pixel rectangle and this thread's place in it need nothing but kernel
+  // arguments, so the first depth rows are requested before anything of the staged
+  // table has arrived (window, union window, frame record: all of the head of the kernel
+  // runs under these loads).
+  const int q0 = pcx * a.parts.wp;
+  int q1 = q0 + a.parts.wp; if (q1 > a.W) q1 = a.W;
+  const int r0 = pry * a.parts.hp;
+  int r1 = r0 + a.parts.hp; if (r1 > a.H) r1 = a.H;
+  const int nx = (q1 - q0 + VEC - 1) / VEC;    // lane groups per row
+  const int ntx = nx < kScatterThreads ? nx : kScatterThreads;
+  const int rows_per_iter = kScatterThreads / ntx;
+  const int gx = threadIdx.x % ntx, gy = threadIdx.x / ntx;
+  const size_t N = (size_t)a.H * a.W;
+  const float* dimg = a.depth + ((size_t)b * a.dc + dch) * N;
+  const uint8_t* vimg = HAS_VALID
+      ? a.valid + ((size_t)b * a.valid_c + (a.valid_c == 1 ? 0 : dch)) * N : nullptr;
+  const float* simg = HAS_VALUE ? a.value + ((size_t)b * a.oc_total + ch) * N : nullptr;
+  const float qnan = __builtin_nanf("");
+  float za[kRowsInFlight][VEC], zb_[kRowsInFlight][VEC];
+  float va[HAS_VALUE ? kRowsInFlight : 1][VEC], vb_[HAS_VALUE ? kRowsInFlight : 1][VEC];
+  auto load_rows_at = [&](float (&z)[kRowsInFlight][VEC],
+                          float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int q, int r) {
+#pragma unroll
+    for (int u = 0; u < kRowsInFlight; ++u) {
+      // rows past the part are clamped to its last row (a legal address);
+      // project_rows() ignores them.  No per-lane branch: the loads stay in
+      // one basic block and the compiler can wait on them individually.
+      int rr = r + u * rows_per_iter;
+      rr = rr < r1 ? rr : r1 - 1;
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(dimg + (size_t)rr * a.W + q);
+        z[u][0] = t.x; z[u][1 % VEC] = t.y; z[u][2 % VEC] = t.z; z[u][3 % VEC] = t.w;
+      } else {
+        z[u][0] = dimg[(size_t)rr * a.W + q];
+      }
+      if (HAS_VALID) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+          z[u][k] = vimg[(size_t)rr * a.W + q + k] ? z[u][k] : qnan;
+      }
+      if (HAS_VALUE) {
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(simg + (size_t)rr * a.W + q);
+          sv[u][0] = t.x; sv[u][1 % VEC] = t.y; sv[u][2 % VEC] = t.z; sv[u][3 % VEC] = t.w;
+        } else {
+          sv[u][0] = simg[(size_t)rr * a.W + q];
+        }
+      }
+    }
+  };
+  bool first_rows_loaded = false;
+  if (gx < nx && q1 > q0 && r1 > r0) {         // (always, for a non-empty part)
+    load_rows_at(za, va, q0 + gx * VEC, r0 + gy);
+    first_rows_loaded = true;
+  }
+
   // Everything this workgroup reads from the staged table -- its window, the frame's union
   // window and the frame record -- is requested in ONE batch of scalar loads and pinned
   // (the asm makes the values opaque): left to the compiler these loads trickle in close
@@ -435,20 +491,6 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
   DM_STAMP(1);
   bool lds_ready = false;
-  const int q0 = pcx * a.parts.wp;
-  int q1 = q0 + a.parts.wp; if (q1 > a.W) q1 = a.W;
-  const int r0 = pry * a.parts.hp;
-  int r1 = r0 + a.parts.hp; if (r1 > a.H) r1 = a.H;
-  const int nx = (q1 - q0 + VEC - 1) / VEC;    // lane groups per row
-  const int ntx = nx < kScatterThreads ? nx : kScatterThreads;
-  const int rows_per_iter = kScatterThreads / ntx;
-  const int gx = threadIdx.x % ntx, gy = threadIdx.x / ntx;
-  const size_t N = (size_t)a.H * a.W;
-  const float* dimg = a.depth + ((size_t)b * a.dc + dch) * N;
-  const uint8_t* vimg = HAS_VALID
-      ? a.valid + ((size_t)b * a.valid_c + (a.valid_c == 1 ? 0 : dch)) * N : nullptr;
-  const float* simg = HAS_VALUE ? a.value + ((size_t)b * a.oc_total + ch) * N : nullptr;
-  const float qnan = __builtin_nanf("");
   const unsigned dummy = (unsigned)area + (threadIdx.x & 63u);   // 64 scratch cells after the window
 
   {
@@ -469,37 +511,9 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
       // i+1 are in flight while group i is projected (all waves of a workgroup
       // run in phase, so latency has to be hidden inside each wave).
       const int step = rows_per_iter * kRowsInFlight;
-      float za[kRowsInFlight][VEC], zb_[kRowsInFlight][VEC];
-      float va[HAS_VALUE ? kRowsInFlight : 1][VEC], vb_[HAS_VALUE ? kRowsInFlight : 1][VEC];
       auto load_rows = [&](float (&z)[kRowsInFlight][VEC],
                            float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
-#pragma unroll
-        for (int u = 0; u < kRowsInFlight; ++u) {
-          // rows past the part are clamped to its last row (a legal address);
-          // project_rows() ignores them.  No per-lane branch: the loads stay in
-          // one basic block and the compiler can wait on them individually.
-          int rr = r + u * rows_per_iter;
-          rr = rr < r1 ? rr : r1 - 1;
-          if (VEC == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(dimg + (size_t)rr * a.W + q);
-            z[u][0] = t.x; z[u][1 % VEC] = t.y; z[u][2 % VEC] = t.z; z[u][3 % VEC] = t.w;
-          } else {
-            z[u][0] = dimg[(size_t)rr * a.W + q];
-          }
-          if (HAS_VALID) {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k)
-              z[u][k] = vimg[(size_t)rr * a.W + q + k] ? z[u][k] : qnan;
-          }
-          if (HAS_VALUE) {
-            if (VEC == 4) {
-              const float4 t = *reinterpret_cast<const float4*>(simg + (size_t)rr * a.W + q);
-              sv[u][0] = t.x; sv[u][1 % VEC] = t.y; sv[u][2 % VEC] = t.z; sv[u][3 % VEC] = t.w;
-            } else {
-              sv[u][0] = simg[(size_t)rr * a.W + q];
-            }
-          }
-        }
+        load_rows_at(z, sv, q, r);
       };
       auto project_rows = [&](const float (&z)[kRowsInFlight][VEC],
                               const float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
@@ -611,7 +625,8 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
       auto pipeline = [&](auto with_fill) {
         constexpr bool kFill = decltype(with_fill)::value;
         int r = r0 + gy;
-        load_rows(za, va, r);
+        if (!first_rows_loaded) load_rows(za, va, r);      // (later trips of the column loop)
+        first_rows_loaded = false;
         DM_STAMP(2);
         // the LDS window is initialised while the first depth rows are in flight
         if (!lds_ready) {                      // wave-uniform, first trip only

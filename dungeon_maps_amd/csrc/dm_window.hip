@@ -10,16 +10,21 @@
 //       part's footprint in the map -- the frustum slab of its pixel rectangle
 //       between trunc_depth_min and trunc_depth_max is a convex polytope whose
 //       extreme cells are reached at its 8 corners -- and the workgroup
-//       accumulates into an LDS image of exactly that window with ds_max_u32 on
-//       order-preserving keys, then flushes the window as a "slab" (plain
-//       16-byte stores; it stays in L2 / Infinity Cache for the next kernel).
-//   k_window_merge    one thread per 16 output cells: combines the <= P slabs
-//       covering them (windows of neighbouring strips overlap), writes the map
-//       and the mask once, 64 + 16 bytes per thread, fill value elsewhere.
+//       accumulates into an LDS image of exactly that window with ds_max_f32 /
+//       ds_min_f32, then flushes the window as a "slab" (plain 16-byte stores,
+//       read back by the next kernel).  Interleaved with the projection it also
+//       writes its share of the map rows outside the frame's union window
+//       (fill value, mask 0): ~77 % of the output never sees a second kernel.
+//   k_window_merge    one thread per 4 cells of the union window: combines the
+//       <= P slabs covering them (windows of neighbouring strips overlap) and
+//       writes map and mask once.
+//   k_fuse_unions / k_fuse_windows  batch fuse (max / min over the frames), from
+//       the finished maps or straight from the slabs.
 //
-// Everything a workgroup needs is wave-uniform (frame record, window) and read
-// through scalar loads; depth is read with 16-byte loads, one row segment per
-// group of lanes, several rows in flight per thread.
+// Everything a workgroup needs is wave-uniform (frame record, windows: one staged
+// table per launch) and read through scalar loads; depth is read with 16-byte
+// loads, one row segment per group of lanes, several rows in flight per thread,
+// the first of them requested before anything but the kernel arguments is known.
 #include <math.h>
 #include <string.h>
 

@@ -830,23 +830,25 @@ k_fuse_windows(FuseWinArgs a) {
   __shared__ int ncand;
   const int chl = blockIdx.y, ch = a.ch0 + chl;
   const int g4 = a.mw >> 2;
-  const int gi = threadIdx.x & (kFuseGroups - 1), lane = threadIdx.x / kFuseGroups;
-  const int g0 = blockIdx.x * kFuseGroups;
-  const int g = g0 + gi;
   const int total = g4 * a.mh;
-  const bool live = g < total;
-  const int z = live ? g / g4 : 0, x = live ? (g - z * g4) << 2 : 0;
-  // cells this block covers: rows z_lo..z_hi, and (when it stays in one row) columns
-  const int g_last = (g0 + kFuseGroups - 1 < total ? g0 + kFuseGroups - 1 : total - 1);
-  const int z_lo = g0 / g4, z_hi = g_last / g4;
-  const int x_lo = z_lo == z_hi ? (g0 - z_lo * g4) << 2 : 0;
-  const int x_hi = z_lo == z_hi ? ((g_last - z_lo * g4) << 2) + 4 : a.mw;
   const size_t M = (size_t)a.mh * a.mw;
-  const size_t cell = (size_t)ch * M + (size_t)z * a.mw + x;
-  // most of a large global map is out of reach of the whole call: such a block writes the
-  // fill value (or, accumulating, only refreshes the mask) without looking at any window
-  if (z_hi < a.gz0 || z_lo >= a.gz1 || x_hi <= a.gx0 || x_lo >= a.gx1) {      // block-uniform
-    if (lane == 0 && live) {
+  // Most of a large global map is out of reach of the whole call.  The first `heavy`
+  // blocks own the 32-group tiles of the call's bounding box (one map row each); the
+  // others stream the fill value (or, accumulating, only refresh the mask) over
+  // everything outside it, 8 groups per thread: few, fat blocks instead of one tiny
+  // block per 128 cells of a mostly empty map.
+  const int bw4 = (a.gx1 - a.gx0) >> 2;                           // groups per bounding-box row
+  const int tpr = (bw4 + kFuseGroups - 1) / kFuseGroups;          // tiles per bounding-box row
+  const int heavy = a.gx1 > a.gx0 ? tpr * (a.gz1 - a.gz0) : 0;
+  if ((int)blockIdx.x >= heavy) {                                 // block-uniform
+    const int first = ((int)blockIdx.x - heavy) * (int)blockDim.x * 8 + (int)threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int g = first + k * (int)blockDim.x;
+      if (g >= total) break;
+      const int z = g / g4, x = (g - z * g4) << 2;
+      if (z >= a.gz0 && z < a.gz1 && x >= a.gx0 && x < a.gx1) continue;     // a tile's cell
+      const size_t cell = (size_t)ch * M + (size_t)z * a.mw + x;
       uint32_t mk = 0u;
       if (a.accumulate) {
         const float4 v = *reinterpret_cast<const float4*>(a.fused + cell);
@@ -859,6 +861,16 @@ k_fuse_windows(FuseWinArgs a) {
     }
     return;
   }
+  const int gi = threadIdx.x & (kFuseGroups - 1), lane = threadIdx.x / kFuseGroups;
+  const int trow = (int)blockIdx.x / tpr, tcol = (int)blockIdx.x - trow * tpr;
+  const int z = a.gz0 + trow;
+  const int gx = (a.gx0 >> 2) + tcol * kFuseGroups + gi;          // group index within the row
+  const bool live = gx < (a.gx1 >> 2);
+  const int x = (live ? gx : (a.gx0 >> 2)) << 2;
+  const int z_lo = z, z_hi = z;
+  const int x_lo = ((a.gx0 >> 2) + tcol * kFuseGroups) << 2;
+  const int x_hi = x_lo + 4 * kFuseGroups < a.gx1 ? x_lo + 4 * kFuseGroups : a.gx1;
+  const size_t cell = (size_t)ch * M + (size_t)z * a.mw + x;
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
   if (a.accumulate && lane == 0 && live) acc = *reinterpret_cast<const float4*>(a.fused + cell);
   for (int c0 = 0; c0 < a.nwin; c0 += kFuseChunk) {
@@ -1113,7 +1125,11 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
       fa.accumulate = accumulate; fa.fill = fill;
       fa.gx0 = st.gx0; fa.gz0 = st.gz0; fa.gx1 = st.gx1; fa.gz1 = st.gz1;
       fa.wins = st.g_wins; fa.slabs = slabs; fa.fused = fused; fa.fused_mask = fused_mask;
-      const dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kFuseGroups - 1) / kFuseGroups), oc);
+      const int bw4 = (st.gx1 - st.gx0) / 4;
+      const int heavy = st.gx1 > st.gx0 ? ((bw4 + kFuseGroups - 1) / kFuseGroups) * (st.gz1 - st.gz0) : 0;
+      const int per_fill_block = kFuseGroups * kFuseLanes * 8;
+      const int fill_blocks = (int)(((size_t)p.mh * p.mw / 4 + per_fill_block - 1) / per_fill_block);
+      const dim3 g((unsigned)(heavy + fill_blocks), oc);
       const dim3 blk(kFuseGroups * kFuseLanes);
       e = is_max ? launch(k_fuse_windows<true>, g, blk, 0, s, fa)
                  : launch(k_fuse_windows<false>, g, blk, 0, s, fa);

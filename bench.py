@@ -292,6 +292,21 @@ def main():
     result["config"]["workload"] = (f"cfg4: B={B}/GPU, {W}x{H} depth fused straight into one "
                                     f"{mw}x{mh} global map (max)"
                                     f"{' + RCCL all-reduce(max)' if world > 1 else ''}")
+  if rank == 0 and world == 1 and args.depth == "uniform" and not fused_only and C == 0:
+    # the same step on scene-like depth (floor + walls: many pixels per cell):
+    # reported beside the headline number, outside its timed region
+    sdepth, spose, _ = synthetic_inputs(B, H, W, C, 1234 + rank, dev, True)
+    sdepth = sdepth.to(dev)
+    for _ in range(10):
+      proj.orth_project_and_fuse(sdepth, cam_pose=spose)
+    torch.cuda.synchronize()
+    n_s = 100
+    t0 = time.perf_counter()
+    for _ in range(n_s):
+      proj.orth_project_and_fuse(sdepth, cam_pose=spose)
+    torch.cuda.synchronize()
+    result["scene_like_depth"] = {"value": B * n_s / (time.perf_counter() - t0), "unit": "frames/s",
+                                  "steps": n_s, "note": "same workload on floor + walls depth"}
   if rank == 0 and world == 1 and not args.no_cpu_baseline and not fused_only:
     result["cpu_baseline"] = cpu_baseline(depth, pose, value, H, W, mh, mw, fill,
                                           args.cpu_seconds, out)

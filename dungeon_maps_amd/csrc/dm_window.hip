@@ -624,7 +624,7 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
           // run of equal cells inside a thread is reduced in registers and only its last
           // pixel issues the atomic.  (Unconditionally the extra selects cost 2.6 us on
           // incoherent depth; behind the test 1 us.)
-          if (VEC == 4 && __builtin_amdgcn_ballot_w64(li[0] == li[3] && li[0] != dummy) != 0) {
+          if (VEC == 4 && __builtin_amdgcn_ballot_w64(li[0] == li[VEC - 1] && li[0] != dummy) != 0) {
 #pragma unroll
             for (int k = 0; k + 1 < VEC; ++k) {
               const bool same = li[k] == li[k + 1];

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DUNGEON_MAPS_AMD_LIB") or os.path.join(
     HERE, "csrc", "libdungeon_maps_amd.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # dm_reduction
 REDUCE_MAX, REDUCE_MIN, REDUCE_SUM, REDUCE_MEAN, REDUCE_PROD = range(5)
@@ -61,6 +61,7 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dm_debug_force_generic_path": (ctypes.c_int, [ctypes.c_int]),
+    "dm_debug_last_split": (None, [ctypes.POINTER(ctypes.c_int32)]),
     "dm_fuse_bbox_f32": (ctypes.c_int, [
         ctypes.POINTER(FuseSrc), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "dm_fuse_scatter_f32": (ctypes.c_int, [

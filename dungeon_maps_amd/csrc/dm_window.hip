@@ -26,8 +26,12 @@
 // loads, one row segment per group of lanes, several rows in flight per thread,
 // the first of them requested before anything but the kernel arguments is known.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <cstddef>
 #include <type_traits>
 #include <vector>
 
@@ -46,6 +50,8 @@ constexpr int kMaxLdsBytes = 160 * 1024;
 struct Parts {
   int pc, pr;          // column strips x row bands
   int wp, hp;          // part width (multiple of 4) / height in pixels
+  int pd;              // depth bands: band k keeps the pixels with depth in [lo_k, hi_k] (every
+                       // band reads the whole rectangle; its window is pd times shorter)
 };
 
 // Window of one part in map cells; w == 0: the part cannot hit the map.
@@ -68,15 +74,17 @@ struct FrameRec {        // what the scatter kernel reads of a dm_frame
 struct Win16 { short x0, z0, w, h; };     // map sides <= 32767
 
 constexpr int kChunkFrames = 64;          // frames per scatter launch
-constexpr int kChunkWins = 512;           // part windows per scatter launch
+constexpr int kChunkWins = 2048;          // part windows per scatter launch
+constexpr int kMaxParts = 256;           // parts of a frame (image parts x depth bands)
 constexpr int kFewParts = 8;              // window-table row stride for frames of up to 8 parts
 
 struct ScatterTables {
   FrameRec frames[kChunkFrames];
-  // (frame, part): row stride kFewParts when a frame has at most kFewParts parts (a
-  // workgroup then finds its window without first loading the part count), else nparts
-  Win16 wins[kChunkWins];
   Win16 unions[kChunkFrames];             // bounding box of a frame's windows, x aligned to 4
+  // (frame, part): row stride kFewParts when a frame has at most kFewParts parts (a
+  // workgroup then finds its window without first loading the part count), else nparts.
+  // Last, so that a call of one chunk copies only the rows it uses.
+  Win16 wins[kChunkWins];
 };
 
 __device__ __host__ inline Window widen(Win16 w) { return Window{w.x0, w.z0, w.w, w.h}; }
@@ -87,7 +95,17 @@ __host__ inline Win16 narrow(Window w) {
   return Win16{(short)w.x0, (short)w.z0, (short)w.w, (short)w.h};
 }
 
-__host__ Parts choose_parts(const dm_params& p, int min_parts = 1) {
+// Depth band k of pd over [dmin, dmax]: the same float expressions on the host (window
+// bounds) and in the kernel (depth test); neighbouring bands share their boundary value,
+// which is harmless for max / min.
+__host__ __device__ inline void band_bounds(float dmin, float dmax, int pd, int k, float& lo,
+                                            float& hi) {
+  const float step = (dmax - dmin) / (float)pd;
+  lo = k == 0 ? dmin : __builtin_fmaf((float)k, step, dmin);
+  hi = k == pd - 1 ? dmax : __builtin_fmaf((float)(k + 1), step, dmin);
+}
+
+__host__ Parts choose_parts(const dm_params& p, int min_parts = 1, int pd = 1) {
   // enough workgroups to fill 256 CUs (and at least min_parts, so that windows fit
   // in LDS), parts not smaller than 32 columns, strip boundaries on 128-byte lines
   // (32 floats) when W allows it
@@ -99,10 +117,11 @@ __host__ Parts choose_parts(const dm_params& p, int min_parts = 1) {
   int want = (int)((256 + frames - 1) / frames);
   const int pays = (int)lround(sqrt(0.8 * (double)p.H * p.W / 1024.0));
   if (want > pays) want = pays;
+  want = (want + pd - 1) / pd;                 // image parts: the depth bands multiply them
   if (want < min_parts) want = min_parts;
   if (want < 1) want = 1;
   Parts s;
-  s.pc = 1; s.pr = 1;
+  s.pc = 1; s.pr = 1; s.pd = pd;
   const int unit = (p.W % 32 == 0) ? 32 : 4;
   const int units = (p.W + unit - 1) / unit;
   int pc = want < units ? want : units;
@@ -190,7 +209,7 @@ __host__ FrameAffine frame_affine(const dm_params& p, const dm_frame& f) {
 // Footprint of the pixel rectangle [q0,q1) x [r0,r1) of a frame in map cells,
 // padded by 2 cells and aligned to 4 columns, clipped to the map.
 __host__ Window part_window(const dm_params& p, const FrameAffine& fa, int q0, int q1, int r0,
-                            int r1) {
+                            int r1, float dlo, float dhi) {
   Window full = {0, 0, p.mw, p.mh};
   if (p.clip_border > 0) {
     const int c = p.clip_border;
@@ -205,7 +224,7 @@ __host__ Window part_window(const dm_params& p, const FrameAffine& fa, int q0, i
     return full;
   double lo_x = INFINITY, hi_x = -INFINITY, lo_z = INFINITY, hi_z = -INFINITY;
   const int qs[2] = {q0, q1 - 1}, rs[2] = {r0, r1 - 1};
-  const double zs[2] = {p.dmin, p.dmax};
+  const double zs[2] = {dlo, dhi};
   for (int qi = 0; qi < 2; ++qi) {
     const double ax = ((double)qs[qi] - p.cx) / p.fx;
     for (int ri = 0; ri < 2; ++ri) {
@@ -335,8 +354,9 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   const int bl = blockIdx.z, b = a.b0 + bl;    // frame within the chunk / in the batch
   const int ch = a.ch0 + chl;                  // output channel
   const int dch = a.dc == 1 ? 0 : ch;          // depth / cell-index channel (utils.py:475-477)
-  const int nparts = a.parts.pc * a.parts.pr;
-  const int pcx = part % a.parts.pc, pry = part / a.parts.pc;
+  const int nparts = a.parts.pc * a.parts.pr * a.parts.pd;
+  const int pcx = part % a.parts.pc, pry = (part / a.parts.pc) % a.parts.pr;
+  const int pdk = part / (a.parts.pc * a.parts.pr);          // depth band
   // The part's pixel rectangle and this thread's place in it need nothing but kernel
   // arguments, so the first depth rows are requested before anything of the staged
   // table has arrived (window, union window, frame record: all of the head of the kernel
@@ -497,6 +517,8 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   DM_STAMP(1);
   bool lds_ready = false;
   const unsigned dummy = (unsigned)area + (threadIdx.x & 63u);   // 64 scratch cells after the window
+  float band_lo = a.dmin, band_hi = a.dmax;    // this part's depth band (wave-uniform)
+  if (a.parts.pd > 1) band_bounds(a.dmin, a.dmax, a.parts.pd, pdk, band_lo, band_hi);
 
   {
     for (int g = gx; g < nx; g += ntx) {       // one trip unless the strip is wider than the block
@@ -605,7 +627,7 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
             // maps.py:537-544, 286-288, 1150-1158
             const unsigned ux = (unsigned)(floor_to_int(xf) - w.x0);
             const unsigned uz = (unsigned)(floor_to_int(zf) - w.z0);
-            ok[k] = ux < (unsigned)w.w && uz < (unsigned)w.h && zz <= a.dmax && zz >= a.dmin;
+            ok[k] = ux < (unsigned)w.w && uz < (unsigned)w.h && zz <= band_hi && zz >= band_lo;
             if (!LEAN) ok[k] = ok[k] && !__builtin_isunordered(xf, zf) && h1 <= a.hmax;
             if (!FAST && !HAS_VALUE) ok[k] = ok[k] && (h2 == h2);
             const float sval = HAS_VALUE ? sv[u][k] : h2;
@@ -733,6 +755,80 @@ k_window_merge(MergeArgs a) {
     acc.y = IS_MAX ? fmaxf(acc.y, s.y) : fminf(acc.y, s.y);
     acc.z = IS_MAX ? fmaxf(acc.z, s.z) : fminf(acc.z, s.z);
     acc.w = IS_MAX ? fmaxf(acc.w, s.w) : fminf(acc.w, s.w);
+  }
+  const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw + x;
+  *reinterpret_cast<float4*>(a.out + cell) = acc;
+  const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+                      ((uint32_t)mask_of(acc.z, a.fill) << 16) |
+                      ((uint32_t)mask_of(acc.w, a.fill) << 24);
+  *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+}
+
+// The same for frames of many parts (image parts x depth bands): a block owns a tile of
+// kTileGroups x kTileRows float4 groups of U, first lists the parts whose windows touch the
+// tile (in part order, so that the result does not depend on the tiling), and its threads
+// then visit only those instead of all of them.
+constexpr int kTileGroups = 16, kTileRows = 16;
+constexpr int kTiledMergeParts = 16;      // frames of at least this many parts take the tiled merge
+static_assert(kTileGroups * kTileRows == kMergeThreads && kMaxParts <= kMergeThreads, "one test per thread");
+
+template <bool IS_MAX>
+__global__ void __launch_bounds__(kMergeThreads)
+k_window_merge_tiled(MergeArgs a) {
+  __shared__ Win16 lwin[kMaxParts];
+  __shared__ short lpart[kMaxParts];
+  __shared__ int wave_hits[kMergeThreads / 64];
+  const int fcl = blockIdx.y;
+  const int bl = fcl / a.oc, b = a.b0 + bl;
+  const int fc = fcl + a.b0 * a.oc;
+  const size_t fo = (size_t)b * a.oc_total + a.ch0 + (fcl - bl * a.oc);
+  const Window U = widen(a.tables->unions[bl]);
+  const int win_stride = a.nparts <= kFewParts ? kFewParts : a.nparts;
+  const int tiles_x = ((U.w >> 2) + kTileGroups - 1) / kTileGroups;
+  const int tiles_z = (U.h + kTileRows - 1) / kTileRows;
+  const int t = blockIdx.x;
+  if (t >= tiles_x * tiles_z) return;            // the whole block
+  const int tz = t / tiles_x, tx = t - tz * tiles_x;
+  const int x0 = U.x0 + tx * (kTileGroups * 4), z0 = U.z0 + tz * kTileRows;
+  const int x1 = min(x0 + kTileGroups * 4, U.x0 + U.w), z1 = min(z0 + kTileRows, U.z0 + U.h);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  Win16 mine = Win16{0, 0, 0, 0};
+  bool hit = false;
+  if (tid < a.nparts) {
+    mine = a.tables->wins[bl * win_stride + tid];
+    hit = mine.w > 0 && mine.x0 < x1 && mine.x0 + mine.w > x0 && mine.z0 < z1 && mine.z0 + mine.h > z0;
+  }
+  const unsigned long long votes = __builtin_amdgcn_ballot_w64(hit);
+  if (lane == 0) wave_hits[wave] = __builtin_popcountll(votes);
+  __syncthreads();
+  int before = 0, n = 0;
+#pragma unroll
+  for (int w = 0; w < kMergeThreads / 64; ++w) {
+    before += w < wave ? wave_hits[w] : 0;
+    n += wave_hits[w];
+  }
+  if (hit) {
+    const int at = before + __builtin_popcountll(votes & ((1ull << lane) - 1ull));
+    lwin[at] = mine;
+    lpart[at] = (short)tid;
+  }
+  __syncthreads();
+
+  const int x = x0 + ((tid & (kTileGroups - 1)) << 2), zb = z0 + tid / kTileGroups;
+  if (x >= x1 || zb >= z1) return;
+  float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+  const float* slabs = a.slabs + (size_t)fc * a.nparts * a.slab_stride;
+  for (int j = 0; j < n; ++j) {
+    const Window w = widen(lwin[j]);
+    const unsigned ux = (unsigned)(x - w.x0), uz = (unsigned)(zb - w.z0);
+    if (ux >= (unsigned)w.w || uz >= (unsigned)w.h) continue;
+    const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)lpart[j] * a.slab_stride +
+                                                     (size_t)uz * w.w + ux);
+    acc.x = IS_MAX ? fmaxf(acc.x, v.x) : fminf(acc.x, v.x);
+    acc.y = IS_MAX ? fmaxf(acc.y, v.y) : fminf(acc.y, v.y);
+    acc.z = IS_MAX ? fmaxf(acc.z, v.z) : fminf(acc.z, v.z);
+    acc.w = IS_MAX ? fmaxf(acc.w, v.w) : fminf(acc.w, v.w);
   }
   const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw + x;
   *reinterpret_cast<float4*>(a.out + cell) = acc;
@@ -986,13 +1082,13 @@ size_t window_workspace_bytes(const dm_params& p) {
   if (cap > kMaxLdsBytes / 4) cap = kMaxLdsBytes / 4;
   const Parts d = choose_parts(p, 1);
   size_t np = (size_t)d.pc * d.pr * 4;
-  if (np > 128) np = 128;
+  if (np > kMaxParts) np = kMaxParts;
   const size_t oc = p.vc ? p.vc : p.dc;
   const size_t one = (size_t)p.B * np * align_up(cap, 4) * 4;     // one channel of every frame
   size_t slabs = one * oc;
   if (slabs > kSlabBudget) slabs = one > kSlabBudget ? one : kSlabBudget;
   const size_t height_mask = p.vc ? align_up((size_t)p.B * p.dc * p.mh * p.mw, 256) : 0;
-  return geometry_bytes(p.B, 128) + slabs + height_mask;
+  return geometry_bytes(p.B, kMaxParts) + slabs + height_mask;
 }
 
 namespace {
@@ -1000,6 +1096,7 @@ namespace {
 struct Staged {                 // what run_window keeps between its passes
   Parts parts;
   int nparts, slab_stride, max_union;
+  int max_tiles;                // k_window_merge_tiled blocks of the largest union window
   int gx0, gz0, gx1, gz1;       // bounding box of all union windows (empty: gx1 <= gx0)
   Win16* g_wins;                // device copies (workspace head)
   Win16* g_unions;
@@ -1127,9 +1224,15 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
         ma.nparts = st.nparts; ma.slab_stride = st.slab_stride; ma.fill = fill;
         ma.tables = st.d_tables + b0 / chunk;
         ma.slabs = slabs; ma.out = out; ma.mask = mask;
-        const dim3 g((unsigned)((st.max_union / 4 + kMergeThreads - 1) / kMergeThreads), nb * oc);
-        e = is_max ? launch(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma)
-                   : launch(k_window_merge<false>, g, dim3(kMergeThreads), 0, s, ma);
+        if (st.nparts >= kTiledMergeParts) {
+          const dim3 g((unsigned)st.max_tiles, nb * oc);
+          e = is_max ? launch(k_window_merge_tiled<true>, g, dim3(kMergeThreads), 0, s, ma)
+                     : launch(k_window_merge_tiled<false>, g, dim3(kMergeThreads), 0, s, ma);
+        } else {
+          const dim3 g((unsigned)((st.max_union / 4 + kMergeThreads - 1) / kMergeThreads), nb * oc);
+          e = is_max ? launch(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma)
+                     : launch(k_window_merge<false>, g, dim3(kMergeThreads), 0, s, ma);
+        }
         if (e != hipSuccess) return e;
       }
     }
@@ -1154,6 +1257,56 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
   return hipSuccess;
 }
 
+// What the previous calls of a shape settled on: the split into parts (stage_windows) and
+// whether the frames have to go through in halves (run_window).  Per thread, a few shapes.
+struct Remembered {
+  int B, H, W, mh, mw, oc;
+  float res, dmin, dmax;
+  Parts parts;
+  bool valid, halve;
+  int hopeless;          // calls left before the search is tried again after it failed
+};
+Remembered& remembered(const dm_params& p) {
+  thread_local Remembered slots[4] = {};
+  thread_local int next = 0;
+  const int oc = p.vc ? p.vc : p.dc;
+  for (Remembered& r : slots)
+    if (r.B == p.B && r.H == p.H && r.W == p.W && r.mh == p.mh && r.mw == p.mw && r.oc == oc &&
+        r.res == p.res && r.dmin == p.dmin && r.dmax == p.dmax)
+      return r;
+  Remembered& r = slots[next];
+  next = (next + 1) % 4;
+  r = Remembered{};
+  r.B = p.B; r.H = p.H; r.W = p.W; r.mh = p.mh; r.mw = p.mw; r.oc = oc;
+  r.res = p.res; r.dmin = p.dmin; r.dmax = p.dmax;
+  return r;
+}
+
+thread_local int g_last_split[4] = {0, 0, 0, 0};   // dm_debug_last_split
+
+// Depth bands multiply the workgroups, each with a window to initialise and flush: with few
+// pixels per part that costs more than the generic path's atomics.  Both sides as measured on
+// MI355X: generic = 22 ps per point + fill at 3 TB/s; windowed = per pass
+// waves of 256 workgroups at 4 us + (slab + part pixels) at 20 GB/s per CU, plus the merge
+// reading the slabs at 3.7 TB/s.
+bool banded_split_pays(const dm_params& p, const Parts& parts, int nparts, int max_area,
+                       size_t slab_capacity) {
+  const double oc = p.vc ? p.vc : p.dc;
+  const double points = (double)p.B * p.H * p.W * oc, cells = (double)p.B * oc * p.mh * p.mw;
+  const double t_generic = points * 22e-6 + cells * 5.0 / 3.0e6;
+  const double slab = (double)align_up((size_t)max_area, 4) * 4.0;
+  double frames = p.B;
+  int passes = 1;
+  while (frames > 1.0 && frames * nparts * slab > (double)slab_capacity) {
+    frames = ceil(frames / 2.0);
+    passes *= 2;
+  }
+  const double t_wg = 4.0 + (slab + (double)parts.wp * parts.hp * 4.0) / 20480.0;
+  const double waves = ceil(frames * oc * nparts / 256.0);
+  const double t_window = passes * (waves * t_wg + 6.0) + (double)p.B * oc * nparts * slab / 3.7e6;
+  return t_window < t_generic;
+}
+
 // Host-side geometry of a call: parts, part windows, frame records.  Returns
 // hipErrorNotSupported when the windows cannot be made to fit in LDS (the caller then
 // takes the generic path); nothing has been enqueued in that case.
@@ -1163,37 +1316,46 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return hipErrorNotSupported;
   thread_local std::vector<FrameRec> recs;
   thread_local std::vector<Win16> wins;      // (B, nparts) then (B) unions
-  // more, narrower parts until every window fits in LDS
+  // more, narrower parts until every window fits in LDS; when splitting the image does not
+  // get there (a long thin wedge: fine resolution, long range) the depth range is split too
   int max_area = 0;
-  for (int min_parts = 1;; min_parts *= 2) {
-    st.parts = choose_parts(p, min_parts);
-    st.nparts = st.parts.pc * st.parts.pr;
-    if (st.nparts > 128) return hipErrorNotSupported;
+  const bool can_band = p.has_dmin && p.has_dmax && p.dmin >= 0.0f && p.dmax > p.dmin &&
+                        isfinite(p.dmax);
+  auto evaluate = [&](const Parts& parts) -> bool {
+    const int pd = parts.pd;
+    st.parts = parts;
+    st.nparts = parts.pc * parts.pr * pd;
     wins.resize((size_t)p.B * (st.nparts + 1));
     Win16* unions = wins.data() + (size_t)p.B * st.nparts;
-    max_area = 0; st.max_union = 0;
+    max_area = 0; st.max_union = 0; st.max_tiles = 0;
     st.gx0 = p.mw; st.gz0 = p.mh; st.gx1 = 0; st.gz1 = 0;
     for (int b = 0; b < p.B; ++b) {
       int ux0 = p.mw, ux1 = 0, uz0 = p.mh, uz1 = 0;
       const FrameAffine fa = frame_affine(p, frames_host[b]);
-      for (int pr = 0; pr < st.parts.pr; ++pr)
-        for (int pc = 0; pc < st.parts.pc; ++pc) {
-          const int q0 = pc * st.parts.wp, r0 = pr * st.parts.hp;
-          const int q1 = q0 + st.parts.wp < p.W ? q0 + st.parts.wp : p.W;
-          const int r1 = r0 + st.parts.hp < p.H ? r0 + st.parts.hp : p.H;
-          const Window w = part_window(p, fa, q0, q1, r0, r1);
-          wins[(size_t)b * st.nparts + pr * st.parts.pc + pc] = narrow(w);
-          if (w.w * w.h > max_area) max_area = w.w * w.h;
-          if (w.w > 0) {
-            if (w.x0 < ux0) ux0 = w.x0;
-            if (w.x0 + w.w > ux1) ux1 = w.x0 + w.w;
-            if (w.z0 < uz0) uz0 = w.z0;
-            if (w.z0 + w.h > uz1) uz1 = w.z0 + w.h;
+      for (int k = 0; k < pd; ++k) {
+        float dlo = p.dmin, dhi = p.dmax;
+        if (pd > 1) band_bounds(p.dmin, p.dmax, pd, k, dlo, dhi);
+        for (int pr = 0; pr < parts.pr; ++pr)
+          for (int pc = 0; pc < parts.pc; ++pc) {
+            const int q0 = pc * parts.wp, r0 = pr * parts.hp;
+            const int q1 = q0 + parts.wp < p.W ? q0 + parts.wp : p.W;
+            const int r1 = r0 + parts.hp < p.H ? r0 + parts.hp : p.H;
+            const Window w = part_window(p, fa, q0, q1, r0, r1, dlo, dhi);
+            wins[(size_t)b * st.nparts + (k * parts.pr + pr) * parts.pc + pc] = narrow(w);
+            if (w.w * w.h > max_area) max_area = w.w * w.h;
+            if (w.w > 0) {
+              if (w.x0 < ux0) ux0 = w.x0;
+              if (w.x0 + w.w > ux1) ux1 = w.x0 + w.w;
+              if (w.z0 < uz0) uz0 = w.z0;
+              if (w.z0 + w.h > uz1) uz1 = w.z0 + w.h;
+            }
           }
-        }
+      }
       const Window U = ux1 > ux0 ? Window{ux0, uz0, ux1 - ux0, uz1 - uz0} : Window{0, 0, 0, 0};
       unions[b] = narrow(U);
       if (U.w * U.h > st.max_union) st.max_union = U.w * U.h;
+      const int tiles = ((U.w / 4 + kTileGroups - 1) / kTileGroups) * ((U.h + kTileRows - 1) / kTileRows);
+      if (tiles > st.max_tiles) st.max_tiles = tiles;
       if (U.w > 0) {
         if (U.x0 < st.gx0) st.gx0 = U.x0;
         if (U.z0 < st.gz0) st.gz0 = U.z0;
@@ -1201,16 +1363,63 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
         if (U.z0 + U.h > st.gz1) st.gz1 = U.z0 + U.h;
       }
     }
-    if ((size_t)max_area * 4 + 64 * 4 + 16 <= (size_t)kMaxLdsBytes) break;
-    // a window that is the whole map cannot shrink by splitting the image
-    if (!p.has_dmin || !p.has_dmax || st.nparts >= 64 ||
-        st.parts.pc * st.parts.pr == choose_parts(p, min_parts * 2).pc * choose_parts(p, min_parts * 2).pr)
-      return hipErrorNotSupported;
+    static const bool verbose = getenv("DM_DEBUG_WINDOWS") != nullptr;
+    if (verbose)
+      fprintf(stderr, "[dm] pd=%d parts=%dx%d nparts=%d max_area=%d max_union=%d\n", pd, parts.pc,
+              parts.pr, st.nparts, max_area, st.max_union);
+    return (size_t)max_area * 4 + 64 * 4 + 16 <= (size_t)kMaxLdsBytes;
+  };
+  // the split that worked for the previous call of the same shape is tried first (the answer
+  // moves with the poses only): one evaluation per call in the steady state
+  Remembered& last = remembered(p);
+  if (last.hopeless > 0) { --last.hopeless; return hipErrorNotSupported; }
+  const bool same_shape = last.valid && (last.parts.pd == 1 || can_band);
+  bool fits = same_shape && evaluate(last.parts);
+  if (!fits) {
+    // candidates: the image splits without bands first (fewest parts first), then the banded
+    // ones by their number of parts
+    std::vector<Parts> cands;
+    auto seen = [&](const Parts& c) {
+      for (const Parts& o : cands)
+        if (o.pc == c.pc && o.pr == c.pr && o.pd == c.pd) return true;
+      return false;
+    };
+    for (int pd = 1; pd <= 8; pd *= 2) {
+      if (pd > 1 && !can_band) break;
+      for (int min_parts = 1;; min_parts *= 2) {
+        const Parts c = choose_parts(p, min_parts, pd);
+        const int image_parts = c.pc * c.pr;
+        if (image_parts * pd > kMaxParts || image_parts < min_parts) break;   // cannot split further
+        if (!seen(c)) cands.push_back(c);
+        // a window that is the whole map cannot shrink by splitting the image
+        if (!p.has_dmin || !p.has_dmax || image_parts >= 64) break;
+      }
+    }
+    std::stable_sort(cands.begin(), cands.end(), [](const Parts& x, const Parts& y) {
+      if ((x.pd == 1) != (y.pd == 1)) return x.pd == 1;
+      return x.pc * x.pr * x.pd < y.pc * y.pr * y.pd;
+    });
+    for (const Parts& c : cands) {
+      if (same_shape && c.pc == last.parts.pc && c.pr == last.parts.pr && c.pd == last.parts.pd) continue;
+      if (evaluate(c)) {
+        const size_t geom = geometry_bytes(p.B, st.nparts);
+        fits = c.pd == 1 || banded_split_pays(p, c, st.nparts, max_area, ws_bytes > geom ? ws_bytes - geom : 0);
+        break;            // splits of more parts cost more still
+      }
+    }
   }
+  last.valid = fits;
+  if (fits) last.parts = st.parts;
+  else last.hopeless = 63;       // the search is host time: not on every call of such a shape
+  if (!fits) {
+    g_last_split[0] = g_last_split[1] = g_last_split[2] = 0;
+    return hipErrorNotSupported;
+  }
+  g_last_split[0] = st.parts.pc; g_last_split[1] = st.parts.pr; g_last_split[2] = st.parts.pd;
   st.slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 4);
   st.geom_bytes = geometry_bytes(p.B, st.nparts);
   if (ws_bytes < st.geom_bytes + (size_t)p.B * st.nparts * st.slab_stride * 4)
-    return hipErrorNotSupported;
+    return hipErrorOutOfMemory;       // run_window then takes the frames in two halves
   slab_bytes = ws_bytes - st.geom_bytes;
   {
     unsigned char* base = static_cast<unsigned char*>(ws);
@@ -1267,8 +1476,11 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
     const hipError_t e = hipEventRecord(before, s);
     if (e != hipSuccess) return e;
   }
-  return hipMemcpyAsync(const_cast<ScatterTables*>(st.d_tables), tabs.data(),
-                        (size_t)nchunks * sizeof(ScatterTables), hipMemcpyHostToDevice, s);
+  const size_t table_bytes =
+      nchunks > 1 ? (size_t)nchunks * sizeof(ScatterTables)
+                  : offsetof(ScatterTables, wins) + (size_t)p.B * win_stride * sizeof(Win16);
+  return hipMemcpyAsync(const_cast<ScatterTables*>(st.d_tables), tabs.data(), table_bytes,
+                        hipMemcpyHostToDevice, s);
 }
 
 }  // namespace
@@ -1286,7 +1498,32 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     return hipErrorNotSupported;
   Staged st;
   size_t slab_bytes = 0;
-  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s, before_projection);
+  Remembered& shape = remembered(p);
+  if (shape.hopeless > 0) { --shape.hopeless; return hipErrorNotSupported; }
+  hipError_t e = shape.halve && !fused && p.B >= 2
+                     ? hipErrorOutOfMemory
+                     : stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s, before_projection);
+  if (e == hipErrorOutOfMemory) {
+    // many parts of large windows (fine resolution): the slabs of all frames do not fit the
+    // workspace.  Frames are independent, so they go through in two halves.
+    if (p.B < 2 || fused) return hipErrorNotSupported;
+    shape.halve = true;
+    g_last_split[3] += 1;
+    dm_params q = p;
+    q.B = p.B / 2;
+    const size_t n = (size_t)p.H * p.W, m = (size_t)p.mh * p.mw, h = q.B;
+    e = run_window(q, frames_host, depth, value, valid, out, mask, height, nullptr, nullptr, ws,
+                   ws_bytes, before_projection, nullptr, s);
+    if (e == hipErrorNotSupported) shape.hopeless = 63;     // a half that does not fit or pay
+    if (e != hipSuccess) return e;
+    q.B = p.B - (int)h;
+    e = run_window(q, frames_host + h, depth + h * p.dc * n, value ? value + h * p.vc * n : nullptr,
+                      valid ? valid + h * p.valid_c * n : nullptr, out + h * oc_total * m,
+                      mask + h * oc_total * m, height ? height + h * p.dc * m : nullptr, nullptr,
+                      nullptr, ws, ws_bytes, nullptr, after_projection, s);
+    if (e == hipErrorNotSupported) shape.hopeless = 63;
+    return e;
+  }
   if (e != hipSuccess) return e;
   unsigned char* base = static_cast<unsigned char*>(ws);
   float* slabs = reinterpret_cast<float*>(base + st.geom_bytes);
@@ -1340,6 +1577,11 @@ hipError_t run_window_fused(const dm_params& p, const dm_frame* frames_host, con
 }
 
 }  // namespace dm
+
+extern "C" __attribute__((visibility("default"))) void dm_debug_last_split(int32_t* out4) {
+  for (int i = 0; i < 4; ++i) out4[i] = dm::g_last_split[i];
+  dm::g_last_split[3] = 0;
+}
 
 #ifdef DM_STAMPS
 extern "C" __attribute__((visibility("default"))) void dm_debug_stamp_buffer(long long* dev) {

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 3
+#define DM_ABI_VERSION 4
 
 typedef enum dm_status {
   DM_OK = 0,
@@ -252,6 +252,14 @@ int dm_scatter_f32(const float* values_dev, const int64_t* index_dev, float* can
  * The LDS-windowed fast path is checked against it on the device.
  */
 int dm_debug_force_generic_path(int on);
+
+/*
+ * Test hook: how the LDS-windowed path split the frames of the calling thread's most recent
+ * dm_orth_project_f32 / dm_orth_project_fused_f32 call: out4 = {image part columns, image
+ * part rows, depth bands, times the frames went through in halves since the last query};
+ * parts 0 x 0 x 0 when the windows did not fit and the call took the generic path.
+ */
+void dm_debug_last_split(int32_t* out4);
 
 /*
  * Measurement hook (bench.py): the next dm_orth_project_f32 call on this thread

@@ -6,6 +6,7 @@ Bar (north_star): integer cell indices bit-exact -- checked through the masks
 and through exact equality of max/min maps; float heights within 1e-5 (they
 are in fact bit-equal); order-dependent sum/mean/prod within rtol 1e-5.
 """
+import ctypes
 import numpy as np
 import pytest
 import torch
@@ -334,6 +335,11 @@ def test_full_size_properties(dmap):
     dict(B=3, H=96, W=128, mh=128, mw=128, C=5, fill_value=0.0),   # value map, shared index
     dict(B=2, H=96, W=128, mh=128, mw=128, C=3, dc=3, fill_value=-1.0, reduction="min"),
     dict(B=70, H=48, W=64, mh=256, mw=256, C=9, res=0.02),         # many channels: 1 strip too big -> split
+    dict(B=2, H=96, W=128, mh=1024, mw=1024, res=0.008),           # long thin wedges, few pixels: generic
+    dict(B=3, H=960, W=1280, mh=2048, mw=2048, res=0.01, bands=True),   # long thin wedges: depth bands
+    dict(B=2, H=960, W=1280, mh=2048, mw=2048, res=0.01, C=2, fill_value=0.0, bands=True, valid=True),
+    dict(B=2, H=960, W=1280, mh=2048, mw=2048, res=0.01, reduction="min", fill_value=np.inf, bands=True),
+    dict(B=16, H=960, W=1280, mh=2048, mw=2048, res=0.01, bands=True, halves=True),  # slabs > workspace
 ])
 def test_window_path_equals_generic_path(dmap, oracle, case):
   from dungeon_maps_amd import _native
@@ -341,6 +347,7 @@ def test_window_path_equals_generic_path(dmap, oracle, case):
   B, H, W, mh, mw = (c.pop(k) for k in ("B", "H", "W", "mh", "mw"))
   C, dcn = c.pop("C", 0), c.pop("dc", 1)
   use_valid = c.pop("valid", False)
+  want_bands, want_halves = c.pop("bands", False), c.pop("halves", False)
   res = c.pop("res", 0.05)
   woff = c.pop("woff", mw / 2.)
   depth, pose = _synthetic(B, H, W, seed=4321)
@@ -362,6 +369,12 @@ def test_window_path_equals_generic_path(dmap, oracle, case):
   lib = _native.lib()
   gh = bool(C)
   fast = _run(dmap, cfg, depth, value=value, valid=valid, get_height_map=gh, cam_pose=pose)
+  split = (ctypes.c_int32 * 4)()
+  lib.dm_debug_last_split(split)
+  if want_bands:
+    assert split[2] > 1, list(split)
+  if want_halves:
+    assert split[3] >= 1, list(split)
   lib.dm_debug_force_generic_path(1)
   try:
     slow = _run(dmap, cfg, depth, value=value, valid=valid, get_height_map=gh, cam_pose=pose)

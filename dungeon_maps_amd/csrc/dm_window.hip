@@ -31,6 +31,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstddef>
 #include <type_traits>
 #include <vector>
@@ -71,7 +72,7 @@ struct FrameRec {        // what the scatter kernel reads of a dm_frame
   float tx, tz, wo, ho;
   float pad;
 };
-struct Win16 { short x0, z0, w, h; };     // map sides <= 32767
+struct alignas(8) Win16 { short x0, z0, w, h; };     // map sides <= 32767 (8-byte aligned: one scalar load)
 
 constexpr int kChunkFrames = 64;          // frames per scatter launch
 constexpr int kChunkWins = 2048;          // part windows per scatter launch
@@ -712,12 +713,29 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   DM_STAMPS_OUT();
 }
 
+// Table ring: the first thread of a kernel that follows k_window_scatter in stream order tells
+// the host that the scatter's table slot may be rewritten (a word in pinned host memory).
+// Called on the way OUT of the kernel: a store ahead of the loads of the read-only window
+// tables (even an opaque one) turns them from scalar into vector loads, each waited for in
+// turn (k_window_merge: 12.2 instead of 9.4 us).
+__device__ inline void signal_slot_free(uint32_t* signal, uint32_t ticket) {
+  if (signal && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(signal), "v"(ticket));
+}
+
 struct MergeArgs {
   int b0, oc, ch0, oc_total, mh, mw;  // oc channels per frame in this launch, starting at ch0
   int nparts;                 // pc * pr
   int slab_stride;
   float fill;
-  const ScatterTables* tables;  // this chunk's staged table (already in every XCD's L2)
+  // this chunk's part windows (row stride win_stride) and union windows: in the staged
+  // table (already in every XCD's L2) or, when that is a slot of the table ring, the device
+  // copies k_window_scatter leaves behind
+  const Win16* wins;
+  const Win16* unions;
+  int win_stride;
+  uint32_t* signal;           // table ring: k_window_scatter of this stream position is done
+  uint32_t ticket;
   const float* slabs;
   float* out;
   uint8_t* mask;
@@ -735,17 +753,20 @@ k_window_merge(MergeArgs a) {
   const int bl = fcl / a.oc, b = a.b0 + bl;
   const int fc = fcl + a.b0 * a.oc;            // slab index of (frame, channel)
   const size_t fo = (size_t)b * a.oc_total + a.ch0 + (fcl - bl * a.oc);   // map index in `out`
-  const Window U = widen(a.tables->unions[bl]);
-  const int win_stride = a.nparts <= kFewParts ? kFewParts : a.nparts;
+  const Window U = widen(a.unions[bl]);
+  const int win_stride = a.win_stride;
   const int ug4 = U.w >> 2;                    // float4 groups per U row
   const int total = ug4 * U.h;
   const int i = blockIdx.x * kMergeThreads + threadIdx.x;
-  if (i >= total) return;
+  if (i >= total) {
+    signal_slot_free(a.signal, a.ticket);
+    return;
+  }
   const int row = i / ug4;
   const int zb = U.z0 + row, x = U.x0 + ((i - row * ug4) << 2);
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
   for (int p = 0; p < a.nparts; ++p) {
-    const Window w = widen(a.tables->wins[bl * win_stride + p]);
+    const Window w = widen(a.wins[bl * win_stride + p]);
     if (w.w == 0) continue;
     const unsigned ux = (unsigned)(x - w.x0), uz = (unsigned)(zb - w.z0);
     if (ux >= (unsigned)w.w || uz >= (unsigned)w.h) continue;
@@ -762,6 +783,7 @@ k_window_merge(MergeArgs a) {
                       ((uint32_t)mask_of(acc.z, a.fill) << 16) |
                       ((uint32_t)mask_of(acc.w, a.fill) << 24);
   *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+  signal_slot_free(a.signal, a.ticket);
 }
 
 // The same for frames of many parts (image parts x depth bands): a block owns a tile of
@@ -782,12 +804,15 @@ k_window_merge_tiled(MergeArgs a) {
   const int bl = fcl / a.oc, b = a.b0 + bl;
   const int fc = fcl + a.b0 * a.oc;
   const size_t fo = (size_t)b * a.oc_total + a.ch0 + (fcl - bl * a.oc);
-  const Window U = widen(a.tables->unions[bl]);
-  const int win_stride = a.nparts <= kFewParts ? kFewParts : a.nparts;
+  const Window U = widen(a.unions[bl]);
+  const int win_stride = a.win_stride;
   const int tiles_x = ((U.w >> 2) + kTileGroups - 1) / kTileGroups;
   const int tiles_z = (U.h + kTileRows - 1) / kTileRows;
   const int t = blockIdx.x;
-  if (t >= tiles_x * tiles_z) return;            // the whole block
+  if (t >= tiles_x * tiles_z) {                  // the whole block
+    signal_slot_free(a.signal, a.ticket);
+    return;
+  }
   const int tz = t / tiles_x, tx = t - tz * tiles_x;
   const int x0 = U.x0 + tx * (kTileGroups * 4), z0 = U.z0 + tz * kTileRows;
   const int x1 = min(x0 + kTileGroups * 4, U.x0 + U.w), z1 = min(z0 + kTileRows, U.z0 + U.h);
@@ -796,7 +821,7 @@ k_window_merge_tiled(MergeArgs a) {
   Win16 mine = Win16{0, 0, 0, 0};
   bool hit = false;
   if (tid < a.nparts) {
-    mine = a.tables->wins[bl * win_stride + tid];
+    mine = a.wins[bl * win_stride + tid];
     hit = mine.w > 0 && mine.x0 < x1 && mine.x0 + mine.w > x0 && mine.z0 < z1 && mine.z0 + mine.h > z0;
   }
   const unsigned long long votes = __builtin_amdgcn_ballot_w64(hit);
@@ -816,7 +841,10 @@ k_window_merge_tiled(MergeArgs a) {
   __syncthreads();
 
   const int x = x0 + ((tid & (kTileGroups - 1)) << 2), zb = z0 + tid / kTileGroups;
-  if (x >= x1 || zb >= z1) return;
+  if (x >= x1 || zb >= z1) {
+    signal_slot_free(a.signal, a.ticket);
+    return;
+  }
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
   const float* slabs = a.slabs + (size_t)fc * a.nparts * a.slab_stride;
   for (int j = 0; j < n; ++j) {
@@ -836,6 +864,7 @@ k_window_merge_tiled(MergeArgs a) {
                       ((uint32_t)mask_of(acc.z, a.fill) << 16) |
                       ((uint32_t)mask_of(acc.w, a.fill) << 24);
   *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+  signal_slot_free(a.signal, a.ticket);
 }
 
 // Batch fuse (north_star "projected+fused"): fused[c] = max/min over the frames
@@ -925,6 +954,8 @@ struct FuseWinArgs {
   int gx0, gz0, gx1, gz1;     // bounding box of every window of the call (cells, half open)
   float fill;
   const Win16* wins;          // (B_total, nparts)   written by k_window_scatter
+  uint32_t* signal;           // table ring (see MergeArgs)
+  uint32_t ticket;
   const float* slabs;         // ((b * oc + chl) * nparts + p) * slab_stride
   float* fused;               // (oc_total, mh, mw)
   uint8_t* fused_mask;
@@ -970,6 +1001,7 @@ k_fuse_windows(FuseWinArgs a) {
       }
       *reinterpret_cast<uint32_t*>(a.fused_mask + cell) = mk;
     }
+    signal_slot_free(a.signal, a.ticket);
     return;
   }
   const int gi = threadIdx.x & (kFuseGroups - 1), lane = threadIdx.x / kFuseGroups;
@@ -1041,6 +1073,7 @@ k_fuse_windows(FuseWinArgs a) {
                         ((uint32_t)mask_of(acc.w, a.fill) << 24);
     *reinterpret_cast<uint32_t*>(a.fused_mask + cell) = mk;
   }
+  signal_slot_free(a.signal, a.ticket);
 }
 
 }  // namespace
@@ -1101,6 +1134,13 @@ struct Staged {                 // what run_window keeps between its passes
   Win16* g_wins;                // device copies (workspace head)
   Win16* g_unions;
   const ScatterTables* d_tables;  // one per chunk of frames
+  // d_tables is a slot of the thread's table ring (device memory the host wrote through the
+  // PCIe BAR, no copy operation): only k_window_scatter may read it, the kernel that follows
+  // signals the slot free.  Else: the workspace, filled by a stream-ordered copy.
+  bool ring_tables;
+  uint32_t* slot_done;            // pinned host word the signalling kernel stores its ticket to
+  uint32_t* slot_issued;          // host: ticket of the last signalling launch that used the slot
+  uint32_t* ring_ticket;          // host: the ring's ticket counter
   int chunk;                    // frames per chunk
   size_t geom_bytes;
   bool fast, fast_div;
@@ -1222,7 +1262,17 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
         MergeArgs ma;
         ma.b0 = b0; ma.oc = oc; ma.ch0 = ch0; ma.oc_total = oc_total; ma.mh = p.mh; ma.mw = p.mw;
         ma.nparts = st.nparts; ma.slab_stride = st.slab_stride; ma.fill = fill;
-        ma.tables = st.d_tables + b0 / chunk;
+        ma.signal = nullptr; ma.ticket = 0;
+        if (st.ring_tables) {
+          ma.wins = st.g_wins + (size_t)b0 * st.nparts; ma.unions = st.g_unions + b0;
+          ma.win_stride = st.nparts;
+          ma.signal = st.slot_done;
+          ma.ticket = *st.slot_issued = ++*st.ring_ticket;
+        } else {
+          const ScatterTables* t = st.d_tables + b0 / chunk;     // device address arithmetic only
+          ma.wins = t->wins; ma.unions = t->unions;
+          ma.win_stride = st.nparts <= kFewParts ? kFewParts : st.nparts;
+        }
         ma.slabs = slabs; ma.out = out; ma.mask = mask;
         if (st.nparts >= kTiledMergeParts) {
           const dim3 g((unsigned)st.max_tiles, nb * oc);
@@ -1243,6 +1293,11 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
       fa.accumulate = accumulate; fa.fill = fill;
       fa.gx0 = st.gx0; fa.gz0 = st.gz0; fa.gx1 = st.gx1; fa.gz1 = st.gz1;
       fa.wins = st.g_wins; fa.slabs = slabs; fa.fused = fused; fa.fused_mask = fused_mask;
+      fa.signal = nullptr; fa.ticket = 0;
+      if (st.ring_tables) {
+        fa.signal = st.slot_done;
+        fa.ticket = *st.slot_issued = ++*st.ring_ticket;
+      }
       const int bw4 = (st.gx1 - st.gx0) / 4;
       const int heavy = st.gx1 > st.gx0 ? ((bw4 + kFuseGroups - 1) / kFuseGroups) * (st.gz1 - st.gz0) : 0;
       const int per_fill_block = kFuseGroups * kFuseLanes * 8;
@@ -1260,8 +1315,7 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
 // What the previous calls of a shape settled on: the split into parts (stage_windows) and
 // whether the frames have to go through in halves (run_window).  Per thread, a few shapes.
 struct Remembered {
-  int B, H, W, mh, mw, oc;
-  float res, dmin, dmax;
+  dm_params key;
   Parts parts;
   bool valid, halve;
   int hopeless;          // calls left before the search is tried again after it failed
@@ -1269,20 +1323,17 @@ struct Remembered {
 Remembered& remembered(const dm_params& p) {
   thread_local Remembered slots[4] = {};
   thread_local int next = 0;
-  const int oc = p.vc ? p.vc : p.dc;
   for (Remembered& r : slots)
-    if (r.B == p.B && r.H == p.H && r.W == p.W && r.mh == p.mh && r.mw == p.mw && r.oc == oc &&
-        r.res == p.res && r.dmin == p.dmin && r.dmax == p.dmax)
-      return r;
+    if (memcmp(&r.key, &p, sizeof(dm_params)) == 0) return r;
   Remembered& r = slots[next];
   next = (next + 1) % 4;
   r = Remembered{};
-  r.B = p.B; r.H = p.H; r.W = p.W; r.mh = p.mh; r.mw = p.mw; r.oc = oc;
-  r.res = p.res; r.dmin = p.dmin; r.dmax = p.dmax;
+  r.key = p;
   return r;
 }
 
 thread_local int g_last_split[4] = {0, 0, 0, 0};   // dm_debug_last_split
+thread_local bool g_force_bands = false;           // dm_debug_force_bands
 
 // Depth bands multiply the workgroups, each with a window to initialise and flush: with few
 // pixels per part that costs more than the generic path's atomics.  Both sides as measured on
@@ -1307,12 +1358,74 @@ bool banded_split_pays(const dm_params& p, const Parts& parts, int nparts, int m
   return t_window < t_generic;
 }
 
+// The scatter tables of a call are ~10 KB the kernels need before they can start.  Staging
+// them with a stream-ordered copy costs a copy kernel and a dependent launch (~4 us of every
+// call).  On a large-BAR system the host instead writes them straight into device memory: a
+// per-thread, per-device ring of kTableSlots fine-grained device buffers (1.4 MB, allocated on
+// first use, kept for the life of the process -- the library's only persistent allocation).
+// PCIe keeps posted writes ordered ahead of the packet fetch that starts the kernel.  A slot
+// is reused only after the kernel that follows its k_window_scatter in stream order has
+// stored the slot's ticket to pinned host memory; the host waits for that (bounded), and
+// without a free slot or a large BAR the call takes the staged copy.
+constexpr int kTableSlots = 64;
+struct TableRing {
+  ScatterTables* slots = nullptr;            // device memory, host-writable
+  volatile uint32_t* done = nullptr;         // pinned host memory, written by the GPU
+  uint32_t issued[kTableSlots] = {};         // ticket of the last signalling launch per slot
+  uint32_t ticket = 0;
+  int next = 0;
+  bool tried = false, off = false;
+
+  int acquire() {
+    if (!tried) {
+      tried = true;
+      static const bool disabled = getenv("DM_NO_TABLE_RING") != nullptr;
+      int dev = 0, large_bar = 0;
+      void* d = nullptr;
+      void* h = nullptr;
+      if (disabled || hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess ||
+          !large_bar ||
+          hipExtMallocWithFlags(&d, kTableSlots * sizeof(ScatterTables), hipDeviceMallocFinegrained) !=
+              hipSuccess) {
+        (void)hipGetLastError();
+        off = true;
+      } else if (hipHostMalloc(&h, kTableSlots * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(d);
+        off = true;
+      } else {
+        slots = static_cast<ScatterTables*>(d);
+        done = static_cast<volatile uint32_t*>(h);
+        for (int i = 0; i < kTableSlots; ++i) done[i] = 0;
+      }
+    }
+    if (off) return -1;
+    const int i = next;
+    if (done[i] != issued[i]) {              // the GPU is kTableSlots calls behind: wait for it
+      const auto t0 = std::chrono::steady_clock::now();
+      while (done[i] != issued[i]) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return -1;
+        __builtin_ia32_pause();
+      }
+    }
+    next = (next + 1) % kTableSlots;
+    return i;
+  }
+};
+TableRing& table_ring() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  thread_local TableRing rings[16];
+  return rings[dev >= 0 && dev < 16 ? dev : 0];
+}
+
 // Host-side geometry of a call: parts, part windows, frame records.  Returns
 // hipErrorNotSupported when the windows cannot be made to fit in LDS (the caller then
 // takes the generic path); nothing has been enqueued in that case.
 hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* ws,
                          size_t ws_bytes, Staged& st, size_t& slab_bytes, hipStream_t s,
-                         hipEvent_t before = nullptr) {
+                         hipEvent_t before = nullptr, bool will_fuse_windows = false) {
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return hipErrorNotSupported;
   thread_local std::vector<FrameRec> recs;
   thread_local std::vector<Win16> wins;      // (B, nparts) then (B) unions
@@ -1372,7 +1485,11 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
   // the split that worked for the previous call of the same shape is tried first (the answer
   // moves with the poses only): one evaluation per call in the steady state
   Remembered& last = remembered(p);
-  if (last.hopeless > 0) { --last.hopeless; return hipErrorNotSupported; }
+  if (last.hopeless > 0 && !g_force_bands) {
+    --last.hopeless;
+    g_last_split[0] = g_last_split[1] = g_last_split[2] = 0;
+    return hipErrorNotSupported;
+  }
   const bool same_shape = last.valid && (last.parts.pd == 1 || can_band);
   bool fits = same_shape && evaluate(last.parts);
   if (!fits) {
@@ -1403,7 +1520,7 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
       if (same_shape && c.pc == last.parts.pc && c.pr == last.parts.pr && c.pd == last.parts.pd) continue;
       if (evaluate(c)) {
         const size_t geom = geometry_bytes(p.B, st.nparts);
-        fits = c.pd == 1 || banded_split_pays(p, c, st.nparts, max_area, ws_bytes > geom ? ws_bytes - geom : 0);
+        fits = c.pd == 1 || g_force_bands || banded_split_pays(p, c, st.nparts, max_area, ws_bytes > geom ? ws_bytes - geom : 0);
         break;            // splits of more parts cost more still
       }
     }
@@ -1479,6 +1596,22 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
   const size_t table_bytes =
       nchunks > 1 ? (size_t)nchunks * sizeof(ScatterTables)
                   : offsetof(ScatterTables, wins) + (size_t)p.B * win_stride * sizeof(Win16);
+  st.ring_tables = false;
+  // a follow-up kernel has to exist to signal the slot free (no union window: no merge)
+  if (nchunks == 1 && (will_fuse_windows || st.max_union > 0)) {
+    TableRing& ring = table_ring();
+    const int i = ring.acquire();
+    if (i >= 0) {
+      memcpy(ring.slots + i, tabs.data(), table_bytes);       // write-combined, through the BAR
+      __builtin_ia32_sfence();                                // on the bus before the launch is
+      st.d_tables = ring.slots + i;
+      st.ring_tables = true;
+      st.slot_done = const_cast<uint32_t*>(ring.done + i);
+      st.slot_issued = ring.issued + i;
+      st.ring_ticket = &ring.ticket;
+      return hipSuccess;
+    }
+  }
   return hipMemcpyAsync(const_cast<ScatterTables*>(st.d_tables), tabs.data(), table_bytes,
                         hipMemcpyHostToDevice, s);
 }
@@ -1499,7 +1632,11 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
   Staged st;
   size_t slab_bytes = 0;
   Remembered& shape = remembered(p);
-  if (shape.hopeless > 0) { --shape.hopeless; return hipErrorNotSupported; }
+  if (shape.hopeless > 0 && !g_force_bands) {
+    --shape.hopeless;
+    g_last_split[0] = g_last_split[1] = g_last_split[2] = 0;
+    return hipErrorNotSupported;
+  }
   hipError_t e = shape.halve && !fused && p.B >= 2
                      ? hipErrorOutOfMemory
                      : stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s, before_projection);
@@ -1568,7 +1705,7 @@ hipError_t run_window_fused(const dm_params& p, const dm_frame* frames_host, con
     return hipErrorNotSupported;
   Staged st;
   size_t slab_bytes = 0;
-  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s);
+  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s, nullptr, true);
   if (e != hipSuccess) return e;
   return window_pass(p, st, reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + st.geom_bytes),
                      depth, value, valid, nullptr, nullptr,
@@ -1581,6 +1718,12 @@ hipError_t run_window_fused(const dm_params& p, const dm_frame* frames_host, con
 extern "C" __attribute__((visibility("default"))) void dm_debug_last_split(int32_t* out4) {
   for (int i = 0; i < 4; ++i) out4[i] = dm::g_last_split[i];
   dm::g_last_split[3] = 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int dm_debug_force_bands(int on) {
+  const int old = dm::g_force_bands;
+  dm::g_force_bands = on != 0;
+  return old;
 }
 
 #ifdef DM_STAMPS

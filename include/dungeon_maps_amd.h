@@ -10,16 +10,24 @@
  * Conventions
  *  - plain pointers and sizes only; every pointer named *_dev is DEVICE memory
  *    (hipMalloc / PyTorch caching allocator), contiguous, float32 unless said
- *    otherwise.  `frames` is a HOST array (pageable is fine): it is staged to
- *    the device with a stream-ordered copy inside the call and may be reused as
- *    soon as the call returns.  The library never allocates or frees device
- *    memory: scratch is a caller-provided workspace (dm_*_workspace_bytes,
- *    256-byte aligned).
+ *    otherwise.  `frames` is a HOST array (pageable is fine): the call copies
+ *    what it needs out of it and it may be reused as soon as the call returns.
+ *    Scratch is a caller-provided workspace (dm_*_workspace_bytes, 256-byte
+ *    aligned); the library never frees caller memory.  Its one allocation of
+ *    its own: on a large-BAR system each calling thread keeps, per device, a
+ *    ring of 64 frame-table slots in device memory (1.4 MB, made on first use,
+ *    kept for the life of the process) that the host writes directly, which
+ *    saves a copy operation per call; DM_NO_TABLE_RING=1 in the environment
+ *    turns it off (the tables are then staged into the workspace by a
+ *    stream-ordered copy).
  *  - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
- *    the default stream).  No host synchronisation inside.
+ *    the default stream).  No host synchronisation inside, except that a
+ *    thread more than 64 projection calls ahead of the GPU waits for a table
+ *    slot (bounded; it then falls back to the staged copy).
  *  - return 0 on success, a negative dm_status otherwise; dm_last_error()
  *    returns a thread-local message.  No exceptions cross the ABI.
- *  - re-entrant; no global state besides the thread-local error string.
+ *  - re-entrant; no global state besides thread-local data (error string,
+ *    table ring, the remembered split of recent call shapes).
  */
 #ifndef DUNGEON_MAPS_AMD_H
 #define DUNGEON_MAPS_AMD_H
@@ -260,6 +268,13 @@ int dm_debug_force_generic_path(int on);
  * parts 0 x 0 x 0 when the windows did not fit and the call took the generic path.
  */
 void dm_debug_last_split(int32_t* out4);
+
+/*
+ * Test hook: non-zero makes the calling thread's projections take a split with depth bands
+ * whenever one fits in LDS, also where the cost model would choose the generic path (small
+ * images); returns the previous setting.  Lets the parity tests cover bands on small shapes.
+ */
+int dm_debug_force_bands(int on);
 
 /*
  * Measurement hook (bench.py): the next dm_orth_project_f32 call on this thread

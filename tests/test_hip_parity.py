@@ -340,6 +340,11 @@ def test_full_size_properties(dmap):
     dict(B=2, H=960, W=1280, mh=2048, mw=2048, res=0.01, C=2, fill_value=0.0, bands=True, valid=True),
     dict(B=2, H=960, W=1280, mh=2048, mw=2048, res=0.01, reduction="min", fill_value=np.inf, bands=True),
     dict(B=16, H=960, W=1280, mh=2048, mw=2048, res=0.01, bands=True, halves=True),  # slabs > workspace
+    # small images: the cost model would take the generic path, the test hook insists on bands
+    dict(B=3, H=120, W=160, mh=512, mw=512, res=0.01, bands=True, force_bands=True),
+    dict(B=5, H=96, W=128, mh=512, mw=640, res=0.0125, bands=True, force_bands=True, valid=True,
+         clip_border=3, trunc_height_max=0.9, flip_h=False),
+    dict(B=2, H=120, W=160, mh=512, mw=512, res=0.0125, C=3, fill_value=0.0, bands=True, force_bands=True),
 ])
 def test_window_path_equals_generic_path(dmap, oracle, case):
   from dungeon_maps_amd import _native
@@ -348,6 +353,7 @@ def test_window_path_equals_generic_path(dmap, oracle, case):
   C, dcn = c.pop("C", 0), c.pop("dc", 1)
   use_valid = c.pop("valid", False)
   want_bands, want_halves = c.pop("bands", False), c.pop("halves", False)
+  force_bands = c.pop("force_bands", False)
   res = c.pop("res", 0.05)
   woff = c.pop("woff", mw / 2.)
   depth, pose = _synthetic(B, H, W, seed=4321)
@@ -368,7 +374,11 @@ def test_window_path_equals_generic_path(dmap, oracle, case):
   cfg.update(c)
   lib = _native.lib()
   gh = bool(C)
-  fast = _run(dmap, cfg, depth, value=value, valid=valid, get_height_map=gh, cam_pose=pose)
+  lib.dm_debug_force_bands(1 if force_bands else 0)
+  try:
+    fast = _run(dmap, cfg, depth, value=value, valid=valid, get_height_map=gh, cam_pose=pose)
+  finally:
+    lib.dm_debug_force_bands(0)
   split = (ctypes.c_int32 * 4)()
   lib.dm_debug_last_split(split)
   if want_bands:
@@ -422,3 +432,46 @@ def test_cfg5_geometry_and_large_batches(dmap, oracle):
   np.testing.assert_array_equal(top.cpu().numpy(), want[0])
   np.testing.assert_array_equal(mask.cpu().numpy(), want[1])
   assert torch.equal(fused, top.amax(dim=0)) and torch.equal(fmask, mask.any(dim=0))
+
+
+# --------------------------------------------------------------------------
+# Table ring: the host writes each call's frame tables into one of 64 device slots through
+# the PCIe BAR and reuses a slot only after the GPU has signalled it free.
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,mh,mw,calls", [
+    (3, 96, 128, 128, 128, 200),       # small calls: the host cycles the ring three times
+    (64, 480, 640, 512, 512, 300),     # cfg2: the host runs ahead of the GPU and has to wait for slots
+])
+def test_table_ring_reuse(dmap, B, H, W, mh, mw, calls):
+  from dungeon_maps_amd import _native
+  lib = _native.lib()
+  depth, _ = _synthetic(B, H, W, seed=99)
+  depth_d = torch.from_numpy(depth).cuda()
+  proj = dmap.MapProjector(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+                           cam_height=0.88, width_offset=mw / 2., height_offset=mh / 2., map_res=0.03,
+                           map_width=mw, map_height=mh, trunc_depth_min=0.15, trunc_depth_max=5.05,
+                           to_global=True, fill_value=-np.inf)
+  g = torch.Generator().manual_seed(7)
+  poses = []
+  for _ in range(5):                   # five pose sets, visited in turn: every slot sees them all
+    pose = torch.empty(B, 3).uniform_(-1, 1, generator=g)
+    pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)
+    poses.append(pose)
+  lib.dm_debug_force_generic_path(1)
+  try:
+    refs = [proj.orth_project_and_fuse(depth_d, cam_pose=pose) for pose in poses]
+  finally:
+    lib.dm_debug_force_generic_path(0)
+  bad = torch.zeros((), dtype=torch.int64, device="cuda")
+  for i in range(calls):               # no host sync inside the loop
+    got = proj.orth_project_and_fuse(depth_d, cam_pose=poses[i % 5])
+    ref = refs[i % 5]
+    bad += (got[0] != ref[0]).sum() + (got[1] != ref[1]).sum() + (got[2] != ref[2]).sum()
+  assert int(bad.item()) == 0
+  # the same through the batch-fused entry point (k_fuse_windows signals the slot)
+  ref_f = [r[2] for r in refs]
+  bad.zero_()
+  for i in range(calls // 2):
+    fused, _ = proj.orth_project_fused(depth_d, cam_pose=poses[i % 5])
+    bad += (fused != ref_f[i % 5]).sum()
+  assert int(bad.item()) == 0

@@ -1,7 +1,7 @@
 """One-off parity campaign (GPU box): the seeded parameter sweep of
 tests/test_hip_parity.py::test_random_configurations_vs_oracle for many more seeds, plus
 larger frames; prints every mismatch.  Usage: python tools/parity_campaign.py [first] [count]"""
-import os, sys
+import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,6 +16,10 @@ def one(seed):
   if B * H * W > 3_000_000:
     B = max(1, 3_000_000 // (H * W))
   mh, mw = [(64, 64), (96, 128), (128, 96), (160, 160), (256, 256), (300, 200)][int(rng.integers(6))]
+  if FINE:      # long thin wedges: the windowed path needs depth bands (forced on small images)
+    mh, mw = [(512, 512), (768, 1024), (1024, 1024), (1024, 640)][int(rng.integers(4))]
+    if B * mh * mw > 12_000_000:
+      B = max(1, 12_000_000 // (mh * mw))
   if rng.integers(2):
     rows = np.arange(H, dtype=np.float64).reshape(1, 1, H, 1)
     wall = rng.uniform(1.0, 6.0, size=(B, 1, 1, W // 8 + 1)).repeat(8, axis=3)[..., :W]
@@ -33,11 +37,13 @@ def one(seed):
   camh = rng.uniform(0.2, 2.0, size=B if per_frame else 1).astype(np.float32)
   is_max = bool(rng.integers(4))
   res = float(rng.choice([0.02, 0.03, 0.05, 0.08, 0.1, 1.0 / 3, 0.0625]))
+  if FINE:
+    res = float(rng.choice([0.004, 0.006, 0.008, 0.01, 0.0125, 0.015]))
   cfg = dict(width=W, height=H, hfov=float(rng.uniform(0.6, 2.0)),
              vfov=None if rng.integers(2) else float(rng.uniform(0.5, 1.6)),
              cam_pitch=pitch, cam_height=camh,
-             width_offset=float(mw / 2 + rng.uniform(-40, 40)),
-             height_offset=float(mh / 2 + rng.uniform(-40, 40)),
+             width_offset=float(mw / 2 + rng.uniform(-40, 40) * (8 if FINE else 1)),
+             height_offset=float(mh / 2 + rng.uniform(-40, 40) * (8 if FINE else 1)),
              map_res=res, map_width=mw, map_height=mh,
              trunc_depth_min=None if EDGE and rng.integers(6) == 0 else float(rng.choice([0.0, 0.15, 0.5])),
              trunc_depth_max=None if EDGE and rng.integers(6) == 0 else float(rng.choice([1.5, 2.5, 5.05, 7.0])),
@@ -60,6 +66,10 @@ def one(seed):
                            value_map=None if value is None else torch.from_numpy(value).cuda(),
                            valid_map=None if valid is None else torch.from_numpy(valid).cuda(),
                            cam_pose=pose, get_height_map=get_h)
+  split = (ctypes.c_int32 * 4)()
+  LIB.dm_debug_last_split(split)
+  STATS["banded"] += split[2] > 1
+  STATS["generic"] += split[0] == 0
   kw = dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose)
   want = oracle.orth_project(depth, value_map=value, valid_map=valid, get_height_map=get_h,
                              nthreads=16, **kw)
@@ -70,6 +80,11 @@ def one(seed):
     bad_v += int((~((a == b) | (np.isnan(a) & np.isnan(b)))).sum())
   return bad_m, bad_v, (B, H, W, mh, mw, res, C)
 
+FINE = os.environ.get("DM_CAMPAIGN_FINE", "0") != "0"    # fine map_res: depth bands (forced)
+STATS = {"banded": 0, "generic": 0}
+from dungeon_maps_amd import _native
+LIB = _native.lib()
+LIB.dm_debug_force_bands(1 if FINE else 0)
 SEMANTIC = os.environ.get("DM_CAMPAIGN_SEMANTIC", "1") != "0"
 EDGE = os.environ.get("DM_CAMPAIGN_EDGE", "1") != "0"      # NaN/inf depths, missing truncations
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -82,4 +97,5 @@ for s in range(first, first + count):
     print("MISMATCH seed", s, shape, "mask cells", bm, "map cells", bv, flush=True)
   if (s - first) % 50 == 49:
     print("  ... %d configurations, %d with mismatches" % (s - first + 1, bad), flush=True)
-print("done: %d configurations, %d with mismatches" % (count, bad))
+print("done: %d configurations, %d with mismatches (%d took depth bands, %d the generic path)"
+      % (count, bad, STATS["banded"], STATS["generic"]))

@@ -208,10 +208,15 @@ __host__ FrameAffine frame_affine(const dm_params& p, const dm_frame& f) {
 }
 
 // Footprint of the pixel rectangle [q0,q1) x [r0,r1) of a frame in map cells,
-// padded by 2 cells and aligned to 4 columns, clipped to the map.
-__host__ Window part_window(const dm_params& p, const FrameAffine& fa, int q0, int q1, int r0,
-                            int r1, float dlo, float dhi) {
-  Window full = {0, 0, p.mw, p.mh};
+// padded by 2 cells and aligned to 4 columns, clipped to the map.  The ray slopes of the
+// rectangle's border pixels do not depend on the frame: PartSlopes holds them per part.
+struct PartSlopes {
+  double ax[2], ay[2];        // (q - cx) / fx at q0, q1 - 1;  (y - cy) / fy at r0, r1 - 1
+  bool empty;                 // nothing left of the part after clip_border
+};
+
+__host__ PartSlopes part_slopes(const dm_params& p, int q0, int q1, int r0, int r1) {
+  PartSlopes s;
   if (p.clip_border > 0) {
     const int c = p.clip_border;
     if (q0 < c) q0 = c;
@@ -219,28 +224,40 @@ __host__ Window part_window(const dm_params& p, const FrameAffine& fa, int q0, i
     if (q1 > p.W - c) q1 = p.W - c;
     if (r1 > p.H - c) r1 = p.H - c;
   }
-  if (q0 >= q1 || r0 >= r1) return Window{0, 0, 0, 0};
-  if (!p.has_dmin || !p.has_dmax || !(p.dmin >= 0.0f) || !(p.dmax >= p.dmin) ||
-      !isfinite(p.dmax) || !fa.finite)
-    return full;
-  double lo_x = INFINITY, hi_x = -INFINITY, lo_z = INFINITY, hi_z = -INFINITY;
+  s.empty = q0 >= q1 || r0 >= r1;
   const int qs[2] = {q0, q1 - 1}, rs[2] = {r0, r1 - 1};
+  for (int i = 0; i < 2; ++i) {
+    s.ax[i] = ((double)qs[i] - p.cx) / p.fx;
+    double yr = rs[i];
+    if (p.flip_h) yr = (double)(p.H - 1) - yr;
+    s.ay[i] = (yr - p.cy) / p.fy;
+  }
+  return s;
+}
+
+__host__ bool frustum_bounded(const dm_params& p) {
+  return p.has_dmin && p.has_dmax && p.dmin >= 0.0f && p.dmax >= p.dmin && isfinite(p.dmax);
+}
+
+__host__ Window part_window(const dm_params& p, const FrameAffine& fa, const PartSlopes& ps,
+                            bool bounded, float dlo, float dhi) {
+  if (ps.empty) return Window{0, 0, 0, 0};
+  if (!bounded || !fa.finite) return Window{0, 0, p.mw, p.mh};
+  double lo_x = INFINITY, hi_x = -INFINITY, lo_z = INFINITY, hi_z = -INFINITY;
+  double poison = 0.0;                         // NaN as soon as one corner is not finite
   const double zs[2] = {dlo, dhi};
-  for (int qi = 0; qi < 2; ++qi) {
-    const double ax = ((double)qs[qi] - p.cx) / p.fx;
+  for (int qi = 0; qi < 2; ++qi)
     for (int ri = 0; ri < 2; ++ri) {
-      double yr = rs[ri];
-      if (p.flip_h) yr = (double)(p.H - 1) - yr;
-      const double ay = (yr - p.cy) / p.fy;
-      const double sx = fa.xa * ax + fa.xb * ay + fa.xc, sz = fa.za * ax + fa.zb * ay + fa.zc;
+      const double sx = fa.xa * ps.ax[qi] + fa.xb * ps.ay[ri] + fa.xc;
+      const double sz = fa.za * ps.ax[qi] + fa.zb * ps.ay[ri] + fa.zc;
       for (int zi = 0; zi < 2; ++zi) {
         const double xf = zs[zi] * sx + fa.xd, zf = zs[zi] * sz + fa.zd;
-        lo_x = fmin(lo_x, xf); hi_x = fmax(hi_x, xf);
-        lo_z = fmin(lo_z, zf); hi_z = fmax(hi_z, zf);
+        lo_x = xf < lo_x ? xf : lo_x; hi_x = xf > hi_x ? xf : hi_x;
+        lo_z = zf < lo_z ? zf : lo_z; hi_z = zf > hi_z ? zf : hi_z;
+        poison += xf * 0.0 + zf * 0.0;
       }
     }
-  }
-  if (!isfinite(lo_x) || !isfinite(hi_x) || !isfinite(lo_z) || !isfinite(hi_z)) return full;
+  if (!(poison == 0.0)) return Window{0, 0, p.mw, p.mh};
   // cells are floor(v + 0.5); 2 cells of slack cover the float32 rounding of
   // the device arithmetic (observed error < 1e-3 cell)
   double x0 = floor(lo_x + 0.5) - 2, x1 = floor(hi_x + 0.5) + 3;
@@ -1434,35 +1451,43 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
   int max_area = 0;
   const bool can_band = p.has_dmin && p.has_dmax && p.dmin >= 0.0f && p.dmax > p.dmin &&
                         isfinite(p.dmax);
+  thread_local std::vector<PartSlopes> slopes;
+  const bool bounded = frustum_bounded(p);
   auto evaluate = [&](const Parts& parts) -> bool {
     const int pd = parts.pd;
     st.parts = parts;
-    st.nparts = parts.pc * parts.pr * pd;
+    const int image_parts = parts.pc * parts.pr;
+    st.nparts = image_parts * pd;
     wins.resize((size_t)p.B * (st.nparts + 1));
     Win16* unions = wins.data() + (size_t)p.B * st.nparts;
+    slopes.resize(image_parts);
+    for (int pr = 0; pr < parts.pr; ++pr)
+      for (int pc = 0; pc < parts.pc; ++pc) {
+        const int q0 = pc * parts.wp, r0 = pr * parts.hp;
+        const int q1 = q0 + parts.wp < p.W ? q0 + parts.wp : p.W;
+        const int r1 = r0 + parts.hp < p.H ? r0 + parts.hp : p.H;
+        slopes[pr * parts.pc + pc] = part_slopes(p, q0, q1, r0, r1);
+      }
     max_area = 0; st.max_union = 0; st.max_tiles = 0;
     st.gx0 = p.mw; st.gz0 = p.mh; st.gx1 = 0; st.gz1 = 0;
     for (int b = 0; b < p.B; ++b) {
       int ux0 = p.mw, ux1 = 0, uz0 = p.mh, uz1 = 0;
       const FrameAffine fa = frame_affine(p, frames_host[b]);
+      Win16* row = wins.data() + (size_t)b * st.nparts;
       for (int k = 0; k < pd; ++k) {
         float dlo = p.dmin, dhi = p.dmax;
         if (pd > 1) band_bounds(p.dmin, p.dmax, pd, k, dlo, dhi);
-        for (int pr = 0; pr < parts.pr; ++pr)
-          for (int pc = 0; pc < parts.pc; ++pc) {
-            const int q0 = pc * parts.wp, r0 = pr * parts.hp;
-            const int q1 = q0 + parts.wp < p.W ? q0 + parts.wp : p.W;
-            const int r1 = r0 + parts.hp < p.H ? r0 + parts.hp : p.H;
-            const Window w = part_window(p, fa, q0, q1, r0, r1, dlo, dhi);
-            wins[(size_t)b * st.nparts + (k * parts.pr + pr) * parts.pc + pc] = narrow(w);
-            if (w.w * w.h > max_area) max_area = w.w * w.h;
-            if (w.w > 0) {
-              if (w.x0 < ux0) ux0 = w.x0;
-              if (w.x0 + w.w > ux1) ux1 = w.x0 + w.w;
-              if (w.z0 < uz0) uz0 = w.z0;
-              if (w.z0 + w.h > uz1) uz1 = w.z0 + w.h;
-            }
+        for (int ip = 0; ip < image_parts; ++ip) {
+          const Window w = part_window(p, fa, slopes[ip], bounded, dlo, dhi);
+          row[k * image_parts + ip] = narrow(w);
+          if (w.w * w.h > max_area) max_area = w.w * w.h;
+          if (w.w > 0) {
+            if (w.x0 < ux0) ux0 = w.x0;
+            if (w.x0 + w.w > ux1) ux1 = w.x0 + w.w;
+            if (w.z0 < uz0) uz0 = w.z0;
+            if (w.z0 + w.h > uz1) uz1 = w.z0 + w.h;
           }
+        }
       }
       const Window U = ux1 > ux0 ? Window{ux0, uz0, ux1 - ux0, uz1 - uz0} : Window{0, 0, 0, 0};
       unions[b] = narrow(U);
@@ -1631,6 +1656,12 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     return hipErrorNotSupported;
   Staged st;
   size_t slab_bytes = 0;
+#ifdef DM_HOST_TIMING
+  using clk = std::chrono::steady_clock;
+  thread_local double acc_t[4] = {0, 0, 0, 0};
+  thread_local int calls_t = 0;
+  const auto t_0 = clk::now();
+#endif
   Remembered& shape = remembered(p);
   if (shape.hopeless > 0 && !g_force_bands) {
     --shape.hopeless;
@@ -1662,6 +1693,9 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     return e;
   }
   if (e != hipSuccess) return e;
+#ifdef DM_HOST_TIMING
+  const auto t_1 = clk::now();
+#endif
   unsigned char* base = static_cast<unsigned char*>(ws);
   float* slabs = reinterpret_cast<float*>(base + st.geom_bytes);
 
@@ -1682,6 +1716,9 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     e = hipEventRecord(after_projection, s);
     if (e != hipSuccess) return e;
   }
+#ifdef DM_HOST_TIMING
+  const auto t_2 = clk::now();
+#endif
   if (fused) {
     FuseArgs fa;
     fa.B = p.B; fa.b0 = 0; fa.accumulate = 0;
@@ -1693,6 +1730,17 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
                : launch(k_fuse_unions<false>, g, blk, 0, s, fa);
     if (e != hipSuccess) return e;
   }
+#ifdef DM_HOST_TIMING
+  const auto t_3 = clk::now();
+  acc_t[0] += std::chrono::duration<double, std::micro>(t_1 - t_0).count();
+  acc_t[1] += std::chrono::duration<double, std::micro>(t_2 - t_1).count();
+  acc_t[2] += std::chrono::duration<double, std::micro>(t_3 - t_2).count();
+  if (++calls_t % 200 == 0) {
+    fprintf(stderr, "[dm timing] stage %.2f us  window_pass %.2f us  fuse %.2f us per call\n",
+            acc_t[0] / 200, acc_t[1] / 200, acc_t[2] / 200);
+    acc_t[0] = acc_t[1] = acc_t[2] = 0;
+  }
+#endif
   return hipSuccess;
 }
 

@@ -39,7 +39,9 @@ def _column(value, batch: int, width: Optional[int] = None) -> np.ndarray:
   """float32 (batch,) or (batch, width) array from a scalar / list / array /
   tensor that has either 1 or ``batch`` rows."""
   if torch.is_tensor(value):
-    value = value.detach().to(device="cpu", dtype=torch.float32).numpy()
+    if value.device.type != "cpu" or value.dtype != torch.float32 or value.requires_grad:
+      value = value.detach().to(device="cpu", dtype=torch.float32)
+    value = value.numpy()
   a = np.asarray(value, dtype=_F32)
   a = a.reshape(-1) if width is None else a.reshape(-1, width)
   if a.shape[0] == 1 and batch != 1:
@@ -52,7 +54,9 @@ def _column(value, batch: int, width: Optional[int] = None) -> np.ndarray:
 def _sin_cos(angles: np.ndarray):
   """float32 sin/cos with torch's CPU kernels; |a| <= eps clamps to 0."""
   a = np.array(angles, dtype=_F32)            # private, contiguous copy
-  a[np.abs(a) <= _ANGLE_EPS] = 0.0
+  small = np.abs(a) <= _ANGLE_EPS
+  if small.any():
+    a[small] = 0.0
   t = torch.from_numpy(a)
   return torch.sin(t).numpy(), torch.cos(t).numpy()
 
@@ -75,11 +79,12 @@ def _terms(angle, batch: int):
   return s, _ONE - (_ONE - c)            # (1 + sin*0) + (1 - cos) * (-1), float32
 
 
-def build_frame_table(batch: int, cam_pose, cam_pitch, cam_height, width_offset,
-                      height_offset, inverse_pitch: bool = False) -> torch.Tensor:
-  """(batch, 32) float32 CPU tensor laid out as ``dm_frame``:
-  [0:9] Rp, [9] cam_height, [10:19] Ry, [19] tx, [20] tz, [21] woff, [22] hoff,
-  [23:32] rotate(X, -pitch) when ``inverse_pitch`` (camera_affine_grid)."""
+_static_tables = {}   # scalar camera state -> (batch, 32) table with everything but yaw / pose
+
+
+def _static_columns(batch: int, cam_pitch, cam_height, width_offset, height_offset,
+                    inverse_pitch: bool) -> np.ndarray:
+  """The columns that do not depend on the pose; yaw = identity, no translation."""
   table = np.zeros((batch, FRAME_FLOATS), dtype=_F32)
   if inverse_pitch:
     neg = -cam_pitch if _is_scalar(cam_pitch) else -_column(cam_pitch, batch)
@@ -96,10 +101,35 @@ def build_frame_table(batch: int, cam_pose, cam_pitch, cam_height, width_offset,
   table[:, 7] = sp
   table[:, 8] = dp
   table[:, 9] = cam_height if _is_scalar(cam_height) else _column(cam_height, batch)
-  if cam_pose is None:
-    table[:, 10] = _ONE
-    table[:, 18] = _ONE
+  table[:, 10] = _ONE
+  table[:, 14] = _ONE
+  table[:, 18] = _ONE
+  table[:, 21] = width_offset if _is_scalar(width_offset) else _column(width_offset, batch)
+  table[:, 22] = height_offset if _is_scalar(height_offset) else _column(height_offset, batch)
+  return table
+
+
+def build_frame_table(batch: int, cam_pose, cam_pitch, cam_height, width_offset,
+                      height_offset, inverse_pitch: bool = False) -> torch.Tensor:
+  """(batch, 32) float32 CPU tensor laid out as ``dm_frame``:
+  [0:9] Rp, [9] cam_height, [10:19] Ry, [19] tx, [20] tz, [21] woff, [22] hoff,
+  [23:32] rotate(X, -pitch) when ``inverse_pitch`` (camera_affine_grid)."""
+  if _is_scalar(cam_pitch) and _is_scalar(cam_height) and _is_scalar(width_offset) \
+      and _is_scalar(height_offset):
+    # the usual case (one camera rig, shared offsets): only yaw and translation change per call
+    key = (batch, float(cam_pitch), float(cam_height), float(width_offset),
+           float(height_offset), inverse_pitch)
+    static = _static_tables.get(key)
+    if static is None:
+      static = _static_columns(batch, cam_pitch, cam_height, width_offset, height_offset,
+                               inverse_pitch)
+      if len(_static_tables) < 256:
+        _static_tables[key] = static
+    table = static.copy()
   else:
+    table = _static_columns(batch, cam_pitch, cam_height, width_offset, height_offset,
+                            inverse_pitch)
+  if cam_pose is not None:
     pose = _column(cam_pose, batch, 3)
     sy, dy = _terms(pose[:, 2], batch)
     table[:, 10] = dy
@@ -107,7 +137,4 @@ def build_frame_table(batch: int, cam_pose, cam_pitch, cam_height, width_offset,
     table[:, 16] = -sy
     table[:, 18] = dy
     table[:, 19:21] = pose[:, 0:2]
-  table[:, 14] = _ONE
-  table[:, 21] = width_offset if _is_scalar(width_offset) else _column(width_offset, batch)
-  table[:, 22] = height_offset if _is_scalar(height_offset) else _column(height_offset, batch)
   return torch.from_numpy(table)

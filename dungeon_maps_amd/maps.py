@@ -325,7 +325,7 @@ def _fuse_topdown_maps_native(maps, proj: MapProjector, fill_value, reduction):
     return None
   lib = _native.lib()
   stream = F._stream_ptr(dev)
-  with torch.cuda.device(dev):
+  with F._on_device(dev):
     stats = torch.empty(5, dtype=torch.int32, device=dev)
     for i, (src, _) in enumerate(srcs):
       _native.check(lib.dm_fuse_bbox_f32(ctypes.byref(src), stats.data_ptr(), int(i == 0), stream))

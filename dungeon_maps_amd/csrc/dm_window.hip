@@ -1422,7 +1422,13 @@ struct TableRing {
     if (done[i] != issued[i]) {              // the GPU is kTableSlots calls behind: wait for it
       const auto t0 = std::chrono::steady_clock::now();
       while (done[i] != issued[i]) {
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return -1;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+          // calls of several ms each (64 of them in flight), or a launch that failed after
+          // its slot was taken: this thread goes back to the staged copy for good -- 4 us
+          // per call are nothing to such calls, and nobody waits here twice
+          off = true;
+          return -1;
+        }
         __builtin_ia32_pause();
       }
     }

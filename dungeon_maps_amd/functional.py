@@ -95,7 +95,14 @@ def _on_device(device: torch.device):
   return torch.cuda.device(device)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr(device: torch.device) -> int:
+  """hipStream_t of PyTorch's current stream on ``device``, as an integer."""
+  if _raw_stream is not None:       # the pointer itself; a Stream object costs ~4 us to build
+    index = device.index
+    return _raw_stream(torch.cuda.current_device() if index is None else index)
   return torch.cuda.current_stream(device).cuda_stream
 
 

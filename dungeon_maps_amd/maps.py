@@ -51,6 +51,14 @@ class MapProjector:
     self.cam_params: CameraIntrinsics = utils.get_camera_intrinsics(
         width=width, height=height, hfov=hfov, vfov=vfov)
 
+  def __setattr__(self, name, value):
+    # the forwarding methods cache their resolved defaults on the instance
+    d = self.__dict__
+    if not name.startswith("_dm_defaults_"):
+      for k in [k for k in d if k.startswith("_dm_defaults_")]:
+        del d[k]
+    d[name] = value
+
   def clone(self, **overrides) -> "MapProjector":
     """Shallow copy with some fields replaced (None = keep)."""
     unknown = set(overrides) - set(self._FIELDS)
@@ -72,31 +80,39 @@ def _forwarding_method(fn, doc_ref: str):
   attrs = tuple(intr.get(n, n) for n in names)
   nargs = len(names)
 
+  cache_key = "_dm_defaults_" + fn.__name__
+
+  def resolve(self):
+    """(value for an argument that was not passed, value for one passed as None), per argument:
+    the projector's field / intrinsic, and for arguments not passed at all the functional
+    API's own default where the projector has none."""
+    cam = self.cam_params
+    field = []
+    for i in range(nargs):
+      kind = kinds[i]
+      field.append(getattr(self, attrs[i]) if kind == 1 else
+                   getattr(cam, attrs[i]) if kind == 2 else None)   # get(arg, self.<arg>)
+    absent = tuple(fn_defaults[i] if v is None else v for i, v in enumerate(field))
+    cached = (absent, tuple(field))
+    self.__dict__[cache_key] = cached          # dropped by MapProjector.__setattr__
+    return cached
+
   def method(self, *args, **kwargs):
-    if len(args) > nargs:
-      raise TypeError(f"{fn.__name__}() takes at most {nargs} arguments")
-    call = list(args) + [None] * (nargs - len(args))
     given = len(args)
+    if given > nargs:
+      raise TypeError(f"{fn.__name__}() takes at most {nargs} arguments")
+    absent, field = self.__dict__.get(cache_key) or resolve(self)
+    call = list(absent)
+    for i in range(given):
+      v = args[i]
+      call[i] = field[i] if v is None else v
     for k, v in kwargs.items():
       i = index.get(k)
       if i is None:
         raise TypeError(f"{fn.__name__}() got an unexpected keyword argument '{k}'")
       if i < given:
         raise TypeError(f"{fn.__name__}() got multiple values for argument '{k}'")
-      call[i] = v
-    cam = self.cam_params
-    for i in range(nargs):
-      if call[i] is None:
-        kind = kinds[i]
-        if kind == 1:
-          v = getattr(self, attrs[i])          # get(arg, self.<arg>)
-        elif kind == 2:
-          v = getattr(cam, attrs[i])
-        else:
-          v = None
-        if v is None and i >= given and names[i] not in kwargs:
-          v = fn_defaults[i]                   # the functional API's own default
-        call[i] = v
+      call[i] = field[i] if v is None else v
     return fn(*call)
 
   method.__name__ = fn.__name__

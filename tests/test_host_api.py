@@ -87,6 +87,16 @@ def test_projector_defaults_clone_and_forwarding():
   assert col.tolist() == [[7, 9]] and row.tolist() == [[-1, -3]]
   x, z = q.map_dequantize(col, row)
   np.testing.assert_allclose(x.numpy(), [[0.1, 0.2]], atol=0.025)
+  # the forwarding methods cache the projector's defaults: a changed field must show at once,
+  # an explicit argument wins, an explicit None falls back to the field
+  q.width_offset = 6.
+  assert q.map_quantize([0.1, 0.2], [0.3, 0.4])[0].tolist() == [[8, 10]]
+  assert q.map_quantize([0.1, 0.2], [0.3, 0.4], width_offset=5.)[0].tolist() == [[7, 9]]
+  assert q.map_quantize([0.1, 0.2], [0.3, 0.4], width_offset=None)[0].tolist() == [[8, 10]]
+  q.map_res = 0.1
+  assert q.map_quantize([0.1, 0.2], [0.3, 0.4])[0].tolist() == [[7, 8]]
+  with pytest.raises(TypeError):
+    q.map_quantize([0.1], [0.3], no_such_argument=1)
 
 
 def test_coordinate_queries_match_reference():

@@ -1,9 +1,9 @@
 """One-off (build container only: imports /root/reference): the oracle against the
 reference itself on many seeded random configurations -- a wider pin than the committed
-fixtures.  Usage: python tools/oracle_vs_reference.py [first] [count]"""
+fixtures.  Usage: python tests/campaigns/oracle_vs_reference.py [first] [count]"""
 import importlib.util, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(ROOT, "tests/golden/gen_golden.py"))
 gg = importlib.util.module_from_spec(spec); spec.loader.exec_module(gg)

@@ -1,9 +1,9 @@
 """One-off parity campaign (GPU box): the seeded parameter sweep of
 tests/test_hip_parity.py::test_random_configurations_vs_oracle for many more seeds, plus
-larger frames; prints every mismatch.  Usage: python tools/parity_campaign.py [first] [count]"""
+larger frames; prints every mismatch.  Usage: python tests/campaigns/parity_campaign.py [first] [count]"""
 import ctypes, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import dungeon_maps_amd as dmap
 from oracle import oracle

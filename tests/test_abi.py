@@ -82,3 +82,10 @@ def test_product_does_not_import_the_oracle():
       if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
         text = open(os.path.join(dirpath, f)).read()
         assert "oracle" not in text.lower(), f"{f} mentions the oracle"
+  # the measurement / profiling helpers under tools/ do not use it either (the parity campaigns
+  # that do live under tests/campaigns/)
+  tools = os.path.join(ROOT, "tools")
+  for f in sorted(os.listdir(tools)):
+    if f.endswith((".py", ".sh", ".hip", ".c")):
+      text = open(os.path.join(tools, f)).read()
+      assert "import oracle" not in text and "from oracle" not in text, f"tools/{f} uses the oracle"

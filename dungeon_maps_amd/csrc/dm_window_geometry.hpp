@@ -1,0 +1,250 @@
+// Geometry of the LDS-windowed path (host side and the small structs both sides share):
+// how a frame is split into parts, which map window a part can reach, the per-launch tables.
+// Included by dm_window.hip only.
+#pragma once
+
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "dm_kernels.hpp"
+
+namespace dm {
+namespace {
+
+constexpr int kScatterThreads = 1024;
+constexpr int kRowsInFlight = 4;
+constexpr int kFillPerHalf = 2;       // fill steps per pipeline half-iteration
+constexpr int kMaxLdsBytes = 160 * 1024;
+
+
+struct Parts {
+  int pc, pr;          // column strips x row bands
+  int wp, hp;          // part width (multiple of 4) / height in pixels
+  int pd;              // depth bands: band k keeps the pixels with depth in [lo_k, hi_k] (every
+                       // band reads the whole rectangle; its window is pd times shorter)
+};
+
+// Window of one part in map cells; w == 0: the part cannot hit the map.
+struct Window {
+  int x0, z0, w, h;
+};
+
+// Tables of the scatter kernel, one per chunk of frames (= launch), staged into the
+// workspace by ONE hipMemcpyAsync per call.  Every access is a scalar load of
+// wave-uniform data.  (Passing them as kernel arguments instead saves the copy but
+// costs as much at the head of the kernel, and the runtime's kernel-argument pool then
+// stalls the host every few dozen launches.)
+struct FrameRec {        // what the scatter kernel reads of a dm_frame
+  float p[9];            // pitch rotation (row-major)
+  float cam_h;
+  float y[9];            // yaw rotation (identity for a local map)
+  float tx, tz, wo, ho;
+  float pad;
+};
+struct alignas(8) Win16 { short x0, z0, w, h; };     // map sides <= 32767 (8-byte aligned: one scalar load)
+
+constexpr int kChunkFrames = 64;          // frames per scatter launch
+constexpr int kChunkWins = 2048;          // part windows per scatter launch
+constexpr int kMaxParts = 256;           // parts of a frame (image parts x depth bands)
+constexpr int kFewParts = 8;              // window-table row stride for frames of up to 8 parts
+
+struct ScatterTables {
+  FrameRec frames[kChunkFrames];
+  Win16 unions[kChunkFrames];             // bounding box of a frame's windows, x aligned to 4
+  // (frame, part): row stride kFewParts when a frame has at most kFewParts parts (a
+  // workgroup then finds its window without first loading the part count), else nparts.
+  // Last, so that a call of one chunk copies only the rows it uses.
+  Win16 wins[kChunkWins];
+};
+
+__device__ __host__ inline Window widen(Win16 w) { return Window{w.x0, w.z0, w.w, w.h}; }
+__device__ inline Win16 narrow16(Window w) {
+  return Win16{(short)w.x0, (short)w.z0, (short)w.w, (short)w.h};
+}
+__host__ inline Win16 narrow(Window w) {
+  return Win16{(short)w.x0, (short)w.z0, (short)w.w, (short)w.h};
+}
+
+// Depth band k of pd over [dmin, dmax]: the same float expressions on the host (window
+// bounds) and in the kernel (depth test); neighbouring bands share their boundary value,
+// which is harmless for max / min.
+__host__ __device__ inline void band_bounds(float dmin, float dmax, int pd, int k, float& lo,
+                                            float& hi) {
+  const float step = (dmax - dmin) / (float)pd;
+  lo = k == 0 ? dmin : __builtin_fmaf((float)k, step, dmin);
+  hi = k == pd - 1 ? dmax : __builtin_fmaf((float)(k + 1), step, dmin);
+}
+
+__host__ Parts choose_parts(const dm_params& p, int min_parts = 1, int pd = 1) {
+  // enough workgroups to fill 256 CUs (and at least min_parts, so that windows fit
+  // in LDS), parts not smaller than 32 columns, strip boundaries on 128-byte lines
+  // (32 floats) when W allows it
+  // ... but not more than pays: the scatter kernel of a small batch is latency bound
+  // (~6 us + 0.3 us per pixel and thread), the merge kernel visits every part per cell
+  // (~0.37 us per part), so the sum is smallest near sqrt(0.8 * pixels / 1024) parts
+  // (measured at B = 1, 320x240: 80 parts 43 us, 10 parts 15 us)
+  const long frames = (long)p.B * (p.vc ? p.vc : p.dc);
+  int want = (int)((256 + frames - 1) / frames);
+  const int pays = (int)lround(sqrt(0.8 * (double)p.H * p.W / 1024.0));
+  if (want > pays) want = pays;
+  want = (want + pd - 1) / pd;                 // image parts: the depth bands multiply them
+  if (want < min_parts) want = min_parts;
+  if (want < 1) want = 1;
+  Parts s;
+  s.pc = 1; s.pr = 1; s.pd = pd;
+  const int unit = (p.W % 32 == 0) ? 32 : 4;
+  const int units = (p.W + unit - 1) / unit;
+  int pc = want < units ? want : units;
+  if (pc > 16) pc = 16;
+  // prefer a divisor of the unit count (equal strips)
+  while (pc > 1 && units % pc != 0) --pc;
+  s.pc = pc;
+  s.wp = ((units + pc - 1) / pc) * unit;
+  int pr = (want + pc - 1) / pc;
+  if (pr > 8) pr = 8;
+  if (pr > p.H / 16) pr = p.H / 16 > 0 ? p.H / 16 : 1;
+  s.pr = pr;
+  s.hp = (p.H + pr - 1) / pr;
+  return s;
+}
+
+// y = RN(1/b) in float32, exactly: pick the neighbour minimising |b*y - 1|
+// (b*y is exact in double).
+__host__ bool exact_reciprocal(float b, float* y_out) {
+  if (!(b > 0.0f) || !isfinite(b)) return false;
+  float y = (float)(1.0 / (double)b);
+  if (!isfinite(y) || y < 1e-30f || y > 1e30f) return false;
+  // the Markstein step needs b's reciprocal rounded to nearest
+  float best = y;
+  double err = fabs(fma((double)b, (double)y, -1.0));
+  const float cand[2] = {nextafterf(y, 0.0f), nextafterf(y, INFINITY)};
+  for (float c : cand) {
+    const double e = fabs(fma((double)b, (double)c, -1.0));
+    if (e < err) { err = e; best = c; }
+  }
+  *y_out = best;
+  return true;
+}
+
+__host__ bool axis_aligned(const FrameRec* f, int B) {
+  for (int b = 0; b < B; ++b) {
+    const float* p = f[b].p; const float* y = f[b].y;
+    if (!(p[0] == 1.0f && p[1] == 0.0f && p[2] == 0.0f && p[3] == 0.0f && p[6] == 0.0f))
+      return false;
+    if (!(y[1] == 0.0f && y[3] == 0.0f && y[4] == 1.0f && y[5] == 0.0f && y[7] == 0.0f))
+      return false;
+  }
+  return true;
+}
+
+// Cell coordinates are affine in (ax*z, ay*z, z) for a given frame:
+//   xf = z * (xa*ax + xb*ay + xc) + xd,   zf = z * (za*ax + zb*ay + zc) + zd
+// (ax, ay = ray slopes of the pixel).  One coefficient set per frame, in double.
+struct FrameAffine {
+  double xa, xb, xc, xd, za, zb, zc, zd;
+  bool finite;
+};
+
+__host__ FrameAffine frame_affine(const dm_params& p, const dm_frame& f) {
+  // local = Rp^T-chain(X, Y, Z) + (0, h, 0);  global = Ry-chain(local) + (tx, 0, tz)
+  double L[3][3], t1[3] = {0.0, f.cam_height, 0.0};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) L[i][j] = f.Rp[3 * j + i];           // out_i = sum_j R[j][i] p_j
+  double G[3][3], t2[3];
+  if (p.to_global) {
+    double Y[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Y[i][j] = f.Ry[3 * j + i];
+    const double tr[3] = {f.tx, 0.0, f.tz};
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) G[i][j] = Y[i][0] * L[0][j] + Y[i][1] * L[1][j] + Y[i][2] * L[2][j];
+      t2[i] = Y[i][0] * t1[0] + Y[i][1] * t1[1] + Y[i][2] * t1[2] + tr[i];
+    }
+  } else {
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) G[i][j] = L[i][j]; t2[i] = t1[i]; }
+  }
+  FrameAffine a;
+  const double inv = 1.0 / p.res;
+  a.xa = G[0][0] * inv; a.xb = G[0][1] * inv; a.xc = G[0][2] * inv;
+  a.xd = t2[0] * inv + f.width_offset;
+  double za = G[2][0] * inv, zb = G[2][1] * inv, zc = G[2][2] * inv;
+  double zd = t2[2] * inv + f.height_offset;
+  if (p.flip_h) { za = -za; zb = -zb; zc = -zc; zd = (double)(p.mh - 1) - zd; }
+  a.za = za; a.zb = zb; a.zc = zc; a.zd = zd;
+  a.finite = isfinite(a.xa) && isfinite(a.xb) && isfinite(a.xc) && isfinite(a.xd) &&
+             isfinite(a.za) && isfinite(a.zb) && isfinite(a.zc) && isfinite(a.zd);
+  return a;
+}
+
+// Footprint of the pixel rectangle [q0,q1) x [r0,r1) of a frame in map cells,
+// padded by 2 cells and aligned to 4 columns, clipped to the map.  The ray slopes of the
+// rectangle's border pixels do not depend on the frame: PartSlopes holds them per part.
+struct PartSlopes {
+  double ax[2], ay[2];        // (q - cx) / fx at q0, q1 - 1;  (y - cy) / fy at r0, r1 - 1
+  bool empty;                 // nothing left of the part after clip_border
+};
+
+__host__ PartSlopes part_slopes(const dm_params& p, int q0, int q1, int r0, int r1) {
+  PartSlopes s;
+  if (p.clip_border > 0) {
+    const int c = p.clip_border;
+    if (q0 < c) q0 = c;
+    if (r0 < c) r0 = c;
+    if (q1 > p.W - c) q1 = p.W - c;
+    if (r1 > p.H - c) r1 = p.H - c;
+  }
+  s.empty = q0 >= q1 || r0 >= r1;
+  const int qs[2] = {q0, q1 - 1}, rs[2] = {r0, r1 - 1};
+  for (int i = 0; i < 2; ++i) {
+    s.ax[i] = ((double)qs[i] - p.cx) / p.fx;
+    double yr = rs[i];
+    if (p.flip_h) yr = (double)(p.H - 1) - yr;
+    s.ay[i] = (yr - p.cy) / p.fy;
+  }
+  return s;
+}
+
+__host__ bool frustum_bounded(const dm_params& p) {
+  return p.has_dmin && p.has_dmax && p.dmin >= 0.0f && p.dmax >= p.dmin && isfinite(p.dmax);
+}
+
+__host__ Window part_window(const dm_params& p, const FrameAffine& fa, const PartSlopes& ps,
+                            bool bounded, float dlo, float dhi) {
+  if (ps.empty) return Window{0, 0, 0, 0};
+  if (!bounded || !fa.finite) return Window{0, 0, p.mw, p.mh};
+  double lo_x = INFINITY, hi_x = -INFINITY, lo_z = INFINITY, hi_z = -INFINITY;
+  double poison = 0.0;                         // NaN as soon as one corner is not finite
+  const double zs[2] = {dlo, dhi};
+  for (int qi = 0; qi < 2; ++qi)
+    for (int ri = 0; ri < 2; ++ri) {
+      const double sx = fa.xa * ps.ax[qi] + fa.xb * ps.ay[ri] + fa.xc;
+      const double sz = fa.za * ps.ax[qi] + fa.zb * ps.ay[ri] + fa.zc;
+      for (int zi = 0; zi < 2; ++zi) {
+        const double xf = zs[zi] * sx + fa.xd, zf = zs[zi] * sz + fa.zd;
+        lo_x = xf < lo_x ? xf : lo_x; hi_x = xf > hi_x ? xf : hi_x;
+        lo_z = zf < lo_z ? zf : lo_z; hi_z = zf > hi_z ? zf : hi_z;
+        poison += xf * 0.0 + zf * 0.0;
+      }
+    }
+  if (!(poison == 0.0)) return Window{0, 0, p.mw, p.mh};
+  // cells are floor(v + 0.5); 2 cells of slack cover the float32 rounding of
+  // the device arithmetic (observed error < 1e-3 cell)
+  double x0 = floor(lo_x + 0.5) - 2, x1 = floor(hi_x + 0.5) + 3;
+  double z0 = floor(lo_z + 0.5) - 2, z1 = floor(hi_z + 0.5) + 3;
+  if (x0 < 0) x0 = 0;
+  if (z0 < 0) z0 = 0;
+  if (x1 > p.mw) x1 = p.mw;
+  if (z1 > p.mh) z1 = p.mh;
+  if (x0 >= x1 || z0 >= z1) return Window{0, 0, 0, 0};
+  Window w;
+  w.x0 = ((int)x0) & ~3;
+  const int xe = ((int)x1 + 3) & ~3;           // mw % 4 == 0 is a precondition
+  w.w = (xe > p.mw ? p.mw : xe) - w.x0;
+  w.z0 = (int)z0;
+  w.h = (int)z1 - w.z0;
+  return w;
+}
+
+}  // namespace
+}  // namespace dm

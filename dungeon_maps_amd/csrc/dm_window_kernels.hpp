@@ -1,0 +1,829 @@
+// Device side of the LDS-windowed path: k_window_scatter, k_window_merge(_tiled),
+// k_fuse_unions, k_fuse_windows and their argument structs.  Included by dm_window.hip only
+// (the kernels are templates launched from that translation unit).
+#pragma once
+
+#include "dm_window_geometry.hpp"
+
+namespace dm {
+namespace {
+
+// ---------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------
+// Scalars of the scatter kernel, slimmed down to what it reads (SGPR budget).
+// Disabled tests are encoded as always-true bounds (dmin = -inf, dmax = hmax =
+// +inf: they then only reject NaN, which never reaches the map anyway) and a
+// local-space projection as an identity yaw with zero translation, so the
+// pixel loop has no flag to branch on.
+// -DDM_STAMPS: instrumented build for tools/phase_stamps.py -- thread 0 of every
+// workgroup of k_window_scatter records the 100 MHz real-time counter at phase boundaries.
+#ifdef DM_STAMPS
+#define DM_STAMP(k) do { long long t_; \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    stamp[k] = t_; } while (0)
+#define DM_STAMPS_OUT() do { if (threadIdx.x == 0 && a.stamps) \
+    for (int k_ = 0; k_ < 12; ++k_) \
+      a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 12 + k_] = stamp[k_]; \
+  } while (0)
+static long long* g_stamp_buffer = nullptr;
+#else
+#define DM_STAMP(k) do { } while (0)
+#define DM_STAMPS_OUT() do { } while (0)
+#endif
+
+struct ScatterArgs {
+  int W, H;
+  int clip;                   // border pixels to drop (0 = none)
+  int flip_h;
+  float cx, cy, fx, fy, res;
+  float fx_inv, fy_inv, res_inv;
+  float dmin, dmax, hmax;
+  float Hm1, mhm1;
+  Parts parts;
+  int dc, valid_c;
+  int oc;                     // output channels per frame handled by this pass
+  int ch0;                    // first output channel of this launch (channel groups)
+  int oc_total;               // channels of `out` / `value`
+  int slab_stride;            // cells per slab
+  float fill;
+#ifdef DM_STAMPS
+  long long* stamps;
+#endif
+  int b0;                     // first frame of this launch's chunk
+  Win16* g_wins;              // (B, nparts)  device copies for the kernels that follow
+  Win16* g_unions;            // (B)
+  const float* depth;
+  const float* value;         // (B, oc_total, H, W) or NULL: project the heights
+  const uint8_t* valid;
+  float* slabs;
+  // fill duty: the part of every output map outside its frame's union window
+  float* out;
+  uint8_t* mask;
+  int mh, mw;
+};
+
+// (int)floorf(x) in one instruction; NaN -> 0, saturating (like v_cvt_i32_f32)
+__device__ inline int floor_to_int(float x) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// global load and store of the wave (s_waitcnt vmcnt(0)), which would expose the latency
+// of the depth rows and fill stores deliberately left in flight across it.
+__device__ inline void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ds_max_f32 / ds_min_f32: "store if new > old" -- torch_scatter's rule; a NaN
+// operand never replaces a number.
+template <bool IS_MAX>
+__device__ inline void lds_reduce(float* cell, float v) {
+  if (IS_MAX) __hip_atomic_fetch_max(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_fetch_min(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// FAST: every frame's rotations have the exact 0/1 pattern of rotate([1,0,0],.)
+//       and rotate([0,1,0],.) AND the Markstein reciprocals are usable
+//       (dm_pixel.hpp).  !FAST: full FMA chains and IEEE division.
+// VEC = 4: 16-byte depth loads (W % 4 == 0, 16-byte aligned base); VEC = 1: any shape.
+// HAS_VALUE: scatter value[b, ch] (maps.py:314-316) instead of the height.
+// LEAN: finite depth bounds on both sides, no height truncation, no poisoned rays
+//       (no border clip, no valid map): a non-finite or out-of-range pixel is then
+//       already rejected by the two depth compares, so the ordered-compare and the
+//       height compare are dropped.  (Pipeline-tail rows are poisoned through z.)
+template <bool IS_MAX, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC, bool LEAN>
+__global__ void __launch_bounds__(kScatterThreads)
+k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
+  const ScatterTables& t = *tables;            // this launch's chunk of frames
+  extern __shared__ float lds[];
+  const int part = blockIdx.x;                 // pr-major, pc-minor
+  const int chl = blockIdx.y;                  // channel within this launch's group
+  const int bl = blockIdx.z, b = a.b0 + bl;    // frame within the chunk / in the batch
+  const int ch = a.ch0 + chl;                  // output channel
+  const int dch = a.dc == 1 ? 0 : ch;          // depth / cell-index channel (utils.py:475-477)
+  const int nparts = a.parts.pc * a.parts.pr * a.parts.pd;
+  const int pcx = part % a.parts.pc, pry = (part / a.parts.pc) % a.parts.pr;
+  const int pdk = part / (a.parts.pc * a.parts.pr);          // depth band
+  // The part's pixel rectangle and this thread's place in it need nothing but kernel
+  // arguments, so the first depth rows are requested before anything of the staged
+  // table has arrived (window, union window, frame record: all of the head of the kernel
+  // runs under these loads).
+  const int q0 = pcx * a.parts.wp;
+  int q1 = q0 + a.parts.wp; if (q1 > a.W) q1 = a.W;
+  const int r0 = pry * a.parts.hp;
+  int r1 = r0 + a.parts.hp; if (r1 > a.H) r1 = a.H;
+  const int nx = (q1 - q0 + VEC - 1) / VEC;    // lane groups per row
+  const int ntx = nx < kScatterThreads ? nx : kScatterThreads;
+  const int rows_per_iter = kScatterThreads / ntx;
+  const int gx = threadIdx.x % ntx, gy = threadIdx.x / ntx;
+  const size_t N = (size_t)a.H * a.W;
+  const float* dimg = a.depth + ((size_t)b * a.dc + dch) * N;
+  const uint8_t* vimg = HAS_VALID
+      ? a.valid + ((size_t)b * a.valid_c + (a.valid_c == 1 ? 0 : dch)) * N : nullptr;
+  const float* simg = HAS_VALUE ? a.value + ((size_t)b * a.oc_total + ch) * N : nullptr;
+  const float qnan = __builtin_nanf("");
+  float za[kRowsInFlight][VEC], zb_[kRowsInFlight][VEC];
+  float va[HAS_VALUE ? kRowsInFlight : 1][VEC], vb_[HAS_VALUE ? kRowsInFlight : 1][VEC];
+  auto load_rows_at = [&](float (&z)[kRowsInFlight][VEC],
+                          float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int q, int r) {
+#pragma unroll
+    for (int u = 0; u < kRowsInFlight; ++u) {
+      // rows past the part are clamped to its last row (a legal address);
+      // project_rows() ignores them.  No per-lane branch: the loads stay in
+      // one basic block and the compiler can wait on them individually.
+      int rr = r + u * rows_per_iter;
+      rr = rr < r1 ? rr : r1 - 1;
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(dimg + (size_t)rr * a.W + q);
+        z[u][0] = t.x; z[u][1 % VEC] = t.y; z[u][2 % VEC] = t.z; z[u][3 % VEC] = t.w;
+      } else {
+        z[u][0] = dimg[(size_t)rr * a.W + q];
+      }
+      if (HAS_VALID) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+          z[u][k] = vimg[(size_t)rr * a.W + q + k] ? z[u][k] : qnan;
+      }
+      if (HAS_VALUE) {
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(simg + (size_t)rr * a.W + q);
+          sv[u][0] = t.x; sv[u][1 % VEC] = t.y; sv[u][2 % VEC] = t.z; sv[u][3 % VEC] = t.w;
+        } else {
+          sv[u][0] = simg[(size_t)rr * a.W + q];
+        }
+      }
+    }
+  };
+  bool first_rows_loaded = false;
+  if (gx < nx && q1 > q0 && r1 > r0) {         // (always, for a non-empty part)
+    load_rows_at(za, va, q0 + gx * VEC, r0 + gy);
+    first_rows_loaded = true;
+  }
+
+  // Everything this workgroup reads from the staged table -- its window, the frame's union
+  // window and the frame record -- is requested in ONE batch of scalar loads and pinned
+  // (the asm makes the values opaque): left to the compiler these loads trickle in close
+  // to their first use, one dependent ~0.7-us round trip after the other.
+  int w_raw[2], u_raw[2];
+  float fr[23];
+  {
+    const int* tw = reinterpret_cast<const int*>(&t.wins[bl * kFewParts + (part & (kFewParts - 1))]);
+    const int* tu = reinterpret_cast<const int*>(&t.unions[bl]);
+    const float* tf = reinterpret_cast<const float*>(&t.frames[bl]);
+    w_raw[0] = tw[0]; w_raw[1] = tw[1]; u_raw[0] = tu[0]; u_raw[1] = tu[1];
+#pragma unroll
+    for (int i = 0; i < 23; ++i) fr[i] = tf[i];
+    asm volatile("" : "+s"(w_raw[0]), "+s"(w_raw[1]), "+s"(u_raw[0]), "+s"(u_raw[1]),
+                      "+s"(fr[0]), "+s"(fr[1]), "+s"(fr[2]), "+s"(fr[3]), "+s"(fr[4]), "+s"(fr[5]),
+                      "+s"(fr[6]), "+s"(fr[7]), "+s"(fr[8]), "+s"(fr[9]), "+s"(fr[10]), "+s"(fr[11]),
+                      "+s"(fr[12]), "+s"(fr[13]), "+s"(fr[14]), "+s"(fr[15]), "+s"(fr[16]),
+                      "+s"(fr[17]), "+s"(fr[18]), "+s"(fr[19]), "+s"(fr[20]), "+s"(fr[21]),
+                      "+s"(fr[22]));
+  }
+  const Win16 w_few = {(short)(w_raw[0] & 0xffff), (short)(w_raw[0] >> 16),
+                       (short)(w_raw[1] & 0xffff), (short)(w_raw[1] >> 16)};
+  const Window w = nparts <= kFewParts ? widen(w_few) : widen(t.wins[bl * nparts + part]);
+  const int area = w.w * w.h;                  // 0: nothing of this part can land
+#ifdef DM_STAMPS
+  long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  DM_STAMP(0);
+  // younger waves of a SIMD get the higher issue priority (age arbitration favours the
+  // oldest wave otherwise, and the last wave left on a SIMD runs latency bound)
+  {
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (wave >= 12) __builtin_amdgcn_s_setprio(3);
+    else if (wave >= 8) __builtin_amdgcn_s_setprio(2);
+    else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  }
+
+  // Fill duty, interleaved with the scatter so that these stores ride under the
+  // projection: map rows part, part + nparts, ... of (b, ch), minus the frame's union
+  // window U (k_window_merge writes U).  One float4 (+ 4 mask bytes) per thread and step,
+  // ALWAYS executed: an element that needs no store (inside U, or past the end) is
+  // redirected to `alt`, a cell of this workgroup's share that does get the fill value,
+  // so the stores are unconditional straight-line code and the compiler can count the
+  // pipelined loop's waits exactly.
+  const Window U = {(short)(u_raw[0] & 0xffff), (short)(u_raw[0] >> 16),
+                    (short)(u_raw[1] & 0xffff), (short)(u_raw[1] >> 16)};
+  const int g4 = a.mw >> 2;
+  const int fill_rows = (a.mh - part + nparts - 1) / nparts;
+  const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
+  // where redirected stores go: a cell of this share outside U if there is one (it gets
+  // the fill value anyway), else the share's first cell (inside U: k_window_merge,
+  // which runs after this kernel, overwrites it)
+  int alt_cell = part * a.mw;
+  if (fill_rows > 0 && U.w > 0 && U.h > 0 && U.x0 == 0) {
+    const int last_row = part + (fill_rows - 1) * nparts;
+    if (U.x0 + U.w < a.mw) alt_cell = part * a.mw + U.x0 + U.w;                  // right of U
+    else if (part >= U.z0 && last_row >= U.z0 + U.h) alt_cell = last_row * a.mw; // below U
+  }
+  const bool do_fill = a.out != nullptr && fill_rows > 0;                       // wave-uniform
+  const int fill_total = do_fill ? fill_rows * g4 : 0;
+  const int fill_steps = (fill_total + kScatterThreads - 1) / kScatterThreads;
+  const float g4_inv = 1.0f / (float)g4;
+  int fs = 0;
+  auto fill_step = [&]() {
+    const int i = fs * kScatterThreads + (int)threadIdx.x;     // < 2^24
+    ++fs;
+    int k = (int)((float)i * g4_inv);          // i / g4 without a division routine or a branch
+    k -= (k * g4 > i);
+    k += ((k + 1) * g4 <= i);
+    const int g = i - k * g4;
+    const int r = part + k * nparts, x = g << 2;
+    const bool skip = i >= fill_total || ((unsigned)(r - U.z0) < (unsigned)U.h &&
+                                          (unsigned)(x - U.x0) < (unsigned)U.w);
+    int cell = r * a.mw + x;
+    asm("" : "+v"(cell));                      // keep the select a v_cndmask
+    cell = skip ? alt_cell : cell;
+    *reinterpret_cast<float4*>(a.out + map_base + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
+    *reinterpret_cast<uint32_t*>(a.mask + map_base + cell) = 0u;
+  };
+  // device copies of the geometry for the kernels that follow (stored at the very end: a
+  // store in flight makes its wave wait before the first depth loads)
+  auto publish_geometry = [&]() {
+    if (chl == 0 && threadIdx.x == 0) {
+      a.g_wins[(size_t)b * nparts + part] = narrow16(w);
+      if (part == 0) a.g_unions[b] = narrow16(U);
+    }
+  };
+  if (area == 0) {                             // wave-uniform
+    while (fs < fill_steps) fill_step();
+    publish_geometry();
+    return;
+  }
+  // FrameRec: p[9], cam_h, y[9], tx, tz, wo, ho
+  // pitch: rows 1,2 of R; yaw: rows 0,2 (the rest is 0/1 when FAST)
+  const float p0 = fr[0], p1 = fr[1], p2 = fr[2], p3 = fr[3], p4 = fr[4],
+              p5 = fr[5], p6 = fr[6], p7 = fr[7], p8 = fr[8];
+  const float y0 = fr[10], y1r = fr[11], y2r = fr[12], y3 = fr[13], y4 = fr[14],
+              y5 = fr[15], y6 = fr[16], y7 = fr[17], y8 = fr[18];
+  const float cam_h = fr[9], tx = fr[19], tz = fr[20];
+  const float wo = fr[21], ho = fr[22];
+  const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
+  DM_STAMP(1);
+  bool lds_ready = false;
+  const unsigned dummy = (unsigned)area + (threadIdx.x & 63u);   // 64 scratch cells after the window
+  float band_lo = a.dmin, band_hi = a.dmax;    // this part's depth band (wave-uniform)
+  if (a.parts.pd > 1) band_bounds(a.dmin, a.dmax, a.parts.pd, pdk, band_lo, band_hi);
+
+  {
+    for (int g = gx; g < nx; g += ntx) {       // one trip unless the strip is wider than the block
+      const int q = q0 + g * VEC;
+      // ray slope of each column (maps.py:677); border columns are poisoned with
+      // NaN, which flows through X to the cell coordinates (maps.py:48-70)
+      float ax[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float d = (float)(q + k) - a.cx;
+        ax[k] = FAST ? div_markstein(d, a.fx, a.fx_inv) : d / a.fx;
+        // (idle threads and pipeline-tail rows simply repeat the part's last row: a max /
+        // min reduction is idempotent, so they need no poison)
+        if (!LEAN) ax[k] = (q + k < a.clip || q + k >= a.W - a.clip) ? qnan : ax[k];
+      }
+      // Software pipeline over groups of kRowsInFlight rows: the loads of group
+      // i+1 are in flight while group i is projected (all waves of a workgroup
+      // run in phase, so latency has to be hidden inside each wave).
+      const int step = rows_per_iter * kRowsInFlight;
+      auto load_rows = [&](float (&z)[kRowsInFlight][VEC],
+                           float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
+        load_rows_at(z, sv, q, r);
+      };
+      auto project_rows = [&](const float (&z)[kRowsInFlight][VEC],
+                              const float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u) {
+          int rr = r + u * rows_per_iter;
+          rr = rr < r1 ? rr : r1 - 1;                            // tail: repeat the last row
+          float yr = (float)rr;
+          yr = a.flip_h ? a.Hm1 - yr : yr;                       // maps.py:670-671
+          const float dy = yr - a.cy;
+          float ay = FAST ? div_markstein(dy, a.fy, a.fy_inv) : dy / a.fy;
+          // rows in the clipped border: poison
+          if (!LEAN) ay = (rr < a.clip || rr >= a.H - a.clip) ? qnan : ay;
+          // the VEC pixels of a row are projected side by side (independent
+          // chains for the scheduler); their LDS atomics come last so that no
+          // branch separates the arithmetic of neighbouring pixels
+          unsigned li[VEC];
+          float hv[VEC];
+          bool ok[VEC];
+          float xfv[VEC], zfv[VEC], h1v[VEC], h2v[VEC];
+          if (FAST && VEC == 4) {
+            // two pixels per instruction (v_pk_mul/fma/add_f32): the kernel is bound by
+            // dependent-instruction issue, and the packed forms have the same rounding
+            // per element as the scalar ones
+            typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int k = 0; k < VEC; k += 2) {
+              const f2 zz = {z[u][k], z[u][(k + 1) % VEC]};
+              const f2 axp = {ax[k], ax[(k + 1) % VEC]};
+              const f2 X = axp * zz;
+              const f2 Y = zz * ay;                                            // maps.py:677-678
+              f2 h1 = __builtin_elementwise_fma(zz, (f2){p7, p7}, Y * p4) + cam_h;   // maps.py:790-797
+              const f2 z1 = __builtin_elementwise_fma(zz, (f2){p8, p8}, Y * p5);
+              const f2 x2 = __builtin_elementwise_fma(z1, (f2){y6, y6}, X * y0) + tx;   // maps.py:884-892
+              const f2 z2 = __builtin_elementwise_fma(z1, (f2){y8, y8}, X * y2r) + tz;
+              const f2 ri = {a.res_inv, a.res_inv}, nres = {-a.res, -a.res};
+              const f2 qx = x2 * ri, qz = z2 * ri;                             // exact division
+              f2 xf2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nres, qx, x2), ri, qx) + wo;
+              f2 zf2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nres, qz, z2), ri, qz) + ho;
+              zf2 = __builtin_elementwise_fma(zf2, (f2){flip_s, flip_s}, (f2){flip_c, flip_c});
+              xf2 = xf2 + 0.5f;
+              zf2 = zf2 + 0.5f;
+              xfv[k] = xf2.x; xfv[(k + 1) % VEC] = xf2.y;
+              zfv[k] = zf2.x; zfv[(k + 1) % VEC] = zf2.y;
+              h1v[k] = h1.x; h1v[(k + 1) % VEC] = h1.y;
+              h2v[k] = h1.x; h2v[(k + 1) % VEC] = h1.y;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+              const float zz = z[u][k];
+              const float X = ax[k] * zz, Y = ay * zz;             // maps.py:677-678
+              float x1, h1, z1, x2, h2, z2;
+              if (FAST) {
+                x1 = X;
+                h1 = __builtin_fmaf(zz, p7, Y * p4) + cam_h;       // maps.py:790-797
+                z1 = __builtin_fmaf(zz, p8, Y * p5);
+                x2 = __builtin_fmaf(z1, y6, x1 * y0) + tx;         // maps.py:884-892
+                z2 = __builtin_fmaf(z1, y8, x1 * y2r) + tz;
+                h2 = h1;
+              } else {
+                x1 = __builtin_fmaf(zz, p6, __builtin_fmaf(Y, p3, X * p0)) + 0.0f;
+                h1 = __builtin_fmaf(zz, p7, __builtin_fmaf(Y, p4, X * p1)) + cam_h;
+                z1 = __builtin_fmaf(zz, p8, __builtin_fmaf(Y, p5, X * p2)) + 0.0f;
+                x2 = __builtin_fmaf(z1, y6, __builtin_fmaf(h1, y3, x1 * y0)) + tx;
+                h2 = __builtin_fmaf(z1, y7, __builtin_fmaf(h1, y4, x1 * y1r)) + 0.0f;
+                z2 = __builtin_fmaf(z1, y8, __builtin_fmaf(h1, y5, x1 * y2r)) + tz;
+              }
+              float xf = (FAST ? div_markstein(x2, a.res, a.res_inv) : x2 / a.res) + wo;
+              float zf = (FAST ? div_markstein(z2, a.res, a.res_inv) : z2 / a.res) + ho;
+              // flip: (mh-1) - zf as fma(zf, -1, mh-1); no flip: fma(zf, 1, 0) -- both exact
+              zf = __builtin_fmaf(zf, flip_s, flip_c);             // maps.py:1006-1009
+              xfv[k] = xf + 0.5f;                                  // maps.py:1012-1013
+              zfv[k] = zf + 0.5f;
+              h1v[k] = h1; h2v[k] = h2;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const float zz = z[u][k], xf = xfv[k], zf = zfv[k], h1 = h1v[k], h2 = h2v[k];
+            // floor + convert in one instruction; window test in integers (the
+            // window lies inside the map).  The conversion saturates and maps
+            // NaN to 0, so NaN is excluded by the ordered compare.
+            // maps.py:537-544, 286-288, 1150-1158
+            const unsigned ux = (unsigned)(floor_to_int(xf) - w.x0);
+            const unsigned uz = (unsigned)(floor_to_int(zf) - w.z0);
+            ok[k] = ux < (unsigned)w.w && uz < (unsigned)w.h && zz <= band_hi && zz >= band_lo;
+            if (!LEAN) ok[k] = ok[k] && !__builtin_isunordered(xf, zf) && h1 <= a.hmax;
+            if (!FAST && !HAS_VALUE) ok[k] = ok[k] && (h2 == h2);
+            const float sval = HAS_VALUE ? sv[u][k] : h2;
+            if (HAS_VALUE) ok[k] = ok[k] && (sval == sval);      // NaN never replaces a number
+            // rejected pixels are redirected to a per-lane dummy cell behind the
+            // window instead of being branched around: the whole row group stays
+            // one basic block the scheduler can interleave
+            unsigned cell = __umul24(uz, (unsigned)w.w) + ux;
+            asm("" : "+v"(cell));   // keep the select below a v_cndmask, not a branch
+            li[k] = ok[k] ? cell : dummy;
+            hv[k] = sval;
+          }
+          // Neighbouring pixels of a row often share a cell (walls, near floor), and lanes
+          // that hit one LDS address serialise: +30 % kernel time on scene-like depth.  If
+          // any thread of the wave has its four pixels in ONE cell (wave-uniform test), every
+          // run of equal cells inside a thread is reduced in registers and only its last
+          // pixel issues the atomic.  (Unconditionally the extra selects cost 2.6 us on
+          // incoherent depth; behind the test 1 us.)
+          if (VEC == 4 && __builtin_amdgcn_ballot_w64(li[0] == li[VEC - 1] && li[0] != dummy) != 0) {
+#pragma unroll
+            for (int k = 0; k + 1 < VEC; ++k) {
+              const bool same = li[k] == li[k + 1];
+              const float m = IS_MAX ? fmaxf(hv[k], hv[k + 1]) : fminf(hv[k], hv[k + 1]);
+              hv[k + 1] = same ? m : hv[k + 1];
+              li[k] = same ? dummy : li[k];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) lds_reduce<IS_MAX>(lds + li[k], hv[k]);
+        }
+      };
+      const int niter = (r1 - r0 + step - 1) / step;             // wave-uniform
+      // Two copies of the pipelined loop, with and without fill duty, chosen by ONE
+      // wave-uniform branch: inside, exactly kFillPerHalf unconditional fill stores
+      // follow each group of loads, so the waits count them and never wait on a store
+      // or on the prefetch.
+      auto pipeline = [&](auto with_fill) {
+        constexpr bool kFill = decltype(with_fill)::value;
+        int r = r0 + gy;
+        if (!first_rows_loaded) load_rows(za, va, r);      // (later trips of the column loop)
+        first_rows_loaded = false;
+        DM_STAMP(2);
+        // the LDS window is initialised while the first depth rows are in flight
+        if (!lds_ready) {                      // wave-uniform, first trip only
+          for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
+            *reinterpret_cast<float4*>(lds + i) = make_float4(a.fill, a.fill, a.fill, a.fill);
+          lds_barrier();
+          lds_ready = true;
+        }
+        DM_STAMP(3);
+        for (int it = 0; it < niter; it += 2) {
+          load_rows(zb_, vb_, r + step);
+          if (kFill) {
+#pragma unroll
+            for (int t = 0; t < kFillPerHalf; ++t) fill_step();
+          }
+          project_rows(za, va, r);
+          if (it + 1 < niter) {
+            load_rows(za, va, r + 2 * step);
+            if (kFill) {
+#pragma unroll
+              for (int t = 0; t < kFillPerHalf; ++t) fill_step();
+            }
+            project_rows(zb_, vb_, r + step);
+          }
+          r += 2 * step;
+        }
+      };
+      if (do_fill) pipeline(std::true_type{}); else pipeline(std::false_type{});
+    }
+  }
+  DM_STAMP(4);
+  while (fs < fill_steps) fill_step();
+  lds_barrier();
+  DM_STAMP(5);
+  const int pid = (b * a.oc + chl) * nparts + part;      // slabs are per channel group
+  float* slab = a.slabs + (size_t)pid * a.slab_stride;
+  for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
+    *reinterpret_cast<float4*>(slab + i) = *reinterpret_cast<const float4*>(lds + i);
+  publish_geometry();
+  DM_STAMP(6);
+  DM_STAMPS_OUT();
+}
+
+// Table ring: the first thread of a kernel that follows k_window_scatter in stream order tells
+// the host that the scatter's table slot may be rewritten (a word in pinned host memory).
+// Called on the way OUT of the kernel: a store ahead of the loads of the read-only window
+// tables (even an opaque one) turns them from scalar into vector loads, each waited for in
+// turn (k_window_merge: 12.2 instead of 9.4 us).
+__device__ inline void signal_slot_free(uint32_t* signal, uint32_t ticket) {
+  if (signal && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(signal), "v"(ticket));
+}
+
+struct MergeArgs {
+  int b0, oc, ch0, oc_total, mh, mw;  // oc channels per frame in this launch, starting at ch0
+  int nparts;                 // pc * pr
+  int slab_stride;
+  float fill;
+  // this chunk's part windows (row stride win_stride) and union windows: in the staged
+  // table (already in every XCD's L2) or, when that is a slot of the table ring, the device
+  // copies k_window_scatter leaves behind
+  const Win16* wins;
+  const Win16* unions;
+  int win_stride;
+  uint32_t* signal;           // table ring: k_window_scatter of this stream position is done
+  uint32_t ticket;
+  const float* slabs;
+  float* out;
+  uint8_t* mask;
+};
+
+constexpr int kMergeThreads = 256;
+
+// Writes the union window U of every (frame, channel): max/min over the slabs covering
+// each cell, fill where none does.  One float4 group per thread, row-major inside U, so
+// a wave's store covers up to 1 KiB (map) / 256 B (mask) contiguously.
+template <bool IS_MAX>
+__global__ void __launch_bounds__(kMergeThreads)
+k_window_merge(MergeArgs a) {
+  const int fcl = blockIdx.y;                  // (frame in chunk) * oc + channel of the group
+  const int bl = fcl / a.oc, b = a.b0 + bl;
+  const int fc = fcl + a.b0 * a.oc;            // slab index of (frame, channel)
+  const size_t fo = (size_t)b * a.oc_total + a.ch0 + (fcl - bl * a.oc);   // map index in `out`
+  const Window U = widen(a.unions[bl]);
+  const int win_stride = a.win_stride;
+  const int ug4 = U.w >> 2;                    // float4 groups per U row
+  const int total = ug4 * U.h;
+  const int i = blockIdx.x * kMergeThreads + threadIdx.x;
+  if (i >= total) {
+    signal_slot_free(a.signal, a.ticket);
+    return;
+  }
+  const int row = i / ug4;
+  const int zb = U.z0 + row, x = U.x0 + ((i - row * ug4) << 2);
+  float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+  for (int p = 0; p < a.nparts; ++p) {
+    const Window w = widen(a.wins[bl * win_stride + p]);
+    if (w.w == 0) continue;
+    const unsigned ux = (unsigned)(x - w.x0), uz = (unsigned)(zb - w.z0);
+    if (ux >= (unsigned)w.w || uz >= (unsigned)w.h) continue;
+    const float* slab = a.slabs + ((size_t)fc * a.nparts + p) * a.slab_stride;
+    const float4 s = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
+    acc.x = IS_MAX ? fmaxf(acc.x, s.x) : fminf(acc.x, s.x);
+    acc.y = IS_MAX ? fmaxf(acc.y, s.y) : fminf(acc.y, s.y);
+    acc.z = IS_MAX ? fmaxf(acc.z, s.z) : fminf(acc.z, s.z);
+    acc.w = IS_MAX ? fmaxf(acc.w, s.w) : fminf(acc.w, s.w);
+  }
+  const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw + x;
+  *reinterpret_cast<float4*>(a.out + cell) = acc;
+  const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+                      ((uint32_t)mask_of(acc.z, a.fill) << 16) |
+                      ((uint32_t)mask_of(acc.w, a.fill) << 24);
+  *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+  signal_slot_free(a.signal, a.ticket);
+}
+
+// The same for frames of many parts (image parts x depth bands): a block owns a tile of
+// kTileGroups x kTileRows float4 groups of U, first lists the parts whose windows touch the
+// tile (in part order, so that the result does not depend on the tiling), and its threads
+// then visit only those instead of all of them.
+constexpr int kTileGroups = 16, kTileRows = 16;
+constexpr int kTiledMergeParts = 16;      // frames of at least this many parts take the tiled merge
+static_assert(kTileGroups * kTileRows == kMergeThreads && kMaxParts <= kMergeThreads, "one test per thread");
+
+template <bool IS_MAX>
+__global__ void __launch_bounds__(kMergeThreads)
+k_window_merge_tiled(MergeArgs a) {
+  __shared__ Win16 lwin[kMaxParts];
+  __shared__ short lpart[kMaxParts];
+  __shared__ int wave_hits[kMergeThreads / 64];
+  const int fcl = blockIdx.y;
+  const int bl = fcl / a.oc, b = a.b0 + bl;
+  const int fc = fcl + a.b0 * a.oc;
+  const size_t fo = (size_t)b * a.oc_total + a.ch0 + (fcl - bl * a.oc);
+  const Window U = widen(a.unions[bl]);
+  const int win_stride = a.win_stride;
+  const int tiles_x = ((U.w >> 2) + kTileGroups - 1) / kTileGroups;
+  const int tiles_z = (U.h + kTileRows - 1) / kTileRows;
+  const int t = blockIdx.x;
+  if (t >= tiles_x * tiles_z) {                  // the whole block
+    signal_slot_free(a.signal, a.ticket);
+    return;
+  }
+  const int tz = t / tiles_x, tx = t - tz * tiles_x;
+  const int x0 = U.x0 + tx * (kTileGroups * 4), z0 = U.z0 + tz * kTileRows;
+  const int x1 = min(x0 + kTileGroups * 4, U.x0 + U.w), z1 = min(z0 + kTileRows, U.z0 + U.h);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  Win16 mine = Win16{0, 0, 0, 0};
+  bool hit = false;
+  if (tid < a.nparts) {
+    mine = a.wins[bl * win_stride + tid];
+    hit = mine.w > 0 && mine.x0 < x1 && mine.x0 + mine.w > x0 && mine.z0 < z1 && mine.z0 + mine.h > z0;
+  }
+  const unsigned long long votes = __builtin_amdgcn_ballot_w64(hit);
+  if (lane == 0) wave_hits[wave] = __builtin_popcountll(votes);
+  __syncthreads();
+  int before = 0, n = 0;
+#pragma unroll
+  for (int w = 0; w < kMergeThreads / 64; ++w) {
+    before += w < wave ? wave_hits[w] : 0;
+    n += wave_hits[w];
+  }
+  if (hit) {
+    const int at = before + __builtin_popcountll(votes & ((1ull << lane) - 1ull));
+    lwin[at] = mine;
+    lpart[at] = (short)tid;
+  }
+  __syncthreads();
+
+  const int x = x0 + ((tid & (kTileGroups - 1)) << 2), zb = z0 + tid / kTileGroups;
+  if (x >= x1 || zb >= z1) {
+    signal_slot_free(a.signal, a.ticket);
+    return;
+  }
+  float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+  const float* slabs = a.slabs + (size_t)fc * a.nparts * a.slab_stride;
+  for (int j = 0; j < n; ++j) {
+    const Window w = widen(lwin[j]);
+    const unsigned ux = (unsigned)(x - w.x0), uz = (unsigned)(zb - w.z0);
+    if (ux >= (unsigned)w.w || uz >= (unsigned)w.h) continue;
+    const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)lpart[j] * a.slab_stride +
+                                                     (size_t)uz * w.w + ux);
+    acc.x = IS_MAX ? fmaxf(acc.x, v.x) : fminf(acc.x, v.x);
+    acc.y = IS_MAX ? fmaxf(acc.y, v.y) : fminf(acc.y, v.y);
+    acc.z = IS_MAX ? fmaxf(acc.z, v.z) : fminf(acc.z, v.z);
+    acc.w = IS_MAX ? fmaxf(acc.w, v.w) : fminf(acc.w, v.w);
+  }
+  const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw + x;
+  *reinterpret_cast<float4*>(a.out + cell) = acc;
+  const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+                      ((uint32_t)mask_of(acc.z, a.fill) << 16) |
+                      ((uint32_t)mask_of(acc.w, a.fill) << 24);
+  *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+  signal_slot_free(a.signal, a.ticket);
+}
+
+// Batch fuse (north_star "projected+fused"): fused[c] = max/min over the frames
+// whose union window covers c of out[b][c]; frames that do not cover c hold the
+// fill value there, so they cannot change the result and are never read.
+struct FuseArgs {
+  int B, dc, mh, mw;          // B frames in this launch, starting at frame b0
+  int b0, accumulate;         // accumulate: fold into the current content of `fused`
+  float fill;
+  const Win16* unions;        // (B_total)   written by k_window_scatter
+  const float* maps;          // (B_total, dc, mh, mw)
+  float* fused;               // (dc, mh, mw)
+  uint8_t* fused_mask;
+};
+
+constexpr int kFuseGroups = 32;     // float4 groups of the fused map per block
+constexpr int kFuseLanes = 8;       // threads sharing one group, frames b = lane (mod 8)
+
+// Block = 32 groups x 8 frame lanes.  Each thread tests the unions of its frames
+// (lane, lane + 8, ...) eight at a time, loads the covered maps (independent
+// 16-byte loads), and the 8 partial results of a group are combined through LDS.
+template <bool IS_MAX>
+__global__ void __launch_bounds__(kFuseGroups * kFuseLanes)
+k_fuse_unions(FuseArgs a) {
+  __shared__ float4 part[kFuseLanes][kFuseGroups];
+  const int ch = blockIdx.y;
+  const int g4 = a.mw >> 2;
+  const int gi = threadIdx.x & (kFuseGroups - 1), lane = threadIdx.x / kFuseGroups;
+  const int g = blockIdx.x * kFuseGroups + gi;
+  const bool live = g < g4 * a.mh;
+  const int z = live ? g / g4 : 0, x = live ? (g - z * g4) << 2 : 0;
+  const size_t M = (size_t)a.mh * a.mw;
+  const size_t cell = (size_t)z * a.mw + x;
+  float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+  if (a.accumulate && lane == 0 && live)
+    acc = *reinterpret_cast<const float4*>(a.fused + (size_t)ch * M + cell);
+  for (int b0 = lane; b0 < a.B; b0 += 8 * kFuseLanes) {
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int bb = b0 + k * kFuseLanes;
+      v[k] = acc;
+      if (bb < a.B) {
+        const Window U = widen(a.unions[a.b0 + bb]);
+        if ((unsigned)(z - U.z0) < (unsigned)U.h && (unsigned)(x - U.x0) < (unsigned)U.w)
+          v[k] = *reinterpret_cast<const float4*>(
+              a.maps + ((size_t)(a.b0 + bb) * a.dc + ch) * M + cell);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc.x = IS_MAX ? fmaxf(acc.x, v[k].x) : fminf(acc.x, v[k].x);
+      acc.y = IS_MAX ? fmaxf(acc.y, v[k].y) : fminf(acc.y, v[k].y);
+      acc.z = IS_MAX ? fmaxf(acc.z, v[k].z) : fminf(acc.z, v[k].z);
+      acc.w = IS_MAX ? fmaxf(acc.w, v[k].w) : fminf(acc.w, v[k].w);
+    }
+  }
+  part[lane][gi] = acc;
+  __syncthreads();
+  if (lane == 0 && live) {
+#pragma unroll
+    for (int k = 1; k < kFuseLanes; ++k) {
+      const float4 o = part[k][gi];
+      acc.x = IS_MAX ? fmaxf(acc.x, o.x) : fminf(acc.x, o.x);
+      acc.y = IS_MAX ? fmaxf(acc.y, o.y) : fminf(acc.y, o.y);
+      acc.z = IS_MAX ? fmaxf(acc.z, o.z) : fminf(acc.z, o.z);
+      acc.w = IS_MAX ? fmaxf(acc.w, o.w) : fminf(acc.w, o.w);
+    }
+    *reinterpret_cast<float4*>(a.fused + (size_t)ch * M + cell) = acc;
+    const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+                        ((uint32_t)mask_of(acc.z, a.fill) << 16) |
+                        ((uint32_t)mask_of(acc.w, a.fill) << 24);
+    *reinterpret_cast<uint32_t*>(a.fused_mask + (size_t)ch * M + cell) = mk;
+  }
+}
+
+// Direct batch fuse from the slabs (dm_orth_project_fused_f32): fused[c] =
+// max/min over every (frame, part) window covering c of its slab value -- the
+// per-frame maps are never materialised.  Same block shape as k_fuse_unions; the
+// 8 lanes of a group split the B * nparts windows.
+struct FuseWinArgs {
+  int nwin;                   // windows of this launch: (frames of the chunk) * nparts
+  int b0;                     // first frame of the chunk
+  int nparts, oc, ch0, oc_total, mh, mw;
+  int slab_stride;
+  int accumulate;
+  int gx0, gz0, gx1, gz1;     // bounding box of every window of the call (cells, half open)
+  float fill;
+  const Win16* wins;          // (B_total, nparts)   written by k_window_scatter
+  uint32_t* signal;           // table ring (see MergeArgs)
+  uint32_t ticket;
+  const float* slabs;         // ((b * oc + chl) * nparts + p) * slab_stride
+  float* fused;               // (oc_total, mh, mw)
+  uint8_t* fused_mask;
+};
+
+constexpr int kFuseChunk = 1024;    // windows examined per candidate-list round
+
+template <bool IS_MAX>
+__global__ void __launch_bounds__(kFuseGroups * kFuseLanes)
+k_fuse_windows(FuseWinArgs a) {
+  __shared__ float4 part[kFuseLanes][kFuseGroups];
+  __shared__ int4 cwin[kFuseChunk];     // candidate windows {x0, z0, w, h} ...
+  __shared__ int cslab[kFuseChunk];     // ... and their slab index
+  __shared__ int ncand;
+  const int chl = blockIdx.y, ch = a.ch0 + chl;
+  const int g4 = a.mw >> 2;
+  const int total = g4 * a.mh;
+  const size_t M = (size_t)a.mh * a.mw;
+  // Most of a large global map is out of reach of the whole call.  The first `heavy`
+  // blocks own the 32-group tiles of the call's bounding box (one map row each); the
+  // others stream the fill value (or, accumulating, only refresh the mask) over
+  // everything outside it, 8 groups per thread: few, fat blocks instead of one tiny
+  // block per 128 cells of a mostly empty map.
+  const int bw4 = (a.gx1 - a.gx0) >> 2;                           // groups per bounding-box row
+  const int tpr = (bw4 + kFuseGroups - 1) / kFuseGroups;          // tiles per bounding-box row
+  const int heavy = a.gx1 > a.gx0 ? tpr * (a.gz1 - a.gz0) : 0;
+  if ((int)blockIdx.x >= heavy) {                                 // block-uniform
+    const int first = ((int)blockIdx.x - heavy) * (int)blockDim.x * 8 + (int)threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int g = first + k * (int)blockDim.x;
+      if (g >= total) break;
+      const int z = g / g4, x = (g - z * g4) << 2;
+      if (z >= a.gz0 && z < a.gz1 && x >= a.gx0 && x < a.gx1) continue;     // a tile's cell
+      const size_t cell = (size_t)ch * M + (size_t)z * a.mw + x;
+      uint32_t mk = 0u;
+      if (a.accumulate) {
+        const float4 v = *reinterpret_cast<const float4*>(a.fused + cell);
+        mk = (uint32_t)mask_of(v.x, a.fill) | ((uint32_t)mask_of(v.y, a.fill) << 8) |
+             ((uint32_t)mask_of(v.z, a.fill) << 16) | ((uint32_t)mask_of(v.w, a.fill) << 24);
+      } else {
+        *reinterpret_cast<float4*>(a.fused + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
+      }
+      *reinterpret_cast<uint32_t*>(a.fused_mask + cell) = mk;
+    }
+    signal_slot_free(a.signal, a.ticket);
+    return;
+  }
+  const int gi = threadIdx.x & (kFuseGroups - 1), lane = threadIdx.x / kFuseGroups;
+  const int trow = (int)blockIdx.x / tpr, tcol = (int)blockIdx.x - trow * tpr;
+  const int z = a.gz0 + trow;
+  const int gx = (a.gx0 >> 2) + tcol * kFuseGroups + gi;          // group index within the row
+  const bool live = gx < (a.gx1 >> 2);
+  const int x = (live ? gx : (a.gx0 >> 2)) << 2;
+  const int z_lo = z, z_hi = z;
+  const int x_lo = ((a.gx0 >> 2) + tcol * kFuseGroups) << 2;
+  const int x_hi = x_lo + 4 * kFuseGroups < a.gx1 ? x_lo + 4 * kFuseGroups : a.gx1;
+  const size_t cell = (size_t)ch * M + (size_t)z * a.mw + x;
+  float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+  if (a.accumulate && lane == 0 && live) acc = *reinterpret_cast<const float4*>(a.fused + cell);
+  for (int c0 = 0; c0 < a.nwin; c0 += kFuseChunk) {
+    // round 1: which windows of this chunk touch the block's cells at all?
+    if (threadIdx.x == 0) ncand = 0;
+    __syncthreads();
+    for (int r = c0 + threadIdx.x; r < a.nwin && r < c0 + kFuseChunk; r += blockDim.x) {
+      const Window w = widen(a.wins[(size_t)a.b0 * a.nparts + r]);
+      if (w.w > 0 && w.z0 <= z_hi && w.z0 + w.h > z_lo && w.x0 < x_hi && w.x0 + w.w > x_lo) {
+        const int slot = atomicAdd(&ncand, 1);
+        const int b = r / a.nparts, p = r - b * a.nparts;
+        cwin[slot] = make_int4(w.x0, w.z0, w.w, w.h);
+        cslab[slot] = ((a.b0 + b) * a.oc + chl) * a.nparts + p;
+      }
+    }
+    __syncthreads();
+    // round 2: the 8 lanes of a group split the candidates, four slab loads in flight
+    const int n = ncand;
+    for (int i0 = lane; i0 < n; i0 += 4 * kFuseLanes) {
+      float4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * kFuseLanes;
+        v[k] = acc;
+        if (i < n) {
+          const int4 w = cwin[i];
+          const unsigned ux = (unsigned)(x - w.x), uz = (unsigned)(z - w.y);
+          if (ux < (unsigned)w.z && uz < (unsigned)w.w)
+            v[k] = *reinterpret_cast<const float4*>(
+                a.slabs + (size_t)cslab[i] * a.slab_stride + (size_t)uz * w.z + ux);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc.x = IS_MAX ? fmaxf(acc.x, v[k].x) : fminf(acc.x, v[k].x);
+        acc.y = IS_MAX ? fmaxf(acc.y, v[k].y) : fminf(acc.y, v[k].y);
+        acc.z = IS_MAX ? fmaxf(acc.z, v[k].z) : fminf(acc.z, v[k].z);
+        acc.w = IS_MAX ? fmaxf(acc.w, v[k].w) : fminf(acc.w, v[k].w);
+      }
+    }
+    __syncthreads();
+  }
+  part[lane][gi] = acc;
+  __syncthreads();
+  if (lane == 0 && live) {
+#pragma unroll
+    for (int k = 1; k < kFuseLanes; ++k) {
+      const float4 o = part[k][gi];
+      acc.x = IS_MAX ? fmaxf(acc.x, o.x) : fminf(acc.x, o.x);
+      acc.y = IS_MAX ? fmaxf(acc.y, o.y) : fminf(acc.y, o.y);
+      acc.z = IS_MAX ? fmaxf(acc.z, o.z) : fminf(acc.z, o.z);
+      acc.w = IS_MAX ? fmaxf(acc.w, o.w) : fminf(acc.w, o.w);
+    }
+    *reinterpret_cast<float4*>(a.fused + cell) = acc;
+    const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+                        ((uint32_t)mask_of(acc.z, a.fill) << 16) |
+                        ((uint32_t)mask_of(acc.w, a.fill) << 24);
+    *reinterpret_cast<uint32_t*>(a.fused_mask + cell) = mk;
+  }
+  signal_slot_free(a.signal, a.ticket);
+}
+
+}  // namespace
+}  // namespace dm

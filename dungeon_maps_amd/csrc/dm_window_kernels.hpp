@@ -639,6 +639,7 @@ template <bool IS_MAX>
 __global__ void __launch_bounds__(kFuseGroups * kFuseLanes)
 k_fuse_unions(FuseArgs a) {
   __shared__ float4 part[kFuseLanes][kFuseGroups];
+  __shared__ int4 lunion[kFuseGroups * kFuseLanes];      // union windows of up to 256 frames
   const int ch = blockIdx.y;
   const int g4 = a.mw >> 2;
   const int gi = threadIdx.x & (kFuseGroups - 1), lane = threadIdx.x / kFuseGroups;
@@ -650,25 +651,37 @@ k_fuse_unions(FuseArgs a) {
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
   if (a.accumulate && lane == 0 && live)
     acc = *reinterpret_cast<const float4*>(a.fused + (size_t)ch * M + cell);
-  for (int b0 = lane; b0 < a.B; b0 += 8 * kFuseLanes) {
-    float4 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int bb = b0 + k * kFuseLanes;
-      v[k] = acc;
-      if (bb < a.B) {
-        const Window U = widen(a.unions[a.b0 + bb]);
-        if ((unsigned)(z - U.z0) < (unsigned)U.h && (unsigned)(x - U.x0) < (unsigned)U.w)
-          v[k] = *reinterpret_cast<const float4*>(
-              a.maps + ((size_t)(a.b0 + bb) * a.dc + ch) * M + cell);
-      }
+  constexpr int kStage = kFuseGroups * kFuseLanes;
+  for (int c0 = 0; c0 < a.B; c0 += kStage) {
+    // the union windows go through LDS: one load per thread instead of a dependent global
+    // load in front of every map load
+    if (c0 > 0) __syncthreads();
+    if (c0 + (int)threadIdx.x < a.B) {
+      const Window U = widen(a.unions[a.b0 + c0 + threadIdx.x]);
+      lunion[threadIdx.x] = make_int4(U.x0, U.z0, U.w, U.h);
     }
+    __syncthreads();
+    const int n = a.B - c0 < kStage ? a.B - c0 : kStage;
+    for (int b0 = lane; b0 < n; b0 += 8 * kFuseLanes) {
+      float4 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      acc.x = IS_MAX ? fmaxf(acc.x, v[k].x) : fminf(acc.x, v[k].x);
-      acc.y = IS_MAX ? fmaxf(acc.y, v[k].y) : fminf(acc.y, v[k].y);
-      acc.z = IS_MAX ? fmaxf(acc.z, v[k].z) : fminf(acc.z, v[k].z);
-      acc.w = IS_MAX ? fmaxf(acc.w, v[k].w) : fminf(acc.w, v[k].w);
+      for (int k = 0; k < 8; ++k) {
+        const int bb = b0 + k * kFuseLanes;
+        v[k] = acc;
+        if (bb < n) {
+          const int4 U = lunion[bb];
+          if ((unsigned)(z - U.y) < (unsigned)U.w && (unsigned)(x - U.x) < (unsigned)U.z)
+            v[k] = *reinterpret_cast<const float4*>(
+                a.maps + ((size_t)(a.b0 + c0 + bb) * a.dc + ch) * M + cell);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        acc.x = IS_MAX ? fmaxf(acc.x, v[k].x) : fminf(acc.x, v[k].x);
+        acc.y = IS_MAX ? fmaxf(acc.y, v[k].y) : fminf(acc.y, v[k].y);
+        acc.z = IS_MAX ? fmaxf(acc.z, v[k].z) : fminf(acc.z, v[k].z);
+        acc.w = IS_MAX ? fmaxf(acc.w, v[k].w) : fminf(acc.w, v[k].w);
+      }
     }
   }
   part[lane][gi] = acc;

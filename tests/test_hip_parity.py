@@ -475,3 +475,52 @@ def test_table_ring_reuse(dmap, B, H, W, mh, mw, calls):
     fused, _ = proj.orth_project_fused(depth_d, cam_pose=poses[i % 5])
     bad += (fused != ref_f[i % 5]).sum()
   assert int(bad.item()) == 0
+
+
+def test_two_threads_two_streams(dmap):
+  """The library keeps per-thread state (error string, table ring, remembered splits): two
+  Python threads, each on its own stream and with its own poses, must not disturb each other."""
+  import threading
+  from dungeon_maps_amd import _native
+  lib = _native.lib()
+  B, H, W, mh, mw = 6, 96, 128, 128, 128
+  depth, _ = _synthetic(B, H, W, seed=11)
+  depth_d = torch.from_numpy(depth).cuda()
+  proj = dmap.MapProjector(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+                           cam_height=0.88, width_offset=mw / 2., height_offset=mh / 2., map_res=0.03,
+                           map_width=mw, map_height=mh, trunc_depth_min=0.15, trunc_depth_max=5.05,
+                           to_global=True, fill_value=-np.inf)
+  g = torch.Generator().manual_seed(3)
+  poses, refs = [], []
+  lib.dm_debug_force_generic_path(1)
+  try:
+    for _ in range(2):
+      pose = torch.empty(B, 3).uniform_(-1, 1, generator=g)
+      pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)
+      poses.append(pose)
+      refs.append(proj.orth_project(depth_d, cam_pose=pose))
+  finally:
+    lib.dm_debug_force_generic_path(0)
+  torch.cuda.synchronize()
+  errors = []
+
+  def worker(k):
+    try:
+      stream = torch.cuda.Stream()
+      bad = torch.zeros((), dtype=torch.int64, device="cuda")
+      with torch.cuda.stream(stream):
+        for _ in range(150):
+          top, mask = proj.orth_project(depth_d, cam_pose=poses[k])
+          bad += (top != refs[k][0]).sum() + (mask != refs[k][1]).sum()
+      stream.synchronize()
+      if int(bad.item()) != 0:
+        errors.append(f"thread {k}: {int(bad.item())} cells differ")
+    except Exception as exc:      # noqa: BLE001 - reported by the main thread
+      errors.append(f"thread {k}: {exc!r}")
+
+  threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join()
+  assert not errors, errors

@@ -77,36 +77,41 @@ __host__ __device__ inline void band_bounds(float dmin, float dmax, int pd, int 
 }
 
 __host__ Parts choose_parts(const dm_params& p, int min_parts = 1, int pd = 1) {
-  // enough workgroups to fill 256 CUs (and at least min_parts, so that windows fit
-  // in LDS), parts not smaller than 32 columns, strip boundaries on 128-byte lines
-  // (32 floats) when W allows it
-  // ... but not more than pays: the scatter kernel of a small batch is latency bound
-  // (~6 us + 0.3 us per pixel and thread), the merge kernel visits every part per cell
-  // (~0.37 us per part), so the sum is smallest near sqrt(0.8 * pixels / 1024) parts
-  // (measured at B = 1, 320x240: 80 parts 43 us, 10 parts 15 us)
+  // The split of the image into pc column strips x pr row blocks (x pd depth bands) that the
+  // measured cost model likes best, among those of at least min_parts image parts (more,
+  // narrower parts until the windows fit in LDS).  Model (MI355X, 1024-thread workgroups, one
+  // per CU): workgroups run in waves of 256, a workgroup takes ~6 us + 0.3 us per pixel and
+  // thread, the merge ~0.37 us per part.  So: fill the 256 CUs, but in whole waves (16 frames
+  // of 20 parts are two waves of which the second is a quarter full: 96 us; 16 parts: one),
+  // and do not split a small batch further than pays (B = 1, 320x240: 80 parts 43 us, 10
+  // parts 15 us).  Strips are multiples of 32 columns (128-byte lines) when W allows it and
+  // equal (pc divides the unit count); at most 16 strips x 8 row blocks of >= 16 rows.
   const long frames = (long)p.B * (p.vc ? p.vc : p.dc);
-  int want = (int)((256 + frames - 1) / frames);
-  const int pays = (int)lround(sqrt(0.8 * (double)p.H * p.W / 1024.0));
-  if (want > pays) want = pays;
-  want = (want + pd - 1) / pd;                 // image parts: the depth bands multiply them
-  if (want < min_parts) want = min_parts;
-  if (want < 1) want = 1;
-  Parts s;
-  s.pc = 1; s.pr = 1; s.pd = pd;
   const int unit = (p.W % 32 == 0) ? 32 : 4;
   const int units = (p.W + unit - 1) / unit;
-  int pc = want < units ? want : units;
-  if (pc > 16) pc = 16;
-  // prefer a divisor of the unit count (equal strips)
-  while (pc > 1 && units % pc != 0) --pc;
-  s.pc = pc;
-  s.wp = ((units + pc - 1) / pc) * unit;
-  int pr = (want + pc - 1) / pc;
-  if (pr > 8) pr = 8;
-  if (pr > p.H / 16) pr = p.H / 16 > 0 ? p.H / 16 : 1;
-  s.pr = pr;
-  s.hp = (p.H + pr - 1) / pr;
-  return s;
+  const int max_pr = p.H / 16 > 8 ? 8 : (p.H / 16 > 0 ? p.H / 16 : 1);
+  Parts best;
+  best.pc = 1; best.pr = 1; best.pd = pd; best.wp = units * unit; best.hp = p.H;
+  double best_cost = INFINITY;
+  int best_n = 0;
+  for (int pc = 1; pc <= units && pc <= 16; ++pc) {
+    if (units % pc != 0) continue;
+    for (int pr = 1; pr <= max_pr; ++pr) {
+      const int n = pc * pr;
+      const int wp = (units / pc) * unit, hp = (p.H + pr - 1) / pr;
+      const double waves = ceil((double)frames * n * pd / 256.0);
+      double cost = waves * (6.0 + 0.3 * (double)wp * hp / 1024.0) + 0.37 * n * pd;
+      // not enough parts for the caller: only as the last resort (the most parts there are)
+      if (n < min_parts) cost = 1e30 - n;
+      const bool better = cost < best_cost - 1e-9 ||
+                          (fabs(cost - best_cost) <= 1e-9 && (n < best_n || (n == best_n && pc > best.pc)));
+      if (better) {
+        best_cost = cost; best_n = n;
+        best.pc = pc; best.pr = pr; best.wp = wp; best.hp = hp;
+      }
+    }
+  }
+  return best;
 }
 
 // y = RN(1/b) in float32, exactly: pick the neighbour minimising |b*y - 1|

@@ -4,7 +4,12 @@
 // fallback behind the LDS-windowed fast path (dm_window.hip) and the reference
 // implementation the fast path is tested against on the device.  Memory-side
 // atomics make it ~10-50x slower than the roofline, see DESIGN.md.
+#include <string.h>
+
+#include <vector>
+
 #include "dm_kernels.hpp"
+#include "dm_window_geometry.hpp"      // frame_affine / part_window: a frame's reach in the map
 
 namespace dm {
 
@@ -41,10 +46,11 @@ __device__ inline void reduce_into(float* addr, float v) {
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_fill(float* __restrict__ a, float va, size_t na, float* __restrict__ b, float vb,
-       size_t nb) {
+       size_t nb, uint32_t* __restrict__ zero = nullptr, size_t nzero = 0) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) a[i] = va;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) b[i] = vb;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += stride) zero[i] = 0u;
 }
 
 // One thread per pixel; grid = (ceil(N/256), dc, B).  FUSED: all frames write
@@ -84,20 +90,80 @@ k_scatter_generic(View v, int dc, int vc, int valid_c, const dm_frame* __restric
   if (height) atomic_max_f32(height + ((size_t)b * dc + ch) * M + h.cell, h.y);
 }
 
-// mask (+ mean division).  n = elements of out.
+// mask (+ mean division).  n = elements of out.  Four cells per thread (16-byte loads, one
+// 4-byte mask store: single-byte stores run at a third of the rate) when out / count are
+// 16-byte and mask 4-byte aligned, which the host checks; the tail is done cell by cell.
+__device__ inline float finalize_cell(float o, float c, bool mean) {
+  return mean ? o / (c < 1.0f ? 1.0f : c) : o;
+}
+
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 k_finalize(float* __restrict__ out, const float* __restrict__ count, float fill,
            uint8_t* __restrict__ mask, size_t n) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n4 = VEC ? n / 4 : 0;
+  for (size_t g = first; g < n4; g += stride) {
+    float4 o = reinterpret_cast<const float4*>(out)[g];
+    if (count) {
+      const float4 c = reinterpret_cast<const float4*>(count)[g];
+      o.x = finalize_cell(o.x, c.x, true); o.y = finalize_cell(o.y, c.y, true);
+      o.z = finalize_cell(o.z, c.z, true); o.w = finalize_cell(o.w, c.w, true);
+      reinterpret_cast<float4*>(out)[g] = o;
+    }
+    reinterpret_cast<uint32_t*>(mask)[g] =
+        (uint32_t)mask_of(o.x, fill) | ((uint32_t)mask_of(o.y, fill) << 8) |
+        ((uint32_t)mask_of(o.z, fill) << 16) | ((uint32_t)mask_of(o.w, fill) << 24);
+  }
+  for (size_t i = n4 * 4 + first; i < n; i += stride) {
     float o = out[i];
     if (count) {
-      const float c = count[i];
-      o = o / (c < 1.0f ? 1.0f : c);
+      o = finalize_cell(o, count[i], true);
       out[i] = o;
     }
     mask[i] = mask_of(o, fill);
   }
+}
+
+static hipError_t launch_finalize(float* out, const float* count, float fill, uint8_t* mask, size_t n,
+                                  hipStream_t s) {
+  const bool vec = reinterpret_cast<uintptr_t>(out) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(count) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(mask) % 4 == 0;
+  const size_t threads = vec ? (n + 3) / 4 : n;
+  size_t blocks = (threads + 1023) / 1024;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  if (vec) hipLaunchKernelGGL(k_finalize<true>, dim3((unsigned)blocks), dim3(256), 0, s, out, count, fill, mask, n);
+  else hipLaunchKernelGGL(k_finalize<false>, dim3((unsigned)blocks), dim3(256), 0, s, out, count, fill, mask, n);
+  return hipGetLastError();
+}
+
+// The same restricted to each frame's union window (x0, z0, w, h; x0 and w multiples of 4): on
+// large maps at fine resolution a frame reaches a small part of its map, the rest keeps the
+// fill value and the mask 0 that k_fill wrote.  grid = (groups of the largest window, B * oc).
+__global__ void __launch_bounds__(256)
+k_finalize_unions(float* __restrict__ out, const float* __restrict__ count, float fill,
+                  uint8_t* __restrict__ mask, const int4* __restrict__ unions, int oc, int mh,
+                  int mw) {
+  const int b = blockIdx.y / oc;
+  const int4 U = unions[b];
+  const int ug4 = U.z >> 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ug4 * U.w) return;
+  const int row = i / ug4;
+  const size_t cell = (size_t)blockIdx.y * mh * mw + (size_t)(U.y + row) * mw + U.x + ((i - row * ug4) << 2);
+  float4 o = *reinterpret_cast<const float4*>(out + cell);
+  if (count) {
+    const float4 c = *reinterpret_cast<const float4*>(count + cell);
+    o.x = finalize_cell(o.x, c.x, true); o.y = finalize_cell(o.y, c.y, true);
+    o.z = finalize_cell(o.z, c.z, true); o.w = finalize_cell(o.w, c.w, true);
+    *reinterpret_cast<float4*>(out + cell) = o;
+  }
+  *reinterpret_cast<uint32_t*>(mask + cell) =
+      (uint32_t)mask_of(o.x, fill) | ((uint32_t)mask_of(o.y, fill) << 8) |
+      ((uint32_t)mask_of(o.z, fill) << 16) | ((uint32_t)mask_of(o.w, fill) << 24);
 }
 
 static inline int blocks_for(size_t n, int per_block, int cap) {
@@ -133,9 +199,13 @@ static inline size_t frames_bytes(const dm_params& p) {
   return ((size_t)p.B * sizeof(dm_frame) + 255) / 256 * 256;
 }
 
-// workspace: frame table | per-cell counts (mean only)
+static inline size_t unions_bytes(const dm_params& p) {
+  return ((size_t)p.B * sizeof(int4) + 255) / 256 * 256;
+}
+
+// workspace: frame table | union windows | per-cell counts (mean only)
 size_t generic_workspace_bytes(const dm_params& p) {
-  size_t n = frames_bytes(p);
+  size_t n = frames_bytes(p) + unions_bytes(p);
   if (p.reduction == DM_REDUCE_MEAN) {
     const size_t oc = p.vc ? p.vc : p.dc;
     n += (size_t)p.B * oc * p.mh * p.mw * sizeof(float);
@@ -149,30 +219,72 @@ static hipError_t upload_frames(const dm_params& p, const dm_frame* frames_host,
   return hipMemcpyAsync(ws, frames_host, (size_t)p.B * sizeof(dm_frame), hipMemcpyHostToDevice, s);
 }
 
+// Union window of every frame (the map cells its frustum can reach, x aligned to 4); returns
+// false when restricting the finalize pass to them cannot work or does not pay (unbounded
+// frustum, odd map width, windows covering more than half of the maps).
+static bool frame_unions(const dm_params& p, const dm_frame* frames_host, std::vector<int4>& unions,
+                         int* max_area) {
+  if (p.mw % 4 != 0 || !frustum_bounded(p)) return false;
+  const PartSlopes whole = part_slopes(p, 0, p.W, 0, p.H);
+  unions.resize(p.B);
+  size_t covered = 0;
+  *max_area = 0;
+  for (int b = 0; b < p.B; ++b) {
+    const FrameAffine fa = frame_affine(p, frames_host[b]);
+    const Window w = part_window(p, fa, whole, true, p.dmin, p.dmax);
+    unions[b] = make_int4(w.x0, w.z0, w.w, w.w > 0 ? w.h : 0);
+    covered += (size_t)w.w * w.h;
+    if (w.w * w.h > *max_area) *max_area = w.w * w.h;
+  }
+  return covered * 2 <= (size_t)p.B * p.mh * p.mw;
+}
+
 hipError_t run_generic(const dm_params& p, const dm_frame* frames_host, const float* depth,
                        const float* value, const uint8_t* valid, float* out,
                        uint8_t* mask, float* height, void* ws, hipStream_t s) {
-  hipError_t ue = upload_frames(p, frames_host, ws, s);
-  if (ue != hipSuccess) return ue;
-  const dm_frame* frames = static_cast<const dm_frame*>(ws);
   const View v = make_view(p);
   const size_t M = (size_t)p.mh * p.mw, oc = p.vc ? p.vc : p.dc;
   const size_t n_out = (size_t)p.B * oc * M;
   const size_t n_h = height ? (size_t)p.B * p.dc * M : 0;
+  unsigned char* base = static_cast<unsigned char*>(ws);
+  const dm_frame* frames = static_cast<const dm_frame*>(ws);
+  const int4* d_unions = reinterpret_cast<const int4*>(base + frames_bytes(p));
   float* count = p.reduction == DM_REDUCE_MEAN
-      ? reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + frames_bytes(p)) : nullptr;
+      ? reinterpret_cast<float*>(base + frames_bytes(p) + unions_bytes(p)) : nullptr;
+  // frames (+ union windows) in one stream-ordered copy
+  thread_local std::vector<int4> unions;
+  thread_local std::vector<unsigned char> staging;
+  int max_area = 0;
+  const bool by_unions = reinterpret_cast<uintptr_t>(out) % 16 == 0 &&
+                         reinterpret_cast<uintptr_t>(mask) % 4 == 0 &&
+                         reinterpret_cast<uintptr_t>(ws) % 256 == 0 &&
+                         frame_unions(p, frames_host, unions, &max_area);
+  hipError_t ue;
+  if (by_unions) {
+    staging.resize(frames_bytes(p) + (size_t)p.B * sizeof(int4));
+    memcpy(staging.data(), frames_host, (size_t)p.B * sizeof(dm_frame));
+    memcpy(staging.data() + frames_bytes(p), unions.data(), (size_t)p.B * sizeof(int4));
+    ue = hipMemcpyAsync(ws, staging.data(), staging.size(), hipMemcpyHostToDevice, s);
+  } else {
+    ue = upload_frames(p, frames_host, ws, s);
+  }
+  if (ue != hipSuccess) return ue;
   hipLaunchKernelGGL(k_fill, dim3(blocks_for(n_out > n_h ? n_out : n_h, 1024, 4096)), dim3(256),
-                     0, s, out, p.fill, n_out, height, -__builtin_inff(), n_h);
+                     0, s, out, p.fill, n_out, height, -__builtin_inff(), n_h,
+                     by_unions ? reinterpret_cast<uint32_t*>(mask) : nullptr,
+                     by_unions ? n_out / 4 : (size_t)0);
   if (count)
     hipLaunchKernelGGL(k_fill, dim3(blocks_for(n_out, 1024, 4096)), dim3(256), 0, s, count, 0.0f,
-                       n_out, (float*)nullptr, 0.0f, (size_t)0);
+                       n_out, (float*)nullptr, 0.0f, (size_t)0, (uint32_t*)nullptr, (size_t)0);
   const int N = p.H * p.W;
   dim3 grid((N + 255) / 256, p.dc, p.B);
   hipError_t e = launch_scatter<false>(p, v, grid, frames, depth, value, valid, out, height,
                                        count, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_finalize, dim3(blocks_for(n_out, 1024, 4096)), dim3(256), 0, s, out, count,
-                     p.fill, mask, n_out);
+  if (!by_unions) return launch_finalize(out, count, p.fill, mask, n_out, s);
+  if (max_area == 0) return hipSuccess;           // no frame reaches its map
+  hipLaunchKernelGGL(k_finalize_unions, dim3((unsigned)((max_area / 4 + 255) / 256), (unsigned)(p.B * oc)),
+                     dim3(256), 0, s, out, count, p.fill, mask, d_unions, (int)oc, p.mh, p.mw);
   return hipGetLastError();
 }
 
@@ -187,15 +299,13 @@ hipError_t run_generic_fused(const dm_params& p, const dm_frame* frames_host, co
   const size_t n_out = oc * M;
   if (!accumulate)
     hipLaunchKernelGGL(k_fill, dim3(blocks_for(n_out, 1024, 4096)), dim3(256), 0, s, out, p.fill,
-                       n_out, (float*)nullptr, 0.0f, (size_t)0);
+                       n_out, (float*)nullptr, 0.0f, (size_t)0, (uint32_t*)nullptr, (size_t)0);
   const int N = p.H * p.W;
   dim3 grid((N + 255) / 256, p.dc, p.B);
   hipError_t e = launch_scatter<true>(p, v, grid, frames, depth, value, valid, out, nullptr,
                                       nullptr, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_finalize, dim3(blocks_for(n_out, 1024, 4096)), dim3(256), 0, s, out,
-                     (const float*)nullptr, p.fill, mask, n_out);
-  return hipGetLastError();
+  return launch_finalize(out, nullptr, p.fill, mask, n_out, s);
 }
 
 // out[i] = max/min over b of maps[b][i]; 4 cells per thread, 16-byte accesses.
@@ -251,9 +361,7 @@ hipError_t run_fuse_batch(const float* maps, int B, size_t n, float* out, bool i
 
 hipError_t run_mask_from_map(const float* map, float fill, uint8_t* mask, size_t n,
                              hipStream_t s) {
-  hipLaunchKernelGGL(k_finalize, dim3(blocks_for(n, 1024, 4096)), dim3(256), 0, s,
-                     const_cast<float*>(map), (const float*)nullptr, fill, mask, n);
-  return hipGetLastError();
+  return launch_finalize(const_cast<float*>(map), nullptr, fill, mask, n, s);
 }
 
 }  // namespace dm

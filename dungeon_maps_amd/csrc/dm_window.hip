@@ -301,14 +301,14 @@ thread_local bool g_force_bands = false;           // dm_debug_force_bands
 
 // Depth bands multiply the workgroups, each with a window to initialise and flush: with few
 // pixels per part that costs more than the generic path's atomics.  Both sides as measured on
-// MI355X: generic = 22 ps per point + fill at 3 TB/s; windowed = per pass
+// MI355X: generic = 20 ps per point + fill at 5.5 TB/s; windowed = per pass
 // waves of 256 workgroups at 4 us + (slab + part pixels) at 20 GB/s per CU, plus the merge
 // reading the slabs at 3.7 TB/s.
 bool banded_split_pays(const dm_params& p, const Parts& parts, int nparts, int max_area,
                        size_t slab_capacity) {
   const double oc = p.vc ? p.vc : p.dc;
   const double points = (double)p.B * p.H * p.W * oc, cells = (double)p.B * oc * p.mh * p.mw;
-  const double t_generic = points * 22e-6 + cells * 5.0 / 3.0e6;
+  const double t_generic = points * 20e-6 + cells * 5.0 / 5.5e6;
   const double slab = (double)align_up((size_t)max_area, 4) * 4.0;
   double frames = p.B;
   int passes = 1;

@@ -524,3 +524,32 @@ def test_two_threads_two_streams(dmap):
   for t in threads:
     t.join()
   assert not errors, errors
+
+
+@pytest.mark.parametrize("red,fill", [("sum", 0.0), ("mean", 2.0), ("prod", 1.0), ("min", np.inf),
+                                      ("max", 0.25)])
+def test_generic_path_on_large_sparse_maps(dmap, oracle, red, fill):
+  """Large maps at fine resolution: each frame reaches a small part of its map, the generic path
+  then finalises (mask, mean division) only inside the frame's union window and the rest of
+  the map and mask comes from the fill kernel.  Every reduction, value maps with their height
+  map, valid maps, a frame that misses the map."""
+  B, H, W, mh, mw = 3, 60, 80, 640, 512
+  depth, pose = _synthetic(B, H, W, seed=77)
+  pose[2, :2] = [40.0, -35.0]                      # this frame's frustum lies outside the map
+  value = np.random.default_rng(5).uniform(0.5, 1.5, size=(B, 2, H, W)).astype(np.float32)
+  valid = np.random.default_rng(6).uniform(size=(B, 1, H, W)) > 0.2
+  cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+             cam_height=0.88, width_offset=mw / 2., height_offset=mh / 2., map_res=0.01,
+             map_width=mw, map_height=mh, trunc_depth_min=0.15, trunc_depth_max=2.05,
+             to_global=True, fill_value=fill, reduction=red, clip_border=2)
+  got = _run(dmap, cfg, depth, value=value, valid=valid, get_height_map=True, cam_pose=pose)
+  want = oracle.orth_project(depth, value_map=value, valid_map=valid, get_height_map=True,
+                             **dict(_oracle_kwargs(oracle, cfg), cam_pose=pose))
+  if red in ("max", "min"):
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+  else:
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5, atol=1e-6)
+    assert (got[1] != want[1]).mean() < 1e-4
+  np.testing.assert_array_equal(got[2], np.ascontiguousarray(want[2]))
+  assert got[1][2].sum() == 0 and want[1][2].sum() == 0       # the frame that misses the map

@@ -46,17 +46,19 @@ class MapProjector:
                reduction: Optional[Reduction] = None,
                device: Optional[torch.device] = None):
     values = locals()
+    d = self.__dict__                      # (not through __setattr__: nothing is cached yet)
     for name in self._FIELDS:
-      setattr(self, name, values[name])
-    self.cam_params: CameraIntrinsics = utils.get_camera_intrinsics(
-        width=width, height=height, hfov=hfov, vfov=vfov)
+      d[name] = values[name]
+    d["_dm_defaults"] = {}                 # forwarding methods: their resolved defaults
+    d["cam_params"] = utils.get_camera_intrinsics(width=width, height=height, hfov=hfov, vfov=vfov)
 
   def __setattr__(self, name, value):
-    # the forwarding methods cache their resolved defaults on the instance
+    # the forwarding methods cache their resolved defaults on the instance: any assignment
+    # drops them
     d = self.__dict__
-    if not name.startswith("_dm_defaults_"):
-      for k in [k for k in d if k.startswith("_dm_defaults_")]:
-        del d[k]
+    cache = d.get("_dm_defaults")
+    if cache:
+      cache.clear()
     d[name] = value
 
   def clone(self, **overrides) -> "MapProjector":
@@ -80,7 +82,7 @@ def _forwarding_method(fn, doc_ref: str):
   attrs = tuple(intr.get(n, n) for n in names)
   nargs = len(names)
 
-  cache_key = "_dm_defaults_" + fn.__name__
+  cache_key = fn.__name__
 
   def resolve(self):
     """(value for an argument that was not passed, value for one passed as None), per argument:
@@ -93,15 +95,19 @@ def _forwarding_method(fn, doc_ref: str):
       field.append(getattr(self, attrs[i]) if kind == 1 else
                    getattr(cam, attrs[i]) if kind == 2 else None)   # get(arg, self.<arg>)
     absent = tuple(fn_defaults[i] if v is None else v for i, v in enumerate(field))
-    cached = (absent, tuple(field))
-    self.__dict__[cache_key] = cached          # dropped by MapProjector.__setattr__
+    # (tagged with the owner: a copy.copy() of a projector shares this dict until it is cleared)
+    cached = (absent, tuple(field), id(self))
+    self.__dict__.setdefault("_dm_defaults", {})[cache_key] = cached   # dropped by __setattr__
     return cached
 
   def method(self, *args, **kwargs):
     given = len(args)
     if given > nargs:
       raise TypeError(f"{fn.__name__}() takes at most {nargs} arguments")
-    absent, field = self.__dict__.get(cache_key) or resolve(self)
+    cached = self.__dict__["_dm_defaults"].get(cache_key)
+    if cached is None or cached[2] != id(self):
+      cached = resolve(self)
+    absent, field = cached[0], cached[1]
     call = list(absent)
     for i in range(given):
       v = args[i]

@@ -97,6 +97,13 @@ def test_projector_defaults_clone_and_forwarding():
   assert q.map_quantize([0.1, 0.2], [0.3, 0.4])[0].tolist() == [[7, 8]]
   with pytest.raises(TypeError):
     q.map_quantize([0.1], [0.3], no_such_argument=1)
+  import copy
+  r = copy.copy(q)                       # shares the cache dict until an assignment clears it
+  assert r.map_quantize([0.1, 0.2], [0.3, 0.4])[0].tolist() == [[7, 8]]
+  r.width_offset = 0.
+  assert q.map_quantize([0.1, 0.2], [0.3, 0.4])[0].tolist() == [[7, 8]]
+  assert r.map_quantize([0.1, 0.2], [0.3, 0.4])[0].tolist() == [[1, 2]]
+  assert q.map_quantize([0.1, 0.2], [0.3, 0.4])[0].tolist() == [[7, 8]]
 
 
 def test_coordinate_queries_match_reference():

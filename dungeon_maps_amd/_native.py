@@ -63,6 +63,9 @@ _SIGNATURES = {
     "dm_debug_force_generic_path": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_force_bands": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_last_split": (None, [ctypes.POINTER(ctypes.c_int32)]),
+    "dm_debug_windows": (ctypes.c_int, [ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                        ctypes.c_size_t]),
     "dm_fuse_bbox_f32": (ctypes.c_int, [
         ctypes.POINTER(FuseSrc), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "dm_fuse_scatter_f32": (ctypes.c_int, [

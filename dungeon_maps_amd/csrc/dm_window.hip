@@ -721,6 +721,43 @@ extern "C" __attribute__((visibility("default"))) void dm_debug_last_split(int32
   dm::g_last_split[3] = 0;
 }
 
+// Host only (no GPU needed): the split of the image and every (frame, part) window, exactly
+// as stage_windows derives them.
+extern "C" __attribute__((visibility("default"))) int dm_debug_windows(
+    const dm_params* p, const dm_frame* frames, int min_parts, int pd, int32_t* out_parts,
+    int32_t* out_windows, size_t window_capacity) {
+  using namespace dm;
+  if (!p || !frames || !out_parts || p->B < 1 || pd < 1 || pd > 8) return -1;
+  const Parts parts = choose_parts(*p, min_parts, pd);
+  const int image_parts = parts.pc * parts.pr, nparts = image_parts * pd;
+  out_parts[0] = parts.pc; out_parts[1] = parts.pr; out_parts[2] = parts.pd;
+  out_parts[3] = parts.wp; out_parts[4] = parts.hp;
+  if (!out_windows) return nparts;
+  if (window_capacity < (size_t)p->B * nparts) return -1;
+  const bool bounded = frustum_bounded(*p);
+  std::vector<PartSlopes> slopes(image_parts);
+  for (int pr = 0; pr < parts.pr; ++pr)
+    for (int pc = 0; pc < parts.pc; ++pc) {
+      const int q0 = pc * parts.wp, r0 = pr * parts.hp;
+      const int q1 = q0 + parts.wp < p->W ? q0 + parts.wp : p->W;
+      const int r1 = r0 + parts.hp < p->H ? r0 + parts.hp : p->H;
+      slopes[pr * parts.pc + pc] = part_slopes(*p, q0, q1, r0, r1);
+    }
+  for (int b = 0; b < p->B; ++b) {
+    const FrameAffine fa = frame_affine(*p, frames[b]);
+    for (int k = 0; k < pd; ++k) {
+      float dlo = p->dmin, dhi = p->dmax;
+      if (pd > 1) band_bounds(p->dmin, p->dmax, pd, k, dlo, dhi);
+      for (int ip = 0; ip < image_parts; ++ip) {
+        const Window w = part_window(*p, fa, slopes[ip], bounded, dlo, dhi);
+        int32_t* o = out_windows + ((size_t)b * nparts + k * image_parts + ip) * 4;
+        o[0] = w.x0; o[1] = w.z0; o[2] = w.w; o[3] = w.h;
+      }
+    }
+  }
+  return nparts;
+}
+
 extern "C" __attribute__((visibility("default"))) int dm_debug_force_bands(int on) {
   const int old = dm::g_force_bands;
   dm::g_force_bands = on != 0;

@@ -270,6 +270,19 @@ int dm_debug_force_generic_path(int on);
 void dm_debug_last_split(int32_t* out4);
 
 /*
+ * Test hook, host only (no GPU needed): the split of the image dm_orth_project_f32 derives for
+ * `p` with at least min_parts image parts and pd depth bands (1..8), and the map window of
+ * every (frame, part) for the given poses -- the bound the LDS-windowed path relies on: a
+ * pixel of a part can only land inside the part's window.
+ *   out_parts[5]  = {strips pc, row blocks pr, depth bands pd, strip width wp, block height hp}
+ *   out_windows   (B, pc*pr*pd, 4) int32 {x0, z0, w, h}, part index (band*pr + row)*pc + strip;
+ *                 NULL: only the split.  window_capacity = windows the buffer holds.
+ * Returns the number of parts per frame, negative on bad arguments.
+ */
+int dm_debug_windows(const dm_params* p, const dm_frame* frames, int min_parts, int pd,
+                     int32_t* out_parts, int32_t* out_windows, size_t window_capacity);
+
+/*
  * Test hook: non-zero makes the calling thread's projections take a split with depth bands
  * whenever one fits in LDS, also where the cost model would choose the generic path (small
  * images); returns the previous setting.  Lets the parity tests cover bands on small shapes.

@@ -80,3 +80,48 @@ def test_single_process_all_reduce_is_identity():
   from dungeon_maps_amd import parallel
   t = torch.randn(1, 4, 4)
   assert parallel.all_reduce_fused(t.clone(), None).equal(t)
+
+
+def _gpu_worker(rank, world, port, out_dir):
+  """One rank of the product's N > 1 path on a real GPU (both ranks share cuda:0; the collective
+  runs over gloo because RCCL refuses two ranks on one device)."""
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  import dungeon_maps_amd as dmap
+  from dungeon_maps_amd import parallel
+  depth, pose = _inputs(B=9, H=96, W=128)
+  lo, hi = parallel.shard_range(len(depth), rank, world)
+  proj = dmap.MapProjector(width=128, height=96, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+                           cam_height=0.88, width_offset=64., height_offset=64., map_res=0.05,
+                           map_width=128, map_height=128, trunc_depth_min=0.15, trunc_depth_max=5.05,
+                           to_global=True, fill_value=-np.inf)
+  d = torch.from_numpy(depth[lo:hi]).cuda()
+  top, mask, fused, fmask = parallel.project_and_fuse_sharded(proj, d, pose[lo:hi])
+  torch.cuda.synchronize()
+  np.save(os.path.join(out_dir, f"gpu_fused_{rank}.npy"), fused.cpu().numpy())
+  np.save(os.path.join(out_dir, f"gpu_fmask_{rank}.npy"), fmask.cpu().numpy())
+  np.save(os.path.join(out_dir, f"gpu_top_{rank}.npy"), top.cpu().numpy())
+  dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_gpu_ranks_equal_one_rank(oracle, tmp_path):
+  world = 2
+  port = 31500 + os.getpid() % 2000
+  mp.spawn(_gpu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+  depth, pose = _inputs(B=9, H=96, W=128)
+  cx, cy, fx, fy = oracle.camera_intrinsics(128, 96, np.radians(70.))
+  kw = dict(width_offset=64., height_offset=64., cam_pitch=np.radians(-20.), cam_height=0.88,
+            map_res=0.05, map_width=128, map_height=128, focal_x=fx, focal_y=fy, center_x=cx,
+            center_y=cy, trunc_depth_min=0.15, trunc_depth_max=5.05, to_global=True,
+            fill_value=-np.inf)
+  want, wmask = oracle.orth_project(depth, cam_pose=pose, fused=True, **kw)
+  per_frame, _ = oracle.orth_project(depth, cam_pose=pose, **kw)
+  tops = []
+  for r in range(world):
+    np.testing.assert_array_equal(np.load(tmp_path / f"gpu_fused_{r}.npy"), want)
+    np.testing.assert_array_equal(np.load(tmp_path / f"gpu_fmask_{r}.npy"), wmask)
+    tops.append(np.load(tmp_path / f"gpu_top_{r}.npy"))
+  np.testing.assert_array_equal(np.concatenate(tops), per_frame)     # the shards, in rank order

@@ -103,6 +103,10 @@ def main():
   if world != args.gpus:
     if world == 1 and args.gpus > 1:
       raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+  # (rehearsals on a one-GPU box: DM_BENCH_BACKEND=gloo lets several ranks share the device)
+  backend = os.environ.get("DM_BENCH_BACKEND", "nccl")
+  if backend != "nccl":
+    local_rank %= max(1, torch.cuda.device_count())
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   dist = None
@@ -110,7 +114,10 @@ def main():
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if backend == "nccl":
+      dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+      dist.init_process_group(backend, rank=rank, world_size=world)
 
   import dungeon_maps_amd as dmap
   from dungeon_maps_amd import _native

@@ -30,8 +30,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <setjmp.h>
+#include <signal.h>
+
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <cstddef>
 #include <type_traits>
 #include <vector>
@@ -332,6 +336,40 @@ bool banded_split_pays(const dm_params& p, const Parts& parts, int nparts, int m
 // stored the slot's ticket to pinned host memory; the host waits for that (bounded), and
 // without a free slot or a large BAR the call takes the staged copy.
 constexpr int kTableSlots = 64;
+
+// First use of a ring: does a host store really reach the device buffer?  The attribute says
+// large BAR, but a host that maps the BAR differently must cost a fallback, not the process:
+// the probe store runs under a temporary SIGSEGV / SIGBUS handler and is read back with a
+// (one-off, synchronous) copy.
+sigjmp_buf g_probe_jump;
+void probe_fault(int) { siglongjmp(g_probe_jump, 1); }
+bool host_stores_reach(void* device_buffer) {
+  static std::mutex one_at_a_time;
+  std::lock_guard<std::mutex> lock(one_at_a_time);
+  struct sigaction probe = {}, old_segv = {}, old_bus = {};
+  probe.sa_handler = probe_fault;
+  sigemptyset(&probe.sa_mask);
+  sigaction(SIGSEGV, &probe, &old_segv);
+  sigaction(SIGBUS, &probe, &old_bus);
+  bool stored = false;
+  if (sigsetjmp(g_probe_jump, 1) == 0) {
+    volatile uint32_t* w = static_cast<volatile uint32_t*>(device_buffer);
+    w[0] = 0x600df00du;
+    w[1] = ~0x600df00du;
+    __builtin_ia32_sfence();
+    stored = true;
+  }
+  sigaction(SIGSEGV, &old_segv, nullptr);
+  sigaction(SIGBUS, &old_bus, nullptr);
+  if (!stored) return false;
+  uint32_t back[2] = {0, 0};
+  if (hipMemcpy(back, device_buffer, sizeof(back), hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return back[0] == 0x600df00du && back[1] == ~0x600df00du;
+}
+
 struct TableRing {
   ScatterTables* slots = nullptr;            // device memory, host-writable
   volatile uint32_t* done = nullptr;         // pinned host memory, written by the GPU
@@ -353,6 +391,9 @@ struct TableRing {
           hipExtMallocWithFlags(&d, kTableSlots * sizeof(ScatterTables), hipDeviceMallocFinegrained) !=
               hipSuccess) {
         (void)hipGetLastError();
+        off = true;
+      } else if (!host_stores_reach(d)) {
+        (void)hipFree(d);
         off = true;
       } else if (hipHostMalloc(&h, kTableSlots * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();

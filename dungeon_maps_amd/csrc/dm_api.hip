@@ -39,6 +39,35 @@ int check_params(const dm_params* p) {
   return DM_OK;
 }
 
+// Map widths that are not a multiple of 4 (odd ego-centric maps: 241 x 241 ...): the LDS-windowed
+// path needs 16-byte rows.  Instead of the ~9x slower generic path, the call then projects into
+// maps padded to the next multiple of 4 (workspace) and copies the real columns out: columns
+// are independent, so the kept ones are identical.
+inline bool padded_route(const dm_params& p) {
+  if (p.mw % 4 == 0) return false;
+  dm_params q = p;
+  q.mw = (p.mw + 3) & ~3;
+  return dm::window_path_supported(q);
+}
+inline size_t padded_bytes(const dm_params& p) {          // padded out + mask (+ height), 256-aligned
+  const size_t mw4 = (size_t)((p.mw + 3) & ~3), oc = p.vc ? p.vc : p.dc;
+  const size_t cells = (size_t)p.B * oc * p.mh * mw4, hcells = p.vc ? (size_t)p.B * p.dc * p.mh * mw4 : 0;
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  return up(cells * 4) + up(cells) + up(hcells * 4);
+}
+
+__global__ void __launch_bounds__(256)
+k_unpad(const float* __restrict__ src, const uint8_t* __restrict__ src_mask, float* __restrict__ dst,
+        uint8_t* __restrict__ dst_mask, int mw, int mw4, size_t rows) {
+  const size_t n = rows * (size_t)mw;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const size_t r = i / mw, x = i - r * mw;
+    dst[i] = src[r * mw4 + x];
+    if (dst_mask) dst_mask[i] = src_mask[r * mw4 + x];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -52,6 +81,11 @@ size_t dm_orth_project_workspace_bytes(const dm_params* p) {
   size_t n = dm::generic_workspace_bytes(*p);
   if (dm::window_path_supported(*p)) {
     const size_t w = dm::window_workspace_bytes(*p);
+    if (w > n) n = w;
+  } else if (padded_route(*p)) {
+    dm_params q = *p;
+    q.mw = (p->mw + 3) & ~3;
+    const size_t w = padded_bytes(*p) + dm::window_workspace_bytes(q);
     if (w > n) n = w;
   }
   return n;
@@ -89,6 +123,42 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
     e = dm::run_window(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
                        p->vc ? height_dev : nullptr, fused_dev, fused_mask_dev, workspace_dev,
                        workspace_bytes, pre, mid, s);
+  else if (padded_route(*p) && !g_force_generic &&
+           reinterpret_cast<uintptr_t>(workspace_dev) % 256 == 0) {
+    // project into padded maps at the head of the workspace, then copy the real columns out
+    dm_params q = *p;
+    q.mw = (p->mw + 3) & ~3;
+    const size_t oc = p->vc ? p->vc : p->dc;
+    const size_t cells = (size_t)p->B * oc * p->mh * q.mw;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    unsigned char* base = static_cast<unsigned char*>(workspace_dev);
+    float* out_pad = reinterpret_cast<float*>(base);
+    uint8_t* mask_pad = base + up(cells * 4);
+    float* height_pad = (p->vc && height_dev) ? reinterpret_cast<float*>(base + up(cells * 4) + up(cells))
+                                              : nullptr;
+    const size_t head = padded_bytes(*p);
+    e = dm::run_window(q, frames, depth_dev, value_dev, valid_dev, out_pad, mask_pad, height_pad,
+                       nullptr, nullptr, base + head, workspace_bytes - head, pre, nullptr, s);
+    if (e == hipSuccess) {
+      const size_t rows = (size_t)p->B * oc * p->mh;
+      size_t blocks = (rows * p->mw + 1023) / 1024;
+      if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL(k_unpad, dim3((unsigned)blocks), dim3(256), 0, s, out_pad, mask_pad, out_dev,
+                         mask_dev, p->mw, q.mw, rows);
+      if (height_pad) {
+        const size_t hrows = (size_t)p->B * p->dc * p->mh;
+        hipLaunchKernelGGL(k_unpad, dim3((unsigned)blocks), dim3(256), 0, s, height_pad,
+                           (const uint8_t*)nullptr, height_dev, (uint8_t*)nullptr, p->mw, q.mw, hrows);
+      }
+      e = hipGetLastError();
+      if (e == hipSuccess && mid) e = hipEventRecord(mid, s);
+      if (e == hipSuccess && fused_dev) {
+        const size_t n = oc * p->mh * p->mw;
+        e = dm::run_fuse_batch(out_dev, p->B, n, fused_dev, p->reduction == DM_REDUCE_MAX, 0, s);
+        if (e == hipSuccess) e = dm::run_mask_from_map(fused_dev, p->fill, fused_mask_dev, n, s);
+      }
+    }
+  }
   if (e == hipErrorNotSupported) { // nothing enqueued: a window exceeds LDS, odd alignment, ...
     if (pre) (void)hipEventRecord(pre, s);
     e = dm::run_generic(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,

@@ -553,3 +553,44 @@ def test_generic_path_on_large_sparse_maps(dmap, oracle, red, fill):
     assert (got[1] != want[1]).mean() < 1e-4
   np.testing.assert_array_equal(got[2], np.ascontiguousarray(want[2]))
   assert got[1][2].sum() == 0 and want[1][2].sum() == 0       # the frame that misses the map
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=3, H=96, W=128, mh=97, mw=131),
+    dict(B=2, H=96, W=128, mh=128, mw=241, C=2, fill_value=0.0),          # value maps + height map
+    dict(B=2, H=50, W=70, mh=63, mw=65, reduction="min", fill_value=np.inf, valid=True),
+    dict(B=5, H=96, W=128, mh=101, mw=99, fuse=True),
+])
+def test_odd_map_widths_stay_on_the_window_path(dmap, oracle, case):
+  """mw % 4 != 0 (odd ego-centric maps): projected into maps padded to a multiple of 4 and
+  copied out, not sent down the generic path."""
+  from dungeon_maps_amd import _native
+  lib = _native.lib()
+  c = dict(case)
+  B, H, W, mh, mw = (c.pop(k) for k in ("B", "H", "W", "mh", "mw"))
+  C, use_valid, fuse = c.pop("C", 0), c.pop("valid", False), c.pop("fuse", False)
+  depth, pose = _synthetic(B, H, W, seed=808)
+  value = np.random.default_rng(2).normal(size=(B, C, H, W)).astype(np.float32) if C else None
+  valid = (np.random.default_rng(1).uniform(size=(B, 1, H, W)) > 0.3) if use_valid else None
+  cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+             cam_height=0.88, width_offset=mw / 2., height_offset=mh / 2., map_res=0.05,
+             map_width=mw, map_height=mh, trunc_depth_min=0.15, trunc_depth_max=5.05,
+             to_global=True, fill_value=-np.inf)
+  cfg.update(c)
+  gh = bool(C)
+  got = _run(dmap, cfg, depth, value=value, valid=valid, get_height_map=gh, cam_pose=pose)
+  split = (ctypes.c_int32 * 4)()
+  lib.dm_debug_last_split(split)
+  assert split[0] > 0, "took the generic path"
+  want = oracle.orth_project(depth, value_map=value, valid_map=valid, get_height_map=gh,
+                             **dict(_oracle_kwargs(oracle, cfg), cam_pose=pose))
+  np.testing.assert_array_equal(got[1], want[1])
+  np.testing.assert_array_equal(got[0], want[0])
+  if gh:
+    np.testing.assert_array_equal(got[2], np.ascontiguousarray(want[2]))
+  if fuse:
+    proj = dmap.MapProjector(**cfg)
+    t, m, f, fm = proj.orth_project_and_fuse(torch.from_numpy(depth).cuda(), cam_pose=pose)
+    np.testing.assert_array_equal(t.cpu().numpy(), want[0])
+    np.testing.assert_array_equal(f.cpu().numpy(), want[0].max(axis=0))
+    np.testing.assert_array_equal(fm.cpu().numpy(), want[1].any(axis=0))

@@ -15,7 +15,10 @@ def one(seed):
   H, W = [(48, 64), (60, 80), (96, 128), (50, 70), (120, 160), (240, 320)][int(rng.integers(6))]
   if B * H * W > 3_000_000:
     B = max(1, 3_000_000 // (H * W))
-  mh, mw = [(64, 64), (96, 128), (128, 96), (160, 160), (256, 256), (300, 200)][int(rng.integers(6))]
+  sizes = [(64, 64), (96, 128), (128, 96), (160, 160), (256, 256), (300, 200)]
+  if ODD:          # map widths that are not multiples of 4: padded maps + copy-out (dm_api.hip)
+    sizes = [(65, 63), (97, 131), (128, 241), (255, 255), (301, 199), (100, 102)]
+  mh, mw = sizes[int(rng.integers(6))]
   if FINE:      # long thin wedges: the windowed path needs depth bands (forced on small images)
     mh, mw = [(512, 512), (768, 1024), (1024, 1024), (1024, 640)][int(rng.integers(4))]
     if B * mh * mw > 12_000_000:
@@ -80,6 +83,7 @@ def one(seed):
     bad_v += int((~((a == b) | (np.isnan(a) & np.isnan(b)))).sum())
   return bad_m, bad_v, (B, H, W, mh, mw, res, C)
 
+ODD = os.environ.get("DM_CAMPAIGN_ODD", "0") != "0"      # odd map widths
 FINE = os.environ.get("DM_CAMPAIGN_FINE", "0") != "0"    # fine map_res: depth bands (forced)
 STATS = {"banded": 0, "generic": 0}
 from dungeon_maps_amd import _native

@@ -52,7 +52,8 @@ namespace dm {
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 bool window_path_supported(const dm_params& p) {
-  if (p.reduction != DM_REDUCE_MAX && p.reduction != DM_REDUCE_MIN) return false;
+  if (p.reduction != DM_REDUCE_MAX && p.reduction != DM_REDUCE_MIN && p.reduction != DM_REDUCE_SUM)
+    return false;                               // (mean and prod: generic path)
   if (p.mw % 4 != 0) return false;
   if (p.mw > 32767 || p.mh > 32767) return false;   // Win16
   if (!(p.fill == p.fill)) return false;       // NaN fill has no order
@@ -127,25 +128,25 @@ inline hipError_t launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
 
 using Kernel = void (*)(ScatterArgs, const ScatterTables*);
 
-Kernel pick_kernel(bool is_max, bool fast, bool has_valid, bool has_value, bool vec4, bool lean) {
+Kernel pick_kernel(int red, bool fast, bool has_valid, bool has_value, bool vec4, bool lean) {
 #define DM_K(M, F, V, S) {k_window_scatter<M, F, V, S, 1, false>, k_window_scatter<M, F, V, S, 4, false>}
-  // [is_max][fast][has_valid][has_value][vec4]
-  static const Kernel table[2][2][2][2][2] = {
-      {{{DM_K(false, false, false, false), DM_K(false, false, false, true)},
-        {DM_K(false, false, true, false), DM_K(false, false, true, true)}},
-       {{DM_K(false, true, false, false), DM_K(false, true, false, true)},
-        {DM_K(false, true, true, false), DM_K(false, true, true, true)}}},
-      {{{DM_K(true, false, false, false), DM_K(true, false, false, true)},
-        {DM_K(true, false, true, false), DM_K(true, false, true, true)}},
-       {{DM_K(true, true, false, false), DM_K(true, true, false, true)},
-        {DM_K(true, true, true, false), DM_K(true, true, true, true)}}}};
+#define DM_RED(M)                                                                  \
+      {{{DM_K(M, false, false, false), DM_K(M, false, false, true)},                \
+        {DM_K(M, false, true, false), DM_K(M, false, true, true)}},                 \
+       {{DM_K(M, true, false, false), DM_K(M, true, false, true)},                  \
+        {DM_K(M, true, true, false), DM_K(M, true, true, true)}}}
+  // [kMin | kMax | kSum][fast][has_valid][has_value][vec4]
+  static const Kernel table[3][2][2][2][2] = {DM_RED(kMin), DM_RED(kMax), DM_RED(kSum)};
+#undef DM_RED
 #undef DM_K
-  static const Kernel lean_table[2][2] = {
-      {k_window_scatter<false, true, false, false, 4, true>,
-       k_window_scatter<false, true, false, true, 4, true>},
-      {k_window_scatter<true, true, false, false, 4, true>,
-       k_window_scatter<true, true, false, true, 4, true>}};
-  return lean ? lean_table[is_max][has_value] : table[is_max][fast][has_valid][has_value][vec4];
+  static const Kernel lean_table[3][2] = {
+      {k_window_scatter<kMin, true, false, false, 4, true>,
+       k_window_scatter<kMin, true, false, true, 4, true>},
+      {k_window_scatter<kMax, true, false, false, 4, true>,
+       k_window_scatter<kMax, true, false, true, 4, true>},
+      {k_window_scatter<kSum, true, false, false, 4, true>,
+       k_window_scatter<kSum, true, false, true, 4, true>}};
+  return lean ? lean_table[red][has_value] : table[red][fast][has_valid][has_value][vec4];
 }
 
 // One pass: scatter `value` (or the heights when NULL) of channels [0, oc_total)
@@ -154,7 +155,7 @@ Kernel pick_kernel(bool is_max, bool fast, bool has_valid, bool has_value, bool 
 // group's slabs are reduced straight into the (oc_total, mh, mw) fused map.
 hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
                        const float* depth, const float* value, const uint8_t* valid, float* out,
-                       uint8_t* mask, int oc_total, float fill, bool is_max, size_t slab_bytes,
+                       uint8_t* mask, int oc_total, float fill, int red, size_t slab_bytes,
                        hipStream_t s, float* fused = nullptr, uint8_t* fused_mask = nullptr,
                        int accumulate = 0) {
   ScatterArgs sa;
@@ -188,7 +189,8 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
   // lean variant: both depth bounds finite, no height truncation, no border, no valid map
   const bool lean = st.fast && vec4 && !has_valid && p.has_dmin && p.has_dmax &&
                     isfinite(p.dmin) && isfinite(p.dmax) && !p.has_hmax && p.clip_border <= 0;
-  const Kernel kfn = pick_kernel(is_max, st.fast, has_valid, has_value, vec4, lean);
+  const bool is_max = red == kMax;             // (the fuse kernels: max / min only)
+  const Kernel kfn = pick_kernel(red, st.fast, has_valid, has_value, vec4, lean);
   hipError_t e = hipSuccess;
   {   // raise the dynamic-LDS limit once per kernel variant and device
     static thread_local const void* done[64][8] = {};
@@ -244,12 +246,14 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
         ma.slabs = slabs; ma.out = out; ma.mask = mask;
         if (st.nparts >= kTiledMergeParts) {
           const dim3 g((unsigned)st.max_tiles, nb * oc);
-          e = is_max ? launch(k_window_merge_tiled<true>, g, dim3(kMergeThreads), 0, s, ma)
-                     : launch(k_window_merge_tiled<false>, g, dim3(kMergeThreads), 0, s, ma);
+          e = red == kMax   ? launch(k_window_merge_tiled<kMax>, g, dim3(kMergeThreads), 0, s, ma)
+              : red == kMin ? launch(k_window_merge_tiled<kMin>, g, dim3(kMergeThreads), 0, s, ma)
+                            : launch(k_window_merge_tiled<kSum>, g, dim3(kMergeThreads), 0, s, ma);
         } else {
           const dim3 g((unsigned)((st.max_union / 4 + kMergeThreads - 1) / kMergeThreads), nb * oc);
-          e = is_max ? launch(k_window_merge<true>, g, dim3(kMergeThreads), 0, s, ma)
-                     : launch(k_window_merge<false>, g, dim3(kMergeThreads), 0, s, ma);
+          e = red == kMax   ? launch(k_window_merge<kMax>, g, dim3(kMergeThreads), 0, s, ma)
+              : red == kMin ? launch(k_window_merge<kMin>, g, dim3(kMergeThreads), 0, s, ma)
+                            : launch(k_window_merge<kSum>, g, dim3(kMergeThreads), 0, s, ma);
         }
         if (e != hipSuccess) return e;
       }
@@ -694,7 +698,8 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
   float* slabs = reinterpret_cast<float*>(base + st.geom_bytes);
 
   const bool is_max = p.reduction == DM_REDUCE_MAX;
-  e = window_pass(p, st, slabs, depth, value, valid, out, mask, oc_total, p.fill, is_max,
+  const int red = p.reduction == DM_REDUCE_MAX ? kMax : p.reduction == DM_REDUCE_MIN ? kMin : kSum;
+  e = window_pass(p, st, slabs, depth, value, valid, out, mask, oc_total, p.fill, red,
                   slab_bytes, s);
   if (e != hipSuccess) return e;
   if (height && value) {      // maps.py:332-350: second projection, NINF fill, max
@@ -702,7 +707,7 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     const size_t hm = (size_t)p.B * p.dc * p.mh * p.mw;
     if (slab_bytes < hm + (size_t)p.B * st.nparts * st.slab_stride * 4) return hipErrorNotSupported;
     uint8_t* scratch_mask = base + ws_bytes - hm;
-    e = window_pass(p, st, slabs, depth, nullptr, valid, height, scratch_mask, p.dc, -INFINITY, true,
+    e = window_pass(p, st, slabs, depth, nullptr, valid, height, scratch_mask, p.dc, -INFINITY, kMax,
                     slab_bytes - hm, s);
     if (e != hipSuccess) return e;
   }
@@ -751,7 +756,7 @@ hipError_t run_window_fused(const dm_params& p, const dm_frame* frames_host, con
   if (e != hipSuccess) return e;
   return window_pass(p, st, reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + st.geom_bytes),
                      depth, value, valid, nullptr, nullptr,
-                     p.vc ? p.vc : p.dc, p.fill, p.reduction == DM_REDUCE_MAX, slab_bytes, s, out,
+                     p.vc ? p.vc : p.dc, p.fill, p.reduction == DM_REDUCE_MAX ? kMax : kMin, slab_bytes, s, out,
                      mask, accumulate);
 }
 

@@ -77,12 +77,23 @@ __device__ inline void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Reductions of the scatter and merge kernels.  kMin / kMax have the values of false / true
+// (the batch-fuse kernels, max / min only, keep a bool).  kSum: ds_add_f32 into windows that
+// start at 0, the fill value added once by the merge -- torch_scatter's "reduce into out";
+// order dependent in float32, like torch_scatter's own GPU path (tolerance 1e-5).
+constexpr int kMin = 0, kMax = 1, kSum = 2;
+
 // ds_max_f32 / ds_min_f32: "store if new > old" -- torch_scatter's rule; a NaN
 // operand never replaces a number.
-template <bool IS_MAX>
+template <int RED>
 __device__ inline void lds_reduce(float* cell, float v) {
-  if (IS_MAX) __hip_atomic_fetch_max(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  else __hip_atomic_fetch_min(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (RED == kMax) __hip_atomic_fetch_max(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else if (RED == kMin) __hip_atomic_fetch_min(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_fetch_add(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int RED>
+__device__ inline float combine(float a, float b) {
+  return RED == kMax ? fmaxf(a, b) : RED == kMin ? fminf(a, b) : a + b;
 }
 
 // FAST: every frame's rotations have the exact 0/1 pattern of rotate([1,0,0],.)
@@ -94,7 +105,7 @@ __device__ inline void lds_reduce(float* cell, float v) {
 //       (no border clip, no valid map): a non-finite or out-of-range pixel is then
 //       already rejected by the two depth compares, so the ordered-compare and the
 //       height compare are dropped.  (Pipeline-tail rows are poisoned through z.)
-template <bool IS_MAX, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC, bool LEAN>
+template <int RED, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC, bool LEAN>
 __global__ void __launch_bounds__(kScatterThreads)
 k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   const ScatterTables& t = *tables;            // this launch's chunk of frames
@@ -269,6 +280,10 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   const unsigned dummy = (unsigned)area + (threadIdx.x & 63u);   // 64 scratch cells after the window
   float band_lo = a.dmin, band_hi = a.dmax;    // this part's depth band (wave-uniform)
   if (a.parts.pd > 1) band_bounds(a.dmin, a.dmax, a.parts.pd, pdk, band_lo, band_hi);
+  // neighbouring bands share their boundary value: harmless for max / min, counted twice by
+  // a sum, which therefore takes every band but the last half open
+  const bool last_band = pdk == a.parts.pd - 1;
+  const float lds_init = RED == kSum ? 0.0f : a.fill;
 
   {
     for (int g = gx; g < nx; g += ntx) {       // one trip unless the strip is wider than the block
@@ -297,6 +312,9 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u) {
           int rr = r + u * rows_per_iter;
+          // (a sum counts every pixel once: rows past the part and the idle threads of a
+          // block whose width does not divide 1024 must not repeat a row)
+          const bool own_row = RED != kSum || (rr < r1 && gy < rows_per_iter);
           rr = rr < r1 ? rr : r1 - 1;                            // tail: repeat the last row
           float yr = (float)rr;
           yr = a.flip_h ? a.Hm1 - yr : yr;                       // maps.py:670-671
@@ -377,7 +395,8 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
             // maps.py:537-544, 286-288, 1150-1158
             const unsigned ux = (unsigned)(floor_to_int(xf) - w.x0);
             const unsigned uz = (unsigned)(floor_to_int(zf) - w.z0);
-            ok[k] = ux < (unsigned)w.w && uz < (unsigned)w.h && zz <= band_hi && zz >= band_lo;
+            ok[k] = ux < (unsigned)w.w && uz < (unsigned)w.h && zz >= band_lo &&
+                    (RED == kSum && !last_band ? zz < band_hi : zz <= band_hi) && own_row;
             if (!LEAN) ok[k] = ok[k] && !__builtin_isunordered(xf, zf) && h1 <= a.hmax;
             if (!FAST && !HAS_VALUE) ok[k] = ok[k] && (h2 == h2);
             const float sval = HAS_VALUE ? sv[u][k] : h2;
@@ -400,13 +419,17 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
 #pragma unroll
             for (int k = 0; k + 1 < VEC; ++k) {
               const bool same = li[k] == li[k + 1];
-              const float m = IS_MAX ? fmaxf(hv[k], hv[k + 1]) : fminf(hv[k], hv[k + 1]);
+              const float m = combine<RED>(hv[k], hv[k + 1]);
               hv[k + 1] = same ? m : hv[k + 1];
               li[k] = same ? dummy : li[k];
             }
           }
 #pragma unroll
-          for (int k = 0; k < VEC; ++k) lds_reduce<IS_MAX>(lds + li[k], hv[k]);
+          for (int k = 0; k < VEC; ++k) {
+            // ds_add_f32 runs at 206 G/s on MI355X (ds_max_f32: 4 850 G/s, tools/microbench):
+            // a sum does not pay for the lanes of rejected pixels, it masks them off
+            if (RED != kSum || li[k] != dummy) lds_reduce<RED>(lds + li[k], hv[k]);
+          }
         }
       };
       const int niter = (r1 - r0 + step - 1) / step;             // wave-uniform
@@ -423,7 +446,7 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
         // the LDS window is initialised while the first depth rows are in flight
         if (!lds_ready) {                      // wave-uniform, first trip only
           for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
-            *reinterpret_cast<float4*>(lds + i) = make_float4(a.fill, a.fill, a.fill, a.fill);
+            *reinterpret_cast<float4*>(lds + i) = make_float4(lds_init, lds_init, lds_init, lds_init);
           lds_barrier();
           lds_ready = true;
         }
@@ -495,7 +518,7 @@ constexpr int kMergeThreads = 256;
 // Writes the union window U of every (frame, channel): max/min over the slabs covering
 // each cell, fill where none does.  One float4 group per thread, row-major inside U, so
 // a wave's store covers up to 1 KiB (map) / 256 B (mask) contiguously.
-template <bool IS_MAX>
+template <int RED>
 __global__ void __launch_bounds__(kMergeThreads)
 k_window_merge(MergeArgs a) {
   const int fcl = blockIdx.y;                  // (frame in chunk) * oc + channel of the group
@@ -521,10 +544,10 @@ k_window_merge(MergeArgs a) {
     if (ux >= (unsigned)w.w || uz >= (unsigned)w.h) continue;
     const float* slab = a.slabs + ((size_t)fc * a.nparts + p) * a.slab_stride;
     const float4 s = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
-    acc.x = IS_MAX ? fmaxf(acc.x, s.x) : fminf(acc.x, s.x);
-    acc.y = IS_MAX ? fmaxf(acc.y, s.y) : fminf(acc.y, s.y);
-    acc.z = IS_MAX ? fmaxf(acc.z, s.z) : fminf(acc.z, s.z);
-    acc.w = IS_MAX ? fmaxf(acc.w, s.w) : fminf(acc.w, s.w);
+    acc.x = combine<RED>(acc.x, s.x);
+    acc.y = combine<RED>(acc.y, s.y);
+    acc.z = combine<RED>(acc.z, s.z);
+    acc.w = combine<RED>(acc.w, s.w);
   }
   const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw + x;
   *reinterpret_cast<float4*>(a.out + cell) = acc;
@@ -543,7 +566,7 @@ constexpr int kTileGroups = 16, kTileRows = 16;
 constexpr int kTiledMergeParts = 16;      // frames of at least this many parts take the tiled merge
 static_assert(kTileGroups * kTileRows == kMergeThreads && kMaxParts <= kMergeThreads, "one test per thread");
 
-template <bool IS_MAX>
+template <int RED>
 __global__ void __launch_bounds__(kMergeThreads)
 k_window_merge_tiled(MergeArgs a) {
   __shared__ Win16 lwin[kMaxParts];
@@ -602,10 +625,10 @@ k_window_merge_tiled(MergeArgs a) {
     if (ux >= (unsigned)w.w || uz >= (unsigned)w.h) continue;
     const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)lpart[j] * a.slab_stride +
                                                      (size_t)uz * w.w + ux);
-    acc.x = IS_MAX ? fmaxf(acc.x, v.x) : fminf(acc.x, v.x);
-    acc.y = IS_MAX ? fmaxf(acc.y, v.y) : fminf(acc.y, v.y);
-    acc.z = IS_MAX ? fmaxf(acc.z, v.z) : fminf(acc.z, v.z);
-    acc.w = IS_MAX ? fmaxf(acc.w, v.w) : fminf(acc.w, v.w);
+    acc.x = combine<RED>(acc.x, v.x);
+    acc.y = combine<RED>(acc.y, v.y);
+    acc.z = combine<RED>(acc.z, v.z);
+    acc.w = combine<RED>(acc.w, v.w);
   }
   const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw + x;
   *reinterpret_cast<float4*>(a.out + cell) = acc;

@@ -594,3 +594,57 @@ def test_odd_map_widths_stay_on_the_window_path(dmap, oracle, case):
     np.testing.assert_array_equal(t.cpu().numpy(), want[0])
     np.testing.assert_array_equal(f.cpu().numpy(), want[0].max(axis=0))
     np.testing.assert_array_equal(fm.cpu().numpy(), want[1].any(axis=0))
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=3, H=96, W=128, mh=128, mw=128),
+    dict(B=2, H=50, W=66, mh=64, mw=64),                               # scalar loads, ragged rows
+    dict(B=2, H=100, W=160, mh=128, mw=128),                           # strips whose width does not divide 1024
+    dict(B=5, H=37, W=96, mh=96, mw=160, clip_border=3, valid=True),   # tail rows, border, valid map
+    dict(B=2, H=120, W=160, mh=512, mw=512, res=0.0125, force_bands=True),   # depth bands: shared bounds
+    dict(B=2, H=96, W=128, mh=97, mw=131),                             # odd map width: padded route
+    dict(B=70, H=48, W=64, mh=128, mw=128),                            # two chunks of frames
+])
+def test_sum_reduction_on_the_window_path(dmap, oracle, case):
+  """reduction='sum' in LDS windows (ds_add_f32, windows start at 0, fill added once by the merge).
+  A sum counts every pixel exactly once -- unlike max / min nothing may be projected twice
+  (tail rows, idle threads, depth-band boundaries).  One-hot values make the sums small integers,
+  exact in float32 whatever the order: those must be bit-equal to the oracle."""
+  from dungeon_maps_amd import _native
+  lib = _native.lib()
+  c = dict(case)
+  B, H, W, mh, mw = (c.pop(k) for k in ("B", "H", "W", "mh", "mw"))
+  use_valid, force_bands = c.pop("valid", False), c.pop("force_bands", False)
+  res = c.pop("res", 0.05)
+  rng = np.random.default_rng(31)
+  depth, pose = _synthetic(B, H, W, seed=4242)
+  depth.reshape(-1)[rng.integers(0, depth.size, 200)] = rng.choice(
+      np.array([0.15, 5.05, 1.375, 2.6, 3.825], np.float32), 200)       # on the (band) bounds
+  labels = rng.integers(0, 3, size=(B, H, W))
+  onehot = np.eye(3, dtype=np.float32)[labels].transpose(0, 3, 1, 2).copy()
+  valid = (rng.uniform(size=(B, 1, H, W)) > 0.3) if use_valid else None
+  cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+             cam_height=0.88, width_offset=mw / 2., height_offset=mh / 2., map_res=res,
+             map_width=mw, map_height=mh, trunc_depth_min=0.15, trunc_depth_max=5.05,
+             to_global=True, fill_value=0.0, reduction="sum")
+  cfg.update(c)
+  lib.dm_debug_force_bands(1 if force_bands else 0)
+  try:
+    counts = _run(dmap, cfg, depth, value=onehot, valid=valid, get_height_map=True, cam_pose=pose)
+    split = (ctypes.c_int32 * 4)()
+    lib.dm_debug_last_split(split)
+    heights = _run(dmap, dict(cfg, fill_value=1.5), depth, valid=valid, cam_pose=pose)
+  finally:
+    lib.dm_debug_force_bands(0)
+  assert split[0] > 0, "took the generic path"
+  if force_bands:
+    assert split[2] > 1, list(split)
+  kw = dict(_oracle_kwargs(oracle, cfg), cam_pose=pose)
+  want = oracle.orth_project(depth, value_map=onehot, valid_map=valid, get_height_map=True, **kw)
+  np.testing.assert_array_equal(counts[0], want[0])            # point counts per class: exact
+  np.testing.assert_array_equal(counts[1], want[1])
+  np.testing.assert_array_equal(counts[2], np.ascontiguousarray(want[2]))
+  kw["fill_value"] = 1.5
+  want_h = oracle.orth_project(depth, valid_map=valid, **kw)   # sums of heights on top of a fill
+  np.testing.assert_allclose(heights[0], want_h[0], rtol=1e-5, atol=1e-5)
+  assert (heights[1] != want_h[1]).mean() < 1e-4

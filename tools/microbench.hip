@@ -37,6 +37,20 @@ __global__ void __launch_bounds__(1024) k_lds_fmax(float* out, int iters) {
   if (threadIdx.x == 0) out[blockIdx.x] = ldsf[0] + ldsf[CELLS - 1];
 }
 
+template <int CELLS>
+__global__ void __launch_bounds__(1024) k_lds_fadd(float* out, int iters) {
+  extern __shared__ float ldsf[];
+  for (int i = threadIdx.x; i < CELLS; i += blockDim.x) ldsf[i] = 0;
+  __syncthreads();
+  unsigned s = blockIdx.x * 7919u + threadIdx.x * 104729u + 1;
+  for (int i = 0; i < iters; ++i) {
+    unsigned r = rng(s);
+    __hip_atomic_fetch_add(&ldsf[r % CELLS], (float)(r & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = ldsf[0] + ldsf[CELLS - 1];
+}
+
 template <int SCOPE>
 __global__ void __launch_bounds__(256) k_glb_max(unsigned* canvas, unsigned cells_per_region, int regions, int iters) {
   unsigned s = blockIdx.x * 7919u + threadIdx.x * 104729u + 1;
@@ -203,6 +217,9 @@ int main() {
     CK(hipFuncSetAttribute((const void*)k_lds_fmax<32768>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
     { float ms = time_ms([&] { hipLaunchKernelGGL(k_lds_fmax<32768>, dim3(256), dim3(1024), 32768 * 4, 0, (float*)dout, iters); });
       printf("lds_fmax(f32) 128KB blocks=256: %.3f ms  %.1f Gatomic/s\n", ms, 256.0 * 1024 * iters / ms / 1e6); }
+    CK(hipFuncSetAttribute((const void*)k_lds_fadd<32768>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+    { float ms = time_ms([&] { hipLaunchKernelGGL(k_lds_fadd<32768>, dim3(256), dim3(1024), 32768 * 4, 0, (float*)dout, iters); });
+      printf("lds_fadd(f32) 128KB blocks=256: %.3f ms  %.1f Gatomic/s\n", ms, 256.0 * 1024 * iters / ms / 1e6); }
     CK(hipFuncSetAttribute((const void*)k_lds_max<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 4));
     float ms = time_ms([&] { hipLaunchKernelGGL(k_lds_max<8192>, dim3(1024), dim3(1024), 8192 * 4, 0, dout, iters); });
     printf("lds_max 32KB   blocks=1024: %.3f ms  %.1f Gatomic/s\n", ms, 1024.0 * 1024 * iters / ms / 1e6);

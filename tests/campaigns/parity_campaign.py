@@ -15,6 +15,8 @@ def one(seed):
   H, W = [(48, 64), (60, 80), (96, 128), (50, 70), (120, 160), (240, 320)][int(rng.integers(6))]
   if B * H * W > 3_000_000:
     B = max(1, 3_000_000 // (H * W))
+  if SUM and B * 3 * H * W > 6_000_000:      # always one-hot counts (exact), never height sums
+    B = max(1, 6_000_000 // (3 * H * W))
   sizes = [(64, 64), (96, 128), (128, 96), (160, 160), (256, 256), (300, 200)]
   if ODD:          # map widths that are not multiples of 4: padded maps + copy-out (dm_api.hip)
     sizes = [(65, 63), (97, 131), (128, 241), (255, 255), (301, 199), (100, 102)]
@@ -57,9 +59,14 @@ def one(seed):
              reduction="max" if is_max else "min")
   valid = (rng.uniform(size=(B, 1, H, W)) > 0.1) if rng.integers(3) == 0 else None
   value = None
+  if SUM:       # point counts per class: small integers, exact in float32 whatever the order
+    cfg["reduction"] = "sum"
+    cfg["fill_value"] = float(rng.choice([0.0, 1.0, 5.0]))
   C = int(rng.choice([0, 0, 3, 9])) if SEMANTIC else 0
+  if SUM:
+    C = 3
   if C and B * C * H * W <= 6_000_000:      # value maps: one-hot labels or random reals
-    if rng.integers(2):
+    if SUM or rng.integers(2):
       value = np.eye(C, dtype=np.float32)[rng.integers(0, C, size=(B, H, W))].transpose(0, 3, 1, 2).copy()
     else:
       value = rng.normal(size=(B, C, H, W)).astype(np.float32)
@@ -79,11 +86,26 @@ def one(seed):
   got = [o.cpu().numpy() for o in outs]
   bad_m = int((got[1] != want[1]).sum())
   bad_v = 0
+  if os.environ.get("DM_CAMPAIGN_VERBOSE"):
+    d = ~((got[0] == want[0]) | (np.isnan(got[0]) & np.isnan(want[0])))
+    idx = np.argwhere(d)[:12]
+    print("cfg", {k: v for k, v in cfg.items() if k not in ("cam_pitch", "cam_height")})
+    for i in idx:
+      print("  cell", tuple(i), "got", got[0][tuple(i)], "want", want[0][tuple(i)])
+    print("  differing cells", int(d.sum()), "per frame", d.sum(axis=(1, 2, 3))[:16])
+  exact = not (SUM and value is None)     # sums of heights are order dependent in float32
   for a, b in ((got[0], want[0]),) + (((got[2], np.ascontiguousarray(want[2])),) if get_h else ()):
-    bad_v += int((~((a == b) | (np.isnan(a) & np.isnan(b)))).sum())
+    if exact:
+      bad_v += int((~((a == b) | (np.isnan(a) & np.isnan(b)))).sum())
+    else:
+      bad_v += int((~(np.isclose(a, b, rtol=1e-5, atol=1e-5) | (np.isnan(a) & np.isnan(b)) |
+                      (a == b))).sum())
+  if not exact and bad_m <= 1e-4 * got[1].size:
+    bad_m = 0                               # a sum that lands on the fill value by rounding
   return bad_m, bad_v, (B, H, W, mh, mw, res, C)
 
 ODD = os.environ.get("DM_CAMPAIGN_ODD", "0") != "0"      # odd map widths
+SUM = os.environ.get("DM_CAMPAIGN_SUM", "0") != "0"      # reduction='sum' of one-hot values
 FINE = os.environ.get("DM_CAMPAIGN_FINE", "0") != "0"    # fine map_res: depth bands (forced)
 STATS = {"banded": 0, "generic": 0}
 from dungeon_maps_amd import _native

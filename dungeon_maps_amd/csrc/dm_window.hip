@@ -52,8 +52,7 @@ namespace dm {
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 bool window_path_supported(const dm_params& p) {
-  if (p.reduction != DM_REDUCE_MAX && p.reduction != DM_REDUCE_MIN && p.reduction != DM_REDUCE_SUM)
-    return false;                               // (mean and prod: generic path)
+  if (p.reduction == DM_REDUCE_PROD) return false;      // generic path
   if (p.mw % 4 != 0) return false;
   if (p.mw > 32767 || p.mh > 32767) return false;   // Win16
   if (!(p.fill == p.fill)) return false;       // NaN fill has no order
@@ -80,7 +79,7 @@ size_t window_workspace_bytes(const dm_params& p) {
   // slabs of one channel group (+ the scratch mask of the height pass).  Sized for up
   // to 4x the default number of parts (run_window splits further only when windows do
   // not fit in LDS, and falls back to the generic path if the workspace cannot hold that).
-  size_t cap = (size_t)p.mh * p.mw;
+  size_t cap = (size_t)p.mh * p.mw * (p.reduction == DM_REDUCE_MEAN ? 2 : 1);
   if (cap > kMaxLdsBytes / 4) cap = kMaxLdsBytes / 4;
   const Parts d = choose_parts(p, 1);
   size_t np = (size_t)d.pc * d.pr * 4;
@@ -135,17 +134,19 @@ Kernel pick_kernel(int red, bool fast, bool has_valid, bool has_value, bool vec4
         {DM_K(M, false, true, false), DM_K(M, false, true, true)}},                 \
        {{DM_K(M, true, false, false), DM_K(M, true, false, true)},                  \
         {DM_K(M, true, true, false), DM_K(M, true, true, true)}}}
-  // [kMin | kMax | kSum][fast][has_valid][has_value][vec4]
-  static const Kernel table[3][2][2][2][2] = {DM_RED(kMin), DM_RED(kMax), DM_RED(kSum)};
+  // [kMin | kMax | kSum | kMean][fast][has_valid][has_value][vec4]
+  static const Kernel table[4][2][2][2][2] = {DM_RED(kMin), DM_RED(kMax), DM_RED(kSum), DM_RED(kMean)};
 #undef DM_RED
 #undef DM_K
-  static const Kernel lean_table[3][2] = {
+  static const Kernel lean_table[4][2] = {
       {k_window_scatter<kMin, true, false, false, 4, true>,
        k_window_scatter<kMin, true, false, true, 4, true>},
       {k_window_scatter<kMax, true, false, false, 4, true>,
        k_window_scatter<kMax, true, false, true, 4, true>},
       {k_window_scatter<kSum, true, false, false, 4, true>,
-       k_window_scatter<kSum, true, false, true, 4, true>}};
+       k_window_scatter<kSum, true, false, true, 4, true>},
+      {k_window_scatter<kMean, true, false, false, 4, true>,
+       k_window_scatter<kMean, true, false, true, 4, true>}};
   return lean ? lean_table[red][has_value] : table[red][fast][has_valid][has_value][vec4];
 }
 
@@ -248,12 +249,14 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
           const dim3 g((unsigned)st.max_tiles, nb * oc);
           e = red == kMax   ? launch(k_window_merge_tiled<kMax>, g, dim3(kMergeThreads), 0, s, ma)
               : red == kMin ? launch(k_window_merge_tiled<kMin>, g, dim3(kMergeThreads), 0, s, ma)
-                            : launch(k_window_merge_tiled<kSum>, g, dim3(kMergeThreads), 0, s, ma);
+              : red == kSum ? launch(k_window_merge_tiled<kSum>, g, dim3(kMergeThreads), 0, s, ma)
+                            : launch(k_window_merge_tiled<kMean>, g, dim3(kMergeThreads), 0, s, ma);
         } else {
           const dim3 g((unsigned)((st.max_union / 4 + kMergeThreads - 1) / kMergeThreads), nb * oc);
           e = red == kMax   ? launch(k_window_merge<kMax>, g, dim3(kMergeThreads), 0, s, ma)
               : red == kMin ? launch(k_window_merge<kMin>, g, dim3(kMergeThreads), 0, s, ma)
-                            : launch(k_window_merge<kSum>, g, dim3(kMergeThreads), 0, s, ma);
+              : red == kSum ? launch(k_window_merge<kSum>, g, dim3(kMergeThreads), 0, s, ma)
+                            : launch(k_window_merge<kMean>, g, dim3(kMergeThreads), 0, s, ma);
         }
         if (e != hipSuccess) return e;
       }
@@ -447,6 +450,7 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
   // more, narrower parts until every window fits in LDS; when splitting the image does not
   // get there (a long thin wedge: fine resolution, long range) the depth range is split too
   int max_area = 0;
+  const int planes = p.reduction == DM_REDUCE_MEAN ? 2 : 1;     // mean: sum window + count window
   const bool can_band = p.has_dmin && p.has_dmax && p.dmin >= 0.0f && p.dmax > p.dmin &&
                         isfinite(p.dmax);
   thread_local std::vector<PartSlopes> slopes;
@@ -503,7 +507,7 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
     if (verbose)
       fprintf(stderr, "[dm] pd=%d parts=%dx%d nparts=%d max_area=%d max_union=%d\n", pd, parts.pc,
               parts.pr, st.nparts, max_area, st.max_union);
-    return (size_t)max_area * 4 + 64 * 4 + 16 <= (size_t)kMaxLdsBytes;
+    return (size_t)max_area * 4 * planes + 64 * 4 + 16 <= (size_t)kMaxLdsBytes;
   };
   // the split that worked for the previous call of the same shape is tried first (the answer
   // moves with the poses only): one evaluation per call in the steady state
@@ -543,7 +547,8 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
       if (same_shape && c.pc == last.parts.pc && c.pr == last.parts.pr && c.pd == last.parts.pd) continue;
       if (evaluate(c)) {
         const size_t geom = geometry_bytes(p.B, st.nparts);
-        fits = c.pd == 1 || g_force_bands || banded_split_pays(p, c, st.nparts, max_area, ws_bytes > geom ? ws_bytes - geom : 0);
+        fits = c.pd == 1 || g_force_bands ||
+               banded_split_pays(p, c, st.nparts, max_area * planes, ws_bytes > geom ? ws_bytes - geom : 0);
         break;            // splits of more parts cost more still
       }
     }
@@ -556,7 +561,7 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
     return hipErrorNotSupported;
   }
   g_last_split[0] = st.parts.pc; g_last_split[1] = st.parts.pr; g_last_split[2] = st.parts.pd;
-  st.slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 4);
+  st.slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 4) * planes;
   st.geom_bytes = geometry_bytes(p.B, st.nparts);
   if (ws_bytes < st.geom_bytes + (size_t)p.B * st.nparts * st.slab_stride * 4)
     return hipErrorOutOfMemory;       // run_window then takes the frames in two halves
@@ -698,7 +703,10 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
   float* slabs = reinterpret_cast<float*>(base + st.geom_bytes);
 
   const bool is_max = p.reduction == DM_REDUCE_MAX;
-  const int red = p.reduction == DM_REDUCE_MAX ? kMax : p.reduction == DM_REDUCE_MIN ? kMin : kSum;
+  const int red = p.reduction == DM_REDUCE_MAX   ? kMax
+                  : p.reduction == DM_REDUCE_MIN ? kMin
+                  : p.reduction == DM_REDUCE_SUM ? kSum
+                                                 : kMean;
   e = window_pass(p, st, slabs, depth, value, valid, out, mask, oc_total, p.fill, red,
                   slab_bytes, s);
   if (e != hipSuccess) return e;

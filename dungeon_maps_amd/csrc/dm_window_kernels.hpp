@@ -81,7 +81,10 @@ __device__ inline void lds_barrier() {
 // (the batch-fuse kernels, max / min only, keep a bool).  kSum: ds_add_f32 into windows that
 // start at 0, the fill value added once by the merge -- torch_scatter's "reduce into out";
 // order dependent in float32, like torch_scatter's own GPU path (tolerance 1e-5).
-constexpr int kMin = 0, kMax = 1, kSum = 2;
+// kMean: a sum window followed by a count window (uint32, ds_add_u32) in LDS and in the slab;
+// the merge divides (fill + sum) by max(count, 1) -- torch_scatter's scatter_mean into `out`.
+constexpr int kMin = 0, kMax = 1, kSum = 2, kMean = 3;
+__host__ __device__ constexpr bool additive(int red) { return red == kSum || red == kMean; }
 
 // ds_max_f32 / ds_min_f32: "store if new > old" -- torch_scatter's rule; a NaN
 // operand never replaces a number.
@@ -277,13 +280,14 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
   DM_STAMP(1);
   bool lds_ready = false;
-  const unsigned dummy = (unsigned)area + (threadIdx.x & 63u);   // 64 scratch cells after the window
+  const unsigned dummy = (unsigned)(RED == kMean ? 2 * area : area) + (threadIdx.x & 63u);   // 64 scratch cells after the window(s)
   float band_lo = a.dmin, band_hi = a.dmax;    // this part's depth band (wave-uniform)
   if (a.parts.pd > 1) band_bounds(a.dmin, a.dmax, a.parts.pd, pdk, band_lo, band_hi);
   // neighbouring bands share their boundary value: harmless for max / min, counted twice by
   // a sum, which therefore takes every band but the last half open
   const bool last_band = pdk == a.parts.pd - 1;
-  const float lds_init = RED == kSum ? 0.0f : a.fill;
+  const float lds_init = additive(RED) ? 0.0f : a.fill;
+  const int cells = RED == kMean ? 2 * area : area;   // mean: sum window, then count window
 
   {
     for (int g = gx; g < nx; g += ntx) {       // one trip unless the strip is wider than the block
@@ -314,7 +318,7 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
           int rr = r + u * rows_per_iter;
           // (a sum counts every pixel once: rows past the part and the idle threads of a
           // block whose width does not divide 1024 must not repeat a row)
-          const bool own_row = RED != kSum || (rr < r1 && gy < rows_per_iter);
+          const bool own_row = !additive(RED) || (rr < r1 && gy < rows_per_iter);
           rr = rr < r1 ? rr : r1 - 1;                            // tail: repeat the last row
           float yr = (float)rr;
           yr = a.flip_h ? a.Hm1 - yr : yr;                       // maps.py:670-671
@@ -396,7 +400,7 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
             const unsigned ux = (unsigned)(floor_to_int(xf) - w.x0);
             const unsigned uz = (unsigned)(floor_to_int(zf) - w.z0);
             ok[k] = ux < (unsigned)w.w && uz < (unsigned)w.h && zz >= band_lo &&
-                    (RED == kSum && !last_band ? zz < band_hi : zz <= band_hi) && own_row;
+                    (additive(RED) && !last_band ? zz < band_hi : zz <= band_hi) && own_row;
             if (!LEAN) ok[k] = ok[k] && !__builtin_isunordered(xf, zf) && h1 <= a.hmax;
             if (!FAST && !HAS_VALUE) ok[k] = ok[k] && (h2 == h2);
             const float sval = HAS_VALUE ? sv[u][k] : h2;
@@ -415,7 +419,8 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
           // run of equal cells inside a thread is reduced in registers and only its last
           // pixel issues the atomic.  (Unconditionally the extra selects cost 2.6 us on
           // incoherent depth; behind the test 1 us.)
-          if (VEC == 4 && __builtin_amdgcn_ballot_w64(li[0] == li[VEC - 1] && li[0] != dummy) != 0) {
+          if (VEC == 4 && RED != kMean &&
+              __builtin_amdgcn_ballot_w64(li[0] == li[VEC - 1] && li[0] != dummy) != 0) {
 #pragma unroll
             for (int k = 0; k + 1 < VEC; ++k) {
               const bool same = li[k] == li[k + 1];
@@ -428,7 +433,12 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
           for (int k = 0; k < VEC; ++k) {
             // ds_add_f32 runs at 206 G/s on MI355X (ds_max_f32: 4 850 G/s, tools/microbench):
             // a sum does not pay for the lanes of rejected pixels, it masks them off
-            if (RED != kSum || li[k] != dummy) lds_reduce<RED>(lds + li[k], hv[k]);
+            if (!additive(RED) || li[k] != dummy) {
+              lds_reduce<RED == kMean ? kSum : RED>(lds + li[k], hv[k]);
+              if (RED == kMean)
+                __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(lds + area) + li[k], 1u,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
           }
         }
       };
@@ -445,7 +455,7 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
         DM_STAMP(2);
         // the LDS window is initialised while the first depth rows are in flight
         if (!lds_ready) {                      // wave-uniform, first trip only
-          for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
+          for (int i = threadIdx.x * 4; i < cells; i += kScatterThreads * 4)
             *reinterpret_cast<float4*>(lds + i) = make_float4(lds_init, lds_init, lds_init, lds_init);
           lds_barrier();
           lds_ready = true;
@@ -478,7 +488,7 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   DM_STAMP(5);
   const int pid = (b * a.oc + chl) * nparts + part;      // slabs are per channel group
   float* slab = a.slabs + (size_t)pid * a.slab_stride;
-  for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4)
+  for (int i = threadIdx.x * 4; i < cells; i += kScatterThreads * 4)
     *reinterpret_cast<float4*>(slab + i) = *reinterpret_cast<const float4*>(lds + i);
   publish_geometry();
   DM_STAMP(6);
@@ -493,6 +503,15 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
 __device__ inline void signal_slot_free(uint32_t* signal, uint32_t ticket) {
   if (signal && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
     asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(signal), "v"(ticket));
+}
+
+// scatter_mean into `out` (utils.py:470-477 with torch_scatter's out= semantics): the fill value
+// takes part in the numerator, the count is clamped to 1.
+__device__ inline void mean_of(float4& acc, uint4 cnt) {
+  acc.x = acc.x / (float)(cnt.x < 1u ? 1u : cnt.x);
+  acc.y = acc.y / (float)(cnt.y < 1u ? 1u : cnt.y);
+  acc.z = acc.z / (float)(cnt.z < 1u ? 1u : cnt.z);
+  acc.w = acc.w / (float)(cnt.w < 1u ? 1u : cnt.w);
 }
 
 struct MergeArgs {
@@ -537,6 +556,7 @@ k_window_merge(MergeArgs a) {
   const int row = i / ug4;
   const int zb = U.z0 + row, x = U.x0 + ((i - row * ug4) << 2);
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+  uint4 cnt = make_uint4(0u, 0u, 0u, 0u);      // mean: points per cell
   for (int p = 0; p < a.nparts; ++p) {
     const Window w = widen(a.wins[bl * win_stride + p]);
     if (w.w == 0) continue;
@@ -544,11 +564,16 @@ k_window_merge(MergeArgs a) {
     if (ux >= (unsigned)w.w || uz >= (unsigned)w.h) continue;
     const float* slab = a.slabs + ((size_t)fc * a.nparts + p) * a.slab_stride;
     const float4 s = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
+    if (RED == kMean) {
+      const uint4 c = *reinterpret_cast<const uint4*>(slab + (size_t)w.w * w.h + (size_t)uz * w.w + ux);
+      cnt.x += c.x; cnt.y += c.y; cnt.z += c.z; cnt.w += c.w;
+    }
     acc.x = combine<RED>(acc.x, s.x);
     acc.y = combine<RED>(acc.y, s.y);
     acc.z = combine<RED>(acc.z, s.z);
     acc.w = combine<RED>(acc.w, s.w);
   }
+  if (RED == kMean) mean_of(acc, cnt);
   const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw + x;
   *reinterpret_cast<float4*>(a.out + cell) = acc;
   const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
@@ -618,18 +643,24 @@ k_window_merge_tiled(MergeArgs a) {
     return;
   }
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+  uint4 cnt = make_uint4(0u, 0u, 0u, 0u);      // mean: points per cell
   const float* slabs = a.slabs + (size_t)fc * a.nparts * a.slab_stride;
   for (int j = 0; j < n; ++j) {
     const Window w = widen(lwin[j]);
     const unsigned ux = (unsigned)(x - w.x0), uz = (unsigned)(zb - w.z0);
     if (ux >= (unsigned)w.w || uz >= (unsigned)w.h) continue;
-    const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)lpart[j] * a.slab_stride +
-                                                     (size_t)uz * w.w + ux);
+    const float* slab = slabs + (size_t)lpart[j] * a.slab_stride;
+    const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
+    if (RED == kMean) {
+      const uint4 c = *reinterpret_cast<const uint4*>(slab + (size_t)w.w * w.h + (size_t)uz * w.w + ux);
+      cnt.x += c.x; cnt.y += c.y; cnt.z += c.z; cnt.w += c.w;
+    }
     acc.x = combine<RED>(acc.x, v.x);
     acc.y = combine<RED>(acc.y, v.y);
     acc.z = combine<RED>(acc.z, v.z);
     acc.w = combine<RED>(acc.w, v.w);
   }
+  if (RED == kMean) mean_of(acc, cnt);
   const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw + x;
   *reinterpret_cast<float4*>(a.out + cell) = acc;
   const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |

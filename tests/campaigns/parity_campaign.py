@@ -60,7 +60,7 @@ def one(seed):
   valid = (rng.uniform(size=(B, 1, H, W)) > 0.1) if rng.integers(3) == 0 else None
   value = None
   if SUM:       # point counts per class: small integers, exact in float32 whatever the order
-    cfg["reduction"] = "sum"
+    cfg["reduction"] = "mean" if os.environ.get("DM_CAMPAIGN_SUM") == "mean" else "sum"
     cfg["fill_value"] = float(rng.choice([0.0, 1.0, 5.0]))
   C = int(rng.choice([0, 0, 3, 9])) if SEMANTIC else 0
   if SUM:

@@ -605,8 +605,10 @@ def test_odd_map_widths_stay_on_the_window_path(dmap, oracle, case):
     dict(B=2, H=96, W=128, mh=97, mw=131),                             # odd map width: padded route
     dict(B=70, H=48, W=64, mh=128, mw=128),                            # two chunks of frames
 ])
-def test_sum_reduction_on_the_window_path(dmap, oracle, case):
-  """reduction='sum' in LDS windows (ds_add_f32, windows start at 0, fill added once by the merge).
+@pytest.mark.parametrize("red", ["sum", "mean"])
+def test_sum_reduction_on_the_window_path(dmap, oracle, case, red):
+  """reduction='sum' / 'mean' in LDS windows (mean: a count window beside the sum window, the
+  merge divides (fill + sum) by max(count, 1)).  reduction='sum' in LDS windows (ds_add_f32, windows start at 0, fill added once by the merge).
   A sum counts every pixel exactly once -- unlike max / min nothing may be projected twice
   (tail rows, idle threads, depth-band boundaries).  One-hot values make the sums small integers,
   exact in float32 whatever the order: those must be bit-equal to the oracle."""
@@ -626,7 +628,7 @@ def test_sum_reduction_on_the_window_path(dmap, oracle, case):
   cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
              cam_height=0.88, width_offset=mw / 2., height_offset=mh / 2., map_res=res,
              map_width=mw, map_height=mh, trunc_depth_min=0.15, trunc_depth_max=5.05,
-             to_global=True, fill_value=0.0, reduction="sum")
+             to_global=True, fill_value=0.0, reduction=red)
   cfg.update(c)
   lib.dm_debug_force_bands(1 if force_bands else 0)
   try:

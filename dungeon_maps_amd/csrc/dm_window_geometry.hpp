@@ -211,8 +211,12 @@ __host__ PartSlopes part_slopes(const dm_params& p, int q0, int q1, int r0, int 
   return s;
 }
 
+// A part's reach in the map can be bounded when no depth is negative (a negative depth projects
+// behind the camera: a double cone): trunc_depth_min >= 0 is required, trunc_depth_max is not --
+// without it the part's rays are followed until they have left the map.
 __host__ bool frustum_bounded(const dm_params& p) {
-  return p.has_dmin && p.has_dmax && p.dmin >= 0.0f && p.dmax >= p.dmin && isfinite(p.dmax);
+  if (!p.has_dmin || !(p.dmin >= 0.0f)) return false;
+  return !p.has_dmax || p.dmax >= p.dmin;       // (dmax may be +inf)
 }
 
 __host__ Window part_window(const dm_params& p, const FrameAffine& fa, const PartSlopes& ps,
@@ -221,11 +225,35 @@ __host__ Window part_window(const dm_params& p, const FrameAffine& fa, const Par
   if (!bounded || !fa.finite) return Window{0, 0, p.mw, p.mh};
   double lo_x = INFINITY, hi_x = -INFINITY, lo_z = INFINITY, hi_z = -INFINITY;
   double poison = 0.0;                         // NaN as soon as one corner is not finite
-  const double zs[2] = {dlo, dhi};
+  const bool open_far = !p.has_dmax || !isfinite(dhi);
+  // Open far end: every pixel's cells lie on a ray from the camera's cell (xd, zd).  Inside the
+  // map such a cell is at most r_map away from it; the corner rays are followed to 2 r_map, which
+  // puts the chord between two of them beyond r_map as long as they span less than 120
+  // degrees (checked below: else the whole map).
+  double r_far = 0.0;
+  if (open_far) {
+    const double cx[2] = {0.0, (double)p.mw}, cz[2] = {0.0, (double)p.mh};
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) {
+        const double d = hypot(cx[i] - fa.xd, cz[j] - fa.zd);
+        if (d > r_far) r_far = d;
+      }
+    r_far = 2.0 * r_far + 4.0;
+  }
+  double dirx[4], dirz[4];
   for (int qi = 0; qi < 2; ++qi)
     for (int ri = 0; ri < 2; ++ri) {
       const double sx = fa.xa * ps.ax[qi] + fa.xb * ps.ay[ri] + fa.xc;
       const double sz = fa.za * ps.ax[qi] + fa.zb * ps.ay[ri] + fa.zc;
+      dirx[qi * 2 + ri] = sx; dirz[qi * 2 + ri] = sz;
+      double far = dhi;
+      if (open_far) {
+        const double len = hypot(sx, sz);
+        if (!(len > 1e-9)) return Window{0, 0, p.mw, p.mh};      // a ray straight down / up
+        far = r_far / len;
+        if (far < dlo) far = dlo;
+      }
+      const double zs[2] = {dlo, far};
       for (int zi = 0; zi < 2; ++zi) {
         const double xf = zs[zi] * sx + fa.xd, zf = zs[zi] * sz + fa.zd;
         lo_x = xf < lo_x ? xf : lo_x; hi_x = xf > hi_x ? xf : hi_x;
@@ -233,6 +261,14 @@ __host__ Window part_window(const dm_params& p, const FrameAffine& fa, const Par
         poison += xf * 0.0 + zf * 0.0;
       }
     }
+  if (open_far) {
+    for (int i = 0; i < 4; ++i)
+      for (int j = i + 1; j < 4; ++j) {
+        const double dot = dirx[i] * dirx[j] + dirz[i] * dirz[j];
+        const double norm = hypot(dirx[i], dirz[i]) * hypot(dirx[j], dirz[j]);
+        if (!(dot > -0.5 * norm)) return Window{0, 0, p.mw, p.mh};   // >= 120 degrees apart
+      }
+  }
   if (!(poison == 0.0)) return Window{0, 0, p.mw, p.mh};
   // cells are floor(v + 0.5); 2 cells of slack cover the float32 rounding of
   // the device arithmetic (observed error < 1e-3 cell)

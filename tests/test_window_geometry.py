@@ -30,7 +30,7 @@ def _band(dmin, dmax, pd, k):
   return (dmin if k == 0 else fma(k)), (dmax if k == pd - 1 else fma(k + 1))
 
 
-def _random_case(rng, fine):
+def _random_case(rng, fine, open_far=False):
   B = int(rng.integers(1, 5))
   H, W = [(48, 64), (60, 80), (96, 128), (50, 70), (120, 160)][int(rng.integers(5))]
   if fine:
@@ -40,6 +40,9 @@ def _random_case(rng, fine):
     mh, mw = [(64, 64), (96, 128), (128, 96), (256, 256), (300, 200)][int(rng.integers(5))]
     res = float(rng.choice([0.02, 0.03, 0.05, 0.08, 1.0 / 3]))
   depth = rng.uniform(0.05, 8.0, size=(B, 1, H, W)).astype(np.float32)
+  if open_far:      # no upper depth bound: far points up to where they leave any map
+    far = rng.integers(0, depth.size, depth.size // 4)
+    depth.reshape(-1)[far] = rng.uniform(8.0, 400.0, far.size).astype(np.float32)
   # the extremes of the depth range are where a bound would break first
   depth.reshape(-1)[rng.integers(0, depth.size, 64)] = rng.choice(
       np.array([0.0, 0.15, 0.5, 1.5, 2.5, 5.05, 7.0], np.float32), 64)
@@ -53,20 +56,20 @@ def _random_case(rng, fine):
              height_offset=float(mh / 2 + rng.uniform(-40, 40)),
              map_res=res, map_width=mw, map_height=mh,
              trunc_depth_min=float(rng.choice([0.0, 0.15, 0.5])),
-             trunc_depth_max=float(rng.choice([1.5, 2.5, 5.05, 7.0])),
+             trunc_depth_max=None if open_far else float(rng.choice([1.5, 2.5, 5.05, 7.0])),
              trunc_height_max=None if rng.integers(3) else float(rng.uniform(0.2, 1.2)),
              clip_border=int(rng.choice([0, 0, 3, 9])), to_global=bool(rng.integers(2)),
              flip_h=bool(rng.integers(4)), fill_value=-np.inf, reduction="max")
   return B, H, W, depth, pose, cfg
 
 
-@pytest.mark.parametrize("fine", [False, True])
-def test_every_valid_pixel_lands_inside_its_parts_window(oracle, fine):
+@pytest.mark.parametrize("fine,open_far", [(False, False), (True, False), (False, True), (True, True)])
+def test_every_valid_pixel_lands_inside_its_parts_window(oracle, fine, open_far):
   lib = _native.lib()
-  rng = np.random.default_rng(20240 + fine)
-  checked = banded = 0
+  rng = np.random.default_rng(20240 + fine + 2 * open_far)
+  checked = banded = smaller = 0
   for _ in range(150):
-    B, H, W, depth, pose, cfg = _random_case(rng, fine)
+    B, H, W, depth, pose, cfg = _random_case(rng, fine, open_far)
     kw = dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose)
     *_, dbg = oracle.orth_project(depth, debug=True, **kw)
     intr = oracle.camera_intrinsics(W, H, cfg["hfov"], cfg["vfov"])
@@ -76,7 +79,7 @@ def test_every_valid_pixel_lands_inside_its_parts_window(oracle, fine):
     xb = dbg["x_bin"].reshape(B, H, W); zb = dbg["z_bin"].reshape(B, H, W)
     ok = dbg["valid"].reshape(B, H, W)              # before the in-map test (maps.py:1150-1158)
     ok = ok & (xb >= 0) & (xb < cfg["map_width"]) & (zb >= 0) & (zb < cfg["map_height"])
-    for min_parts, pd in ((1, 1), (4, 1), (1, 2), (2, 4), (1, 8)):
+    for min_parts, pd in ((1, 1), (4, 1)) if open_far else ((1, 1), (4, 1), (1, 2), (2, 4), (1, 8)):
       parts = (ctypes.c_int32 * 5)()
       n = lib.dm_debug_windows(ctypes.byref(p), table.data_ptr(), min_parts, pd, parts, None, 0)
       assert n == parts[0] * parts[1] * parts[2] and parts[2] == pd
@@ -87,8 +90,11 @@ def test_every_valid_pixel_lands_inside_its_parts_window(oracle, fine):
       pc, pr, _, wp, hp = list(parts)
       assert pc * wp >= W and pr * hp >= H and wp % 4 == 0
       for k in range(pd):
-        lo, hi = _band(cfg["trunc_depth_min"], cfg["trunc_depth_max"], pd, k)
-        in_band = (depth[:, 0] >= lo) & (depth[:, 0] <= hi)
+        if open_far:
+          in_band = depth[:, 0] >= np.float32(cfg["trunc_depth_min"])
+        else:
+          lo, hi = _band(cfg["trunc_depth_min"], cfg["trunc_depth_max"], pd, k)
+          in_band = (depth[:, 0] >= lo) & (depth[:, 0] <= hi)
         for iy in range(pr):
           for ix in range(pc):
             rows = slice(iy * hp, min((iy + 1) * hp, H)); cols = slice(ix * wp, min((ix + 1) * wp, W))
@@ -99,10 +105,12 @@ def test_every_valid_pixel_lands_inside_its_parts_window(oracle, fine):
             assert not (sel & ~inside).any(), (cfg, parts[:], k, iy, ix)
             checked += int(sel.sum())
       banded += pd > 1
+      smaller += int((wins[..., 2] * wins[..., 3] < cfg["map_width"] * cfg["map_height"]).sum())
       assert (wins[..., 0] % 4 == 0).all() and (wins[..., 2] % 4 == 0).all()
       assert (wins[..., 0] >= 0).all() and (wins[..., 0] + wins[..., 2] <= cfg["map_width"]).all()
       assert (wins[..., 1] >= 0).all() and (wins[..., 1] + wins[..., 3] <= cfg["map_height"]).all()
-  assert checked > 100_000 and banded > 0
+  assert checked > 100_000 and (banded > 0 or open_far)
+  assert smaller > 0          # (open far end: the windows are still smaller than the map)
 
 
 def test_choose_parts_fills_whole_waves():

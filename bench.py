@@ -91,6 +91,8 @@ def main():
   ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
   ap.add_argument("--depth", default="uniform", choices=["uniform", "scene"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-other-configs", action="store_true",
+                  help="skip the other BASELINE.json configs (reported outside the timed region)")
   ap.add_argument("--cpu-seconds", type=float, default=12.0)
   ap.add_argument("--event-every", type=int, default=8,
                   help="bracket every n-th timed step with HIP events (an event record costs "
@@ -101,8 +103,11 @@ def main():
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # one process per GPU: --gpus N runs under `python -m torch.distributed.run --nproc-per-node N`
+    print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+          f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
+          f"--master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`", file=sys.stderr)
+    raise SystemExit(2)
   # (rehearsals on a one-GPU box: DM_BENCH_BACKEND=gloo lets several ranks share the device)
   backend = os.environ.get("DM_BENCH_BACKEND", "nccl")
   if backend != "nccl":
@@ -244,12 +249,9 @@ def main():
   achieved = alg / kernel_s / 1e9
 
   # HBM bytes of one launch sequence from the PMC counters: bench.py cannot run rocprofv3 on
-  # itself, so it quotes the committed PMC summary of this very command (profiles/)
-  traffic = None
-  tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-  if args.workload == "cfg2" and os.path.exists(tpath):
-    with open(tpath) as f:
-      traffic = json.load(f).get("launch_sequence_bytes")
+  # itself, so it quotes the committed PMC summary of this very command (profiles/) -- but only
+  # when that summary was taken on the library build that is loaded now (md5 of the .so)
+  traffic, traffic_note = committed_traffic(args.workload, _native.LIB_PATH)
 
   result = {
       "metric": "depth frames/sec projected+fused, B=64 640x480->512x512",
@@ -282,8 +284,7 @@ def main():
           "unit": "GB/s",
           "frac": achieved / HBM_PEAK_GBS,
           "traffic": traffic,
-          "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this "
-                            "command, gfx950 correction applied; bytes per launch sequence)" if traffic else None,
+          "traffic_source": traffic_note,
           "kernel": "orth_project launch sequence of dm_orth_project_f32: k_window_scatter + "
                     "k_window_merge (everything that produces the per-frame maps and masks; the "
                     "frame tables are written by the host through the PCIe BAR, or staged by a "
@@ -317,6 +318,16 @@ def main():
     torch.cuda.synchronize()
     result["scene_like_depth"] = {"value": B * n_s / (time.perf_counter() - t0), "unit": "frames/s",
                                   "steps": n_s, "note": "same workload on floor + walls depth"}
+  # checksum of the last step's fused map (a one-rank RCCL run must reproduce the plain run)
+  fz, fm = out[2], out[3]
+  finite = torch.isfinite(fz) & fm
+  result["fused_checksum"] = {
+      "cells": int(fm.sum().item()),
+      "sum": float(torch.where(finite, fz, torch.zeros_like(fz)).double().sum().item()),
+  }
+  if rank == 0 and world == 1 and not args.no_other_configs and args.workload == "cfg2" \
+      and args.depth == "uniform":
+    result["other_configs"] = other_configs(dmap, lib, dev)
   if rank == 0 and world == 1 and not args.no_cpu_baseline and not fused_only:
     result["cpu_baseline"] = cpu_baseline(depth, pose, value, H, W, mh, mw, fill,
                                           args.cpu_seconds, out)
@@ -326,37 +337,201 @@ def main():
     dist.destroy_process_group()
 
 
-def cpu_baseline(depth, pose, value, H, W, mh, mw, fill, budget_s, gpu_out):
-  """The CPU oracle (port of the reference's algorithm, oracle/dm_oracle.c,
-  OpenMP over frames) on a bounded sample of the same workload, on this box's
-  host cores; also used as a last check of the GPU result."""
+def committed_traffic(workload, lib_path):
+  """(bytes per launch sequence, note) from profiles/r02_hbm_traffic.json if its `lib_md5`
+  is the md5 of the loaded library, else (None, why)."""
+  import hashlib
+  tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+  if workload != "cfg2" or not os.path.exists(tpath):
+    return None, "no committed PMC summary for this workload"
+  with open(tpath) as f:
+    rec = json.load(f)
+  with open(lib_path, "rb") as f:
+    md5 = hashlib.md5(f.read()).hexdigest()
+  if rec.get("lib_md5") != md5:
+    return None, (f"profiles/r02_hbm_traffic.json was measured on library build "
+                  f"{rec.get('lib_md5')}, the loaded one is {md5}: not quoted")
+  return rec.get("launch_sequence_bytes"), (
+      "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command on "
+      "this library build, gfx950 correction applied; bytes per launch sequence)")
+
+
+def _event_us(fn, lib, n, hooks=True):
+  """Mean HIP-event time (us) of fn()'s projection sequence over n calls, and the wall time
+  per call of a back-to-back loop."""
+  ea = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+  eb = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+  for e in ea + eb:
+    e.record()
+  for _ in range(3):
+    fn()
+  torch.cuda.synchronize()
+  for i in range(n):
+    if hooks:
+      lib.dm_debug_record_before_projection(ea[i].cuda_event)
+      lib.dm_debug_record_after_projection(eb[i].cuda_event)
+      fn()
+    else:
+      ea[i].record()
+      fn()
+      eb[i].record()
+  torch.cuda.synchronize()
+  ev = float(np.mean([ea[i].elapsed_time(eb[i]) for i in range(n)])) * 1e3
+  t0 = time.perf_counter()
+  for _ in range(n):
+    fn()
+  torch.cuda.synchronize()
+  return ev, (time.perf_counter() - t0) / n * 1e6
+
+
+def other_configs(dmap, lib, dev):
+  """The other BASELINE.json configs, outside the headline's timed region: HIP-event time of the
+  projection sequence, algorithmic bytes, fraction of the 8 TB/s HBM peak, and a
+  check against the CPU oracle on a bounded sample.  Kept short (a few seconds in all)."""
   from oracle import oracle
-  cores = min(oracle.max_threads(), os.cpu_count() or 1)
-  n = min(depth.shape[0], max(cores, 16))
-  d = depth[:n].numpy()
+  res = {}
+  g = torch.Generator(device=dev).manual_seed(4242)
+  cxyf = lambda W, H: oracle.camera_intrinsics(W, H, np.radians(70.))
+
+  def projector(H, W, mh, mw, fill):
+    return dmap.MapProjector(
+        width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
+        width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
+        trunc_depth_min=0.15, trunc_depth_max=5.05, clip_border=0, to_global=True,
+        fill_value=fill, reduction="max")
+
+  def okw(H, W, mh, mw, fill):
+    cx, cy, fx, fy = cxyf(W, H)
+    return dict(width_offset=mw / 2., height_offset=mh / 2., cam_pitch=np.radians(-20.),
+                cam_height=0.88, map_res=0.03, map_width=mw, map_height=mh, focal_x=fx, focal_y=fy,
+                center_x=cx, center_y=cy, trunc_depth_min=0.15, trunc_depth_max=5.05,
+                to_global=True, fill_value=fill)
+
+  def poses(B):
+    p = torch.empty(B, 3, device=dev).uniform_(-1, 1, generator=g)
+    p[:, 2] = torch.empty(B, device=dev).uniform_(-np.pi, np.pi, generator=g)
+    return p.cpu()
+
+  def entry(name, us, wall_us, alg, same, note):
+    res[name] = {"launch_us": us, "call_wall_us": wall_us, "algorithmic_bytes": alg,
+                 "achieved_GBps": alg / us / 1e3, "frac": alg / us / 1e3 / HBM_PEAK_GBS,
+                 "gpu_matches_cpu_on_sample": same, "workload": note}
+
+  # cfg1: B=1, 320x240 -> 256x256 (the reference's own demo size)
+  B, H, W, mh, mw, _ = WORKLOADS["cfg1"]
+  d = torch.empty(B, 1, H, W, device=dev).uniform_(0.1, 10.0, generator=g)
+  po = poses(B)
+  proj = projector(H, W, mh, mw, -np.inf)
+  us, wall = _event_us(lambda: proj.orth_project(d, cam_pose=po), lib, 50)
+  top, mask = proj.orth_project(d, cam_pose=po)
+  want = oracle.orth_project(d.cpu().numpy(), cam_pose=po.numpy(), **okw(H, W, mh, mw, -np.inf))
+  same = bool(np.array_equal(top.cpu().numpy(), want[0]) and np.array_equal(mask.cpu().numpy(), want[1]))
+  entry("cfg1", us, wall, algorithmic_bytes(B, H, W, mh, mw, 0), same,
+        "B=1, 320x240 -> 256x256 height map, orth_project per call")
+
+  # cfg3: B=64, 40-class one-hot object map (no height map), checked on frame 0
+  B, H, W, mh, mw, C = WORKLOADS["cfg3"]
+  d = torch.empty(B, 1, H, W, device=dev).uniform_(0.1, 10.0, generator=g)
+  po = poses(B)
+  labels = torch.randint(0, C, (B, H, W), device=dev, generator=g)
+  v = torch.zeros(B, C, H, W, device=dev)
+  v.scatter_(1, labels.unsqueeze(1), 1.0)
+  del labels
+  proj = projector(H, W, mh, mw, 0.0)
+  us, wall = _event_us(lambda: proj.orth_project(d, value_map=v, cam_pose=po), lib, 4)
+  top, mask = proj.orth_project(d, value_map=v, cam_pose=po)
+  want = oracle.orth_project(d[:1].cpu().numpy(), value_map=v[:1].cpu().numpy(),
+                             cam_pose=po[:1].numpy(), **okw(H, W, mh, mw, 0.0))
+  same = bool(np.array_equal(top[:1].cpu().numpy(), want[0]) and np.array_equal(mask[:1].cpu().numpy(), want[1]))
+  entry("cfg3", us, wall, algorithmic_bytes(B, H, W, mh, mw, C), same,
+        "B=64, 640x480 + 40-class one-hot -> 512x512 object map (checked on frame 0)")
+  del v, top, mask
+
+  # cfg4 per rank: 64 frames of one trajectory fused straight into ONE 1024x1024 map
+  B, H, W, mh, mw, _ = WORKLOADS["cfg4"]
+  k = torch.arange(B, dtype=torch.float32)
+  po = torch.stack((0.02 * k, 0.01 * k, 0.01 * k), dim=1)
+  proj = projector(H, W, mh, mw, -np.inf)
+  us, wall = _event_us(lambda: proj.orth_project_fused(d, cam_pose=po), lib, 20, hooks=False)
+  fused, fmask = proj.orth_project_fused(d, cam_pose=po)
+  want = oracle.orth_project(d.cpu().numpy(), cam_pose=po.numpy(), fused=True, **okw(H, W, mh, mw, -np.inf))
+  same = bool(np.array_equal(fused.cpu().numpy(), want[0]) and np.array_equal(fmask.cpu().numpy(), want[1]))
+  entry("cfg4_per_gpu", us, wall, algorithmic_bytes(B, H, W, mh, mw, 0, True), same,
+        "64 frames/GPU of one trajectory fused into one 1024x1024 map (events around the call)")
+
+  # cfg5 per GPU: 16 frames of 1280x960 -> 2048x2048, plus the ego-motion flow grid
+  B, H, W, mh, mw = 16, 960, 1280, 2048, 2048
+  d = torch.empty(B, 1, H, W, device=dev).uniform_(0.1, 10.0, generator=g)
+  po = poses(B)
+  proj = projector(H, W, mh, mw, -np.inf)
+  us, wall = _event_us(lambda: proj.orth_project(d, cam_pose=po), lib, 6)
+  top, mask = proj.orth_project(d, cam_pose=po)
+  want = oracle.orth_project(d[:1].cpu().numpy(), cam_pose=po[:1].numpy(), **okw(H, W, mh, mw, -np.inf))
+  same = bool(np.array_equal(top[:1].cpu().numpy(), want[0]) and np.array_equal(mask[:1].cpu().numpy(), want[1]))
+  entry("cfg5_per_gpu", us, wall, algorithmic_bytes(B, H, W, mh, mw, 0), same,
+        "16 frames/GPU, 1280x960 -> 2048x2048 height map (checked on frame 0)")
+  del top, mask
+  tp = torch.tensor([0.05, 0.1, 0.02])
+  us, wall = _event_us(lambda: proj.camera_affine_grid(d, tp), lib, 6, hooks=False)
+  alg = B * H * W * (4 + 8)
+  res["cfg5_ego_flow"] = {"launch_us": us, "call_wall_us": wall, "algorithmic_bytes": alg,
+                          "achieved_GBps": alg / us / 1e3, "frac": alg / us / 1e3 / HBM_PEAK_GBS,
+                          "workload": "camera_affine_grid of the same 16 frames (events around the call)"}
+  return res
+
+
+def cpu_baseline(depth, pose, value, H, W, mh, mw, fill, budget_s, gpu_out):
+  """The CPU oracle (port of the reference's algorithm, oracle/dm_oracle.c, one OpenMP
+  thread per frame) on a bounded sample of the same workload, on the host cores this
+  process may use; also the last check of the GPU result.  Context, never the target."""
+  from oracle import oracle
+  try:
+    avail = len(os.sched_getaffinity(0))
+  except AttributeError:
+    avail = os.cpu_count() or 1
+  cores = max(1, min(oracle.max_threads(), avail))
+  B = depth.shape[0]
+  # the oracle parallelises over frames: the sample holds at least as many frames as there
+  # are cores (the batch repeated), so every core has work
+  reps = 1 if value is not None else max(1, min(4, -(-cores // B)))
+  n = B * reps if value is None else min(B, max(cores, 8))
+  d = depth[:B].numpy() if reps == 1 else np.concatenate([depth.numpy()] * reps, 0)
+  d = d[:n]
+  po = (pose.numpy() if reps == 1 else np.concatenate([pose.numpy()] * reps, 0))[:n]
   v = None if value is None else value[:n].numpy()
+  threads = min(cores, n)
   cx, cy, fx, fy = oracle.camera_intrinsics(W, H, np.radians(70.))
-  kw = dict(cam_pose=pose[:n].numpy(), width_offset=mw / 2., height_offset=mh / 2.,
+  kw = dict(width_offset=mw / 2., height_offset=mh / 2.,
             cam_pitch=np.radians(-20.), cam_height=0.88, map_res=0.03, map_width=mw,
             map_height=mh, focal_x=fx, focal_y=fy, center_x=cx, center_y=cy,
-            trunc_depth_min=0.15, trunc_depth_max=5.05, to_global=True, fill_value=fill,
-            nthreads=cores)
-  want = oracle.orth_project(d, value_map=v, **kw)     # warm-up + parity check
-  same = bool(np.array_equal(gpu_out[0][:n].cpu().numpy(), want[0])
-              and np.array_equal(gpu_out[1][:n].cpu().numpy(), want[1]))
+            trunc_depth_min=0.15, trunc_depth_max=5.05, to_global=True, fill_value=fill)
+  want = oracle.orth_project(d, value_map=v, cam_pose=po, nthreads=threads, **kw)   # warm-up + parity
+  m = min(n, B)
+  same = bool(np.array_equal(gpu_out[0][:m].cpu().numpy(), want[0][:m])
+              and np.array_equal(gpu_out[1][:m].cpu().numpy(), want[1][:m]))
   times = []
   t_end = time.perf_counter() + budget_s
   while time.perf_counter() < t_end or len(times) < 3:
     t0 = time.perf_counter()
-    oracle.orth_project(d, value_map=v, **kw)
+    oracle.orth_project(d, value_map=v, cam_pose=po, nthreads=threads, **kw)
     times.append(time.perf_counter() - t0)
+  k1 = 2 if value is None else 1                   # one thread, a couple of frames
+  t1 = []
+  for _ in range(3):
+    t0 = time.perf_counter()
+    oracle.orth_project(d[:k1], value_map=None if v is None else v[:k1], cam_pose=po[:k1],
+                        nthreads=1, **kw)
+    t1.append(time.perf_counter() - t0)
   return {
       "value": n / float(np.median(times)),
       "unit": "frames/s",
-      "cores": cores,
+      "cores": threads,
+      "cores_available": avail,
+      "single_thread_value": k1 / float(np.median(t1)),
       "kind": "port",
-      "sample": f"{n} frames of the same workload, median of {len(times)} runs "
-                f"(~{sum(times):.0f} s), OpenMP over frames",
+      "sample": f"{n} frames of the same workload ({'the batch repeated ' + str(reps) + 'x' if reps > 1 else 'a slice of the batch'}), "
+                f"median of {len(times)} runs (~{sum(times):.0f} s), one OpenMP thread per frame, "
+                f"{threads} threads; single_thread_value = {k1} frame(s) on one thread",
       "gpu_matches_cpu_on_sample": same,
   }
 

@@ -30,12 +30,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <setjmp.h>
-#include <signal.h>
-
 #include <algorithm>
 #include <chrono>
-#include <mutex>
 #include <cstddef>
 #include <type_traits>
 #include <vector>
@@ -94,6 +90,8 @@ size_t window_workspace_bytes(const dm_params& p) {
 
 namespace {
 
+thread_local size_t g_slab_budget = 0;             // dm_debug_slab_budget (0: no cap)
+
 struct Staged {                 // what run_window keeps between its passes
   Parts parts;
   int nparts, slab_stride, max_union;
@@ -101,14 +99,7 @@ struct Staged {                 // what run_window keeps between its passes
   int gx0, gz0, gx1, gz1;       // bounding box of all union windows (empty: gx1 <= gx0)
   Win16* g_wins;                // device copies (workspace head)
   Win16* g_unions;
-  const ScatterTables* d_tables;  // one per chunk of frames
-  // d_tables is a slot of the thread's table ring (device memory the host wrote through the
-  // PCIe BAR, no copy operation): only k_window_scatter may read it, the kernel that follows
-  // signals the slot free.  Else: the workspace, filled by a stream-ordered copy.
-  bool ring_tables;
-  uint32_t* slot_done;            // pinned host word the signalling kernel stores its ticket to
-  uint32_t* slot_issued;          // host: ticket of the last signalling launch that used the slot
-  uint32_t* ring_ticket;          // host: the ring's ticket counter
+  const ScatterTables* d_tables;  // one per chunk of frames: workspace, filled by ONE stream-ordered copy
   int chunk;                    // frames per chunk
   size_t geom_bytes;
   bool fast, fast_div;
@@ -216,6 +207,7 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
   const int chunk = st.chunk;                // frames per launch: what one table holds
   // channel groups: the slabs of one group fit the workspace's slab region
   const size_t per_channel = (size_t)p.B * st.nparts * st.slab_stride * 4;
+  if (g_slab_budget && slab_bytes > g_slab_budget) slab_bytes = g_slab_budget;
   int group = (int)(slab_bytes / (per_channel ? per_channel : 1));
   if (group < 1) group = 1;
   if (group > oc_total) group = oc_total;
@@ -233,13 +225,7 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
         MergeArgs ma;
         ma.b0 = b0; ma.oc = oc; ma.ch0 = ch0; ma.oc_total = oc_total; ma.mh = p.mh; ma.mw = p.mw;
         ma.nparts = st.nparts; ma.slab_stride = st.slab_stride; ma.fill = fill;
-        ma.signal = nullptr; ma.ticket = 0;
-        if (st.ring_tables) {
-          ma.wins = st.g_wins + (size_t)b0 * st.nparts; ma.unions = st.g_unions + b0;
-          ma.win_stride = st.nparts;
-          ma.signal = st.slot_done;
-          ma.ticket = *st.slot_issued = ++*st.ring_ticket;
-        } else {
+        {
           const ScatterTables* t = st.d_tables + b0 / chunk;     // device address arithmetic only
           ma.wins = t->wins; ma.unions = t->unions;
           ma.win_stride = st.nparts <= kFewParts ? kFewParts : st.nparts;
@@ -268,11 +254,6 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
       fa.accumulate = accumulate; fa.fill = fill;
       fa.gx0 = st.gx0; fa.gz0 = st.gz0; fa.gx1 = st.gx1; fa.gz1 = st.gz1;
       fa.wins = st.g_wins; fa.slabs = slabs; fa.fused = fused; fa.fused_mask = fused_mask;
-      fa.signal = nullptr; fa.ticket = 0;
-      if (st.ring_tables) {
-        fa.signal = st.slot_done;
-        fa.ticket = *st.slot_issued = ++*st.ring_ticket;
-      }
       const int bw4 = (st.gx1 - st.gx0) / 4;
       const int heavy = st.gx1 > st.gx0 ? ((bw4 + kFuseGroups - 1) / kFuseGroups) * (st.gz1 - st.gz0) : 0;
       const int per_fill_block = kFuseGroups * kFuseLanes * 8;
@@ -333,117 +314,12 @@ bool banded_split_pays(const dm_params& p, const Parts& parts, int nparts, int m
   return t_window < t_generic;
 }
 
-// The scatter tables of a call are ~10 KB the kernels need before they can start.  Staging
-// them with a stream-ordered copy costs a copy kernel and a dependent launch (~4 us of every
-// call).  On a large-BAR system the host instead writes them straight into device memory: a
-// per-thread, per-device ring of kTableSlots fine-grained device buffers (1.4 MB, allocated on
-// first use, kept for the life of the process -- the library's only persistent allocation).
-// PCIe keeps posted writes ordered ahead of the packet fetch that starts the kernel.  A slot
-// is reused only after the kernel that follows its k_window_scatter in stream order has
-// stored the slot's ticket to pinned host memory; the host waits for that (bounded), and
-// without a free slot or a large BAR the call takes the staged copy.
-constexpr int kTableSlots = 64;
-
-// First use of a ring: does a host store really reach the device buffer?  The attribute says
-// large BAR, but a host that maps the BAR differently must cost a fallback, not the process:
-// the probe store runs under a temporary SIGSEGV / SIGBUS handler and is read back with a
-// (one-off, synchronous) copy.
-sigjmp_buf g_probe_jump;
-void probe_fault(int) { siglongjmp(g_probe_jump, 1); }
-bool host_stores_reach(void* device_buffer) {
-  static std::mutex one_at_a_time;
-  std::lock_guard<std::mutex> lock(one_at_a_time);
-  struct sigaction probe = {}, old_segv = {}, old_bus = {};
-  probe.sa_handler = probe_fault;
-  sigemptyset(&probe.sa_mask);
-  sigaction(SIGSEGV, &probe, &old_segv);
-  sigaction(SIGBUS, &probe, &old_bus);
-  bool stored = false;
-  if (sigsetjmp(g_probe_jump, 1) == 0) {
-    volatile uint32_t* w = static_cast<volatile uint32_t*>(device_buffer);
-    w[0] = 0x600df00du;
-    w[1] = ~0x600df00du;
-    __builtin_ia32_sfence();
-    stored = true;
-  }
-  sigaction(SIGSEGV, &old_segv, nullptr);
-  sigaction(SIGBUS, &old_bus, nullptr);
-  if (!stored) return false;
-  uint32_t back[2] = {0, 0};
-  if (hipMemcpy(back, device_buffer, sizeof(back), hipMemcpyDeviceToHost) != hipSuccess) {
-    (void)hipGetLastError();
-    return false;
-  }
-  return back[0] == 0x600df00du && back[1] == ~0x600df00du;
-}
-
-struct TableRing {
-  ScatterTables* slots = nullptr;            // device memory, host-writable
-  volatile uint32_t* done = nullptr;         // pinned host memory, written by the GPU
-  uint32_t issued[kTableSlots] = {};         // ticket of the last signalling launch per slot
-  uint32_t ticket = 0;
-  int next = 0;
-  bool tried = false, off = false;
-
-  int acquire() {
-    if (!tried) {
-      tried = true;
-      static const bool disabled = getenv("DM_NO_TABLE_RING") != nullptr;
-      int dev = 0, large_bar = 0;
-      void* d = nullptr;
-      void* h = nullptr;
-      if (disabled || hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess ||
-          !large_bar ||
-          hipExtMallocWithFlags(&d, kTableSlots * sizeof(ScatterTables), hipDeviceMallocFinegrained) !=
-              hipSuccess) {
-        (void)hipGetLastError();
-        off = true;
-      } else if (!host_stores_reach(d)) {
-        (void)hipFree(d);
-        off = true;
-      } else if (hipHostMalloc(&h, kTableSlots * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipFree(d);
-        off = true;
-      } else {
-        slots = static_cast<ScatterTables*>(d);
-        done = static_cast<volatile uint32_t*>(h);
-        for (int i = 0; i < kTableSlots; ++i) done[i] = 0;
-      }
-    }
-    if (off) return -1;
-    const int i = next;
-    if (done[i] != issued[i]) {              // the GPU is kTableSlots calls behind: wait for it
-      const auto t0 = std::chrono::steady_clock::now();
-      while (done[i] != issued[i]) {
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
-          // calls of several ms each (64 of them in flight), or a launch that failed after
-          // its slot was taken: this thread goes back to the staged copy for good -- 4 us
-          // per call are nothing to such calls, and nobody waits here twice
-          off = true;
-          return -1;
-        }
-        __builtin_ia32_pause();
-      }
-    }
-    next = (next + 1) % kTableSlots;
-    return i;
-  }
-};
-TableRing& table_ring() {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  thread_local TableRing rings[16];
-  return rings[dev >= 0 && dev < 16 ? dev : 0];
-}
-
 // Host-side geometry of a call: parts, part windows, frame records.  Returns
 // hipErrorNotSupported when the windows cannot be made to fit in LDS (the caller then
 // takes the generic path); nothing has been enqueued in that case.
 hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* ws,
                          size_t ws_bytes, Staged& st, size_t& slab_bytes, hipStream_t s,
-                         hipEvent_t before = nullptr, bool will_fuse_windows = false) {
+                         hipEvent_t before = nullptr) {
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return hipErrorNotSupported;
   thread_local std::vector<FrameRec> recs;
   thread_local std::vector<Win16> wins;      // (B, nparts) then (B) unions
@@ -624,22 +500,6 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
   const size_t table_bytes =
       nchunks > 1 ? (size_t)nchunks * sizeof(ScatterTables)
                   : offsetof(ScatterTables, wins) + (size_t)p.B * win_stride * sizeof(Win16);
-  st.ring_tables = false;
-  // a follow-up kernel has to exist to signal the slot free (no union window: no merge)
-  if (nchunks == 1 && (will_fuse_windows || st.max_union > 0)) {
-    TableRing& ring = table_ring();
-    const int i = ring.acquire();
-    if (i >= 0) {
-      memcpy(ring.slots + i, tabs.data(), table_bytes);       // write-combined, through the BAR
-      __builtin_ia32_sfence();                                // on the bus before the launch is
-      st.d_tables = ring.slots + i;
-      st.ring_tables = true;
-      st.slot_done = const_cast<uint32_t*>(ring.done + i);
-      st.slot_issued = ring.issued + i;
-      st.ring_ticket = &ring.ticket;
-      return hipSuccess;
-    }
-  }
   return hipMemcpyAsync(const_cast<ScatterTables*>(st.d_tables), tabs.data(), table_bytes,
                         hipMemcpyHostToDevice, s);
 }
@@ -760,7 +620,7 @@ hipError_t run_window_fused(const dm_params& p, const dm_frame* frames_host, con
     return hipErrorNotSupported;
   Staged st;
   size_t slab_bytes = 0;
-  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s, nullptr, true);
+  hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s, nullptr);
   if (e != hipSuccess) return e;
   return window_pass(p, st, reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + st.geom_bytes),
                      depth, value, valid, nullptr, nullptr,
@@ -810,6 +670,12 @@ extern "C" __attribute__((visibility("default"))) int dm_debug_windows(
     }
   }
   return nparts;
+}
+
+extern "C" __attribute__((visibility("default"))) size_t dm_debug_slab_budget(size_t bytes) {
+  const size_t old = dm::g_slab_budget;
+  dm::g_slab_budget = bytes;
+  return old;
 }
 
 extern "C" __attribute__((visibility("default"))) int dm_debug_force_bands(int on) {

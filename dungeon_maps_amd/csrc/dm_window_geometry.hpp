@@ -30,10 +30,9 @@ struct Window {
   int x0, z0, w, h;
 };
 
-// Tables of the scatter kernel, one per chunk of frames (= launch): written by the host into
-// a slot of the thread's table ring (device memory, through the PCIe BAR) when the call is one
-// chunk, else staged into the workspace by ONE hipMemcpyAsync per call (dm_window.hip,
-// TableRing).  Every access is a scalar load of wave-uniform data.  (Passing them as kernel
+// Tables of the scatter kernel, one per chunk of frames (= launch): staged into the workspace
+// by ONE hipMemcpyAsync per call (dm_window.hip).  Every access is a scalar load of
+// wave-uniform data.  (Passing them as kernel
 // arguments instead costs as much at the head of the kernel, and the runtime's
 // kernel-argument pool then stalls the host every few dozen launches.)
 struct FrameRec {        // what the scatter kernel reads of a dm_frame

@@ -495,16 +495,6 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   DM_STAMPS_OUT();
 }
 
-// Table ring: the first thread of a kernel that follows k_window_scatter in stream order tells
-// the host that the scatter's table slot may be rewritten (a word in pinned host memory).
-// Called on the way OUT of the kernel: a store ahead of the loads of the read-only window
-// tables (even an opaque one) turns them from scalar into vector loads, each waited for in
-// turn (k_window_merge: 12.2 instead of 9.4 us).
-__device__ inline void signal_slot_free(uint32_t* signal, uint32_t ticket) {
-  if (signal && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-    asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(signal), "v"(ticket));
-}
-
 // scatter_mean into `out` (utils.py:470-477 with torch_scatter's out= semantics): the fill value
 // takes part in the numerator, the count is clamped to 1.
 __device__ inline void mean_of(float4& acc, uint4 cnt) {
@@ -520,13 +510,10 @@ struct MergeArgs {
   int slab_stride;
   float fill;
   // this chunk's part windows (row stride win_stride) and union windows: in the staged
-  // table (already in every XCD's L2) or, when that is a slot of the table ring, the device
-  // copies k_window_scatter leaves behind
+  // table (already in every XCD's L2)
   const Win16* wins;
   const Win16* unions;
   int win_stride;
-  uint32_t* signal;           // table ring: k_window_scatter of this stream position is done
-  uint32_t ticket;
   const float* slabs;
   float* out;
   uint8_t* mask;
@@ -549,10 +536,7 @@ k_window_merge(MergeArgs a) {
   const int ug4 = U.w >> 2;                    // float4 groups per U row
   const int total = ug4 * U.h;
   const int i = blockIdx.x * kMergeThreads + threadIdx.x;
-  if (i >= total) {
-    signal_slot_free(a.signal, a.ticket);
-    return;
-  }
+  if (i >= total) return;
   const int row = i / ug4;
   const int zb = U.z0 + row, x = U.x0 + ((i - row * ug4) << 2);
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
@@ -580,7 +564,6 @@ k_window_merge(MergeArgs a) {
                       ((uint32_t)mask_of(acc.z, a.fill) << 16) |
                       ((uint32_t)mask_of(acc.w, a.fill) << 24);
   *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
-  signal_slot_free(a.signal, a.ticket);
 }
 
 // The same for frames of many parts (image parts x depth bands): a block owns a tile of
@@ -607,7 +590,6 @@ k_window_merge_tiled(MergeArgs a) {
   const int tiles_z = (U.h + kTileRows - 1) / kTileRows;
   const int t = blockIdx.x;
   if (t >= tiles_x * tiles_z) {                  // the whole block
-    signal_slot_free(a.signal, a.ticket);
     return;
   }
   const int tz = t / tiles_x, tx = t - tz * tiles_x;
@@ -639,7 +621,6 @@ k_window_merge_tiled(MergeArgs a) {
 
   const int x = x0 + ((tid & (kTileGroups - 1)) << 2), zb = z0 + tid / kTileGroups;
   if (x >= x1 || zb >= z1) {
-    signal_slot_free(a.signal, a.ticket);
     return;
   }
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
@@ -667,7 +648,6 @@ k_window_merge_tiled(MergeArgs a) {
                       ((uint32_t)mask_of(acc.z, a.fill) << 16) |
                       ((uint32_t)mask_of(acc.w, a.fill) << 24);
   *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
-  signal_slot_free(a.signal, a.ticket);
 }
 
 // Batch fuse (north_star "projected+fused"): fused[c] = max/min over the frames
@@ -770,8 +750,6 @@ struct FuseWinArgs {
   int gx0, gz0, gx1, gz1;     // bounding box of every window of the call (cells, half open)
   float fill;
   const Win16* wins;          // (B_total, nparts)   written by k_window_scatter
-  uint32_t* signal;           // table ring (see MergeArgs)
-  uint32_t ticket;
   const float* slabs;         // ((b * oc + chl) * nparts + p) * slab_stride
   float* fused;               // (oc_total, mh, mw)
   uint8_t* fused_mask;
@@ -817,7 +795,6 @@ k_fuse_windows(FuseWinArgs a) {
       }
       *reinterpret_cast<uint32_t*>(a.fused_mask + cell) = mk;
     }
-    signal_slot_free(a.signal, a.ticket);
     return;
   }
   const int gi = threadIdx.x & (kFuseGroups - 1), lane = threadIdx.x / kFuseGroups;
@@ -889,7 +866,6 @@ k_fuse_windows(FuseWinArgs a) {
                         ((uint32_t)mask_of(acc.w, a.fill) << 24);
     *reinterpret_cast<uint32_t*>(a.fused_mask + cell) = mk;
   }
-  signal_slot_free(a.signal, a.ticket);
 }
 
 }  // namespace

@@ -140,6 +140,8 @@ class _Call:
         raise ValueError(f"depth_map has {dc} channels; expected 1 or {vc} (value_map's)")
     valid_c = 0
     if self.valid is not None:
+      # (a (b, C, h, w) valid map over a 1-channel depth map is refused like the reference
+      # refuses it: maps.py:1155-1158 raises on the channel mismatch)
       if self.valid.shape[2:] != (H, W) or self.valid.shape[0] not in (1, B) \
           or self.valid.shape[1] not in (1, dc):
         raise ValueError(f"valid_map {tuple(self.valid.shape)} does not broadcast to "
@@ -210,7 +212,7 @@ def orth_project(
     clip_border: Optional[int], to_global: bool, flip_h: bool = True,
     fill_value: Optional[float] = None, reduction: Optional[Reduction] = None,
     get_height_map: bool = False, device: Optional[torch.device] = None,
-    _validate_args: bool = True, _fuse: bool = False, _fused_out=None
+    _validate_args: bool = True
 ) -> Union[Tuple[torch.Tensor, torch.Tensor],
            Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
   """Orthographic projection of depth maps (b, c, h, w) to top-down maps.
@@ -225,6 +227,19 @@ def orth_project(
   unproject, pitch/yaw/translate, truncations, quantisation, scatter-reduce and
   the changed-mask (dm_orth_project_f32).
   """
+  return _orth_project(depth_map, value_map, valid_map, cam_pose, width_offset, height_offset,
+                       cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
+                       center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
+                       clip_border, to_global, flip_h, fill_value, reduction, get_height_map,
+                       device, False, None)
+
+
+def _orth_project(depth_map, value_map, valid_map, cam_pose, width_offset, height_offset,
+                  cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
+                  center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
+                  clip_border, to_global, flip_h, fill_value, reduction, get_height_map, device,
+                  _fuse, _fused_out):
+  """orth_project / orth_project_and_fuse behind one native call."""
   import ctypes
   call = _Call(depth_map, value_map, valid_map, cam_pose, width_offset, height_offset,
                cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
@@ -283,11 +298,11 @@ def orth_project_and_fuse(depth_map, value_map, valid_map, cam_pose, width_offse
   (float32 (C,mh,mw), bool (C,mh,mw)) writes the fused map and its mask into
   caller-owned buffers, e.g. slots of a ring that is all-reduced once per several
   steps (fewer, larger collectives)."""
-  return orth_project(depth_map, value_map, valid_map, cam_pose, width_offset, height_offset,
-                      cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
-                      center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
-                      clip_border, to_global, flip_h, fill_value, reduction, False, device,
-                      True, _fuse=True, _fused_out=fused_out)
+  return _orth_project(depth_map, value_map, valid_map, cam_pose, width_offset, height_offset,
+                       cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
+                       center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
+                       clip_border, to_global, flip_h, fill_value, reduction, False, device,
+                       True, fused_out)
 
 
 def orth_project_fused(
@@ -326,6 +341,8 @@ def orth_project_fused(
         ctypes.byref(p), _ptr(call.frames), _ptr(call.depth), _ptr(call.value),
         _ptr(call.valid), _ptr(out), _ptr(mask), int(accumulate), _ptr(ws), ws_bytes,
         _stream_ptr(call.dev)))
+  if call.target != call.dev:       # outputs live on the depth map's device (maps.py:227-232)
+    out, mask = out.to(call.target), mask.to(call.target)
   return out, mask
 
 

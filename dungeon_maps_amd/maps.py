@@ -66,12 +66,21 @@ class MapProjector:
       cache.clear()
     d[name] = value
 
-  def clone(self, **overrides) -> "MapProjector":
-    """Shallow copy with some fields replaced (None = keep)."""
-    unknown = set(overrides) - set(self._FIELDS)
-    if unknown:
-      raise TypeError(f"clone() got unexpected keyword arguments {sorted(unknown)}")
-    return MapProjector(**{name: get(overrides.get(name), getattr(self, name))
+  def clone(self, width: Optional[int] = None, height: Optional[int] = None,
+            hfov: Optional[float] = None, vfov: Optional[float] = None,
+            cam_pose: Optional[Float3D] = None, width_offset: Optional[float] = None,
+            height_offset: Optional[float] = None, cam_pitch: Optional[float] = None,
+            cam_height: Optional[float] = None, map_res: Optional[float] = None,
+            map_width: Optional[int] = None, map_height: Optional[int] = None,
+            trunc_depth_min: Optional[float] = None, trunc_depth_max: Optional[float] = None,
+            trunc_height_max: Optional[float] = None, clip_border: Optional[int] = None,
+            to_global: Optional[bool] = None, flip_h: Optional[bool] = None,
+            fill_value: Optional[float] = None, reduction: Optional[Reduction] = None,
+            device: Optional[torch.device] = None) -> "MapProjector":
+    """Shallow copy with some fields replaced (None = keep); parameter list of reference
+    maps.py:1349-1372."""
+    overrides = locals()
+    return MapProjector(**{name: get(overrides[name], getattr(self, name))
                            for name in self._FIELDS})
 
 
@@ -126,7 +135,23 @@ def _forwarding_method(fn, doc_ref: str):
       call[i] = field[i] if v is None else v
     return fn(*call)
 
+  # The signature the reference's method of the same name declares (maps.py:1406-1749): `self`,
+  # then the functional twin's parameters, every one the projector can supply (or that the
+  # reference defaults) optional = None.
+  sig_params = [inspect.Parameter("self", inspect.Parameter.POSITIONAL_OR_KEYWORD)]
+  for i, (n, p) in enumerate(params.items()):
+    if kinds[i] or n in ("value_map", "valid_map"):
+      default = None
+    elif p.default is inspect.Parameter.empty:
+      default = inspect.Parameter.empty
+    else:
+      default = p.default
+    sig_params.append(inspect.Parameter(n, inspect.Parameter.POSITIONAL_OR_KEYWORD,
+                                        default=default, annotation=p.annotation))
+  method.__signature__ = inspect.Signature(
+      sig_params, return_annotation=inspect.signature(fn).return_annotation)
   method.__name__ = fn.__name__
+  method.__qualname__ = f"MapProjector.{fn.__name__}"
   method.__doc__ = (f"``{fn.__name__}`` with None arguments taken from this projector "
                     f"(reference {doc_ref}).\n\n" + (fn.__doc__ or ""))
   return method

@@ -13,21 +13,15 @@
  *    otherwise.  `frames` is a HOST array (pageable is fine): the call copies
  *    what it needs out of it and it may be reused as soon as the call returns.
  *    Scratch is a caller-provided workspace (dm_*_workspace_bytes, 256-byte
- *    aligned); the library never frees caller memory.  Its one allocation of
- *    its own: on a large-BAR system each calling thread keeps, per device, a
- *    ring of 64 frame-table slots in device memory (1.4 MB, made on first use,
- *    kept for the life of the process) that the host writes directly, which
- *    saves a copy operation per call; DM_NO_TABLE_RING=1 in the environment
- *    turns it off (the tables are then staged into the workspace by a
- *    stream-ordered copy).
+ *    aligned); the library allocates no device memory of its own and never
+ *    frees caller memory.
  *  - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
- *    the default stream).  No host synchronisation inside, except that a
- *    thread more than 64 projection calls ahead of the GPU waits for a table
- *    slot (bounded; it then falls back to the staged copy).
+ *    the default stream).  No host synchronisation inside.
  *  - return 0 on success, a negative dm_status otherwise; dm_last_error()
  *    returns a thread-local message.  No exceptions cross the ABI.
  *  - re-entrant; no global state besides thread-local data (error string,
- *    table ring, the remembered split of recent call shapes).
+ *    the remembered split of recent call shapes).  No signal handlers, no
+ *    threads of its own.
  */
 #ifndef DUNGEON_MAPS_AMD_H
 #define DUNGEON_MAPS_AMD_H
@@ -288,6 +282,14 @@ int dm_debug_windows(const dm_params* p, const dm_frame* frames, int min_parts, 
  * images); returns the previous setting.  Lets the parity tests cover bands on small shapes.
  */
 int dm_debug_force_bands(int on);
+
+/*
+ * Test hook: caps the bytes of LDS-window slabs one channel group of the calling thread's
+ * projections may use (0 = no cap; returns the previous cap), so that value maps of few
+ * frames go through several channel groups -- the route a 40-class object map of a full
+ * batch takes -- at sizes the oracle finishes in seconds.
+ */
+size_t dm_debug_slab_budget(size_t bytes);
 
 /*
  * Measurement hook (bench.py): the next dm_orth_project_f32 call on this thread

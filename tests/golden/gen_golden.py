@@ -395,6 +395,22 @@ def g8(dmap):
   save("g8_camera_affine_grid_64x48", **pack_kwargs(cfg), **arrays)
 
 
+def g8b(dmap):
+  """camera_affine_grid at BASELINE configs[4]'s frame size (1280x960).  The depth map is
+  regenerated from the seed by the test (numpy PCG64 uniform); the fixture keeps the
+  reference's grid at every 16th row / column (the op is per pixel)."""
+  h, w, seed, stride = 960, 1280, 809, 16
+  depth = np.random.default_rng(seed).uniform(0.1, 10.0, (1, 1, h, w)).astype(np.float32)
+  cfg = dict(width=w, height=h, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+             cam_height=0.88)
+  proj = dmap.MapProjector(**cfg)
+  tp = np.asarray([0.05, 0.1, 0.02], dtype=np.float32)
+  g = proj.camera_affine_grid(T(depth), T(tp)).numpy()
+  save("g8b_camera_affine_grid_1280x960_sampled", **pack_kwargs(cfg), seed=np.int64(seed),
+       stride=np.int64(stride), trans_pose=tp, depth_checksum=np.float64(depth.astype(np.float64).sum()),
+       grid_sampled=g[:, :, ::stride, ::stride].copy())
+
+
 def g9(dmap):
   """TopdownMap.select / get_camera / get_origin / get_coords / get_points and
   compute_center_offsets (maps.py:1824-1949, 1959-2037, 1175-1248)."""
@@ -531,6 +547,27 @@ def g11(dmap):
   save("g11_parameter_sweep_56x40", **arrays)
 
 
+def g12(dmap):
+  """Public method signatures of the object API (maps.py:1253-1749, 1753-1955, 2289-2550):
+  parameter names in order, which are required, and the repr of simple defaults."""
+  import inspect
+  import json
+  out = {}
+  for cls in (dmap.MapProjector, dmap.TopdownMap, dmap.MapBuilder):
+    for name, fn in inspect.getmembers(cls, predicate=inspect.isfunction):
+      if name.startswith("_") and name != "__init__":
+        continue
+      out[f"{cls.__name__}.{name}"] = [
+          {"name": p.name, "required": p.default is inspect.Parameter.empty
+                                       and p.kind is not inspect.Parameter.VAR_KEYWORD,
+           "kind": p.kind.name,
+           "default": None if p.default is inspect.Parameter.empty else repr(p.default)}
+          for p in inspect.signature(fn).parameters.values()]
+  with open(os.path.join(HERE, "g12_api_signatures.json"), "w") as f:
+    json.dump(out, f, indent=1, sort_keys=True)
+  print("wrote g12_api_signatures.json", len(out), "methods")
+
+
 def main():
   torch.set_num_threads(1)
   torch.manual_seed(0)
@@ -542,9 +579,11 @@ def main():
   g6(dmap)
   g7(dmap)
   g8(dmap)
+  g8b(dmap)
   g9(dmap)
   g10(dmap)
   g11(dmap)
+  g12(dmap)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,154 @@
+"""BASELINE.json configs at their real geometry, through the public API -> ctypes -> C ABI,
+against the CPU oracle / the reference-generated fixtures.
+
+  configs[3]  64 x (640x480) of one trajectory fused straight into ONE 1024x1024 map
+  configs[2]  40-class one-hot object map, 640x480 -> 512x512, through several channel groups
+  configs[4]  ego-motion flow grid at 1280x960 (fixture g8b: the reference's grid, sampled)
+  N > 1 leg   bench.py under torch.distributed.run with ONE rank on real RCCL
+"""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, project_kwargs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dmap():
+  import dungeon_maps_amd as dmap
+  from dungeon_maps_amd import _native
+  _native.lib()
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU (run with -m gpu on an MI355X box)")
+  return dmap
+
+
+def _cfg(H, W, mh, mw, fill):
+  return dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+              cam_height=0.88, width_offset=mw / 2., height_offset=mh / 2., map_res=0.03,
+              map_width=mw, map_height=mh, trunc_depth_min=0.15, trunc_depth_max=5.05,
+              clip_border=0, to_global=True, fill_value=fill)
+
+
+def test_cfg4_trajectory_fused_into_1024_map(dmap, oracle):
+  """BASELINE configs[3], one rank's share: 64 frames of 640x480 along the trajectory of
+  bench.py (pose_i = (0.02 i, 0.01 i, 0.01 i)) fused into one 1024x1024 global map."""
+  B, H, W, mh, mw = 64, 480, 640, 1024, 1024
+  g = torch.Generator().manual_seed(1234)
+  depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g)
+  k = torch.arange(B, dtype=torch.float32)
+  pose = torch.stack((0.02 * k, 0.01 * k, 0.01 * k), dim=1)
+  cfg = _cfg(H, W, mh, mw, -np.inf)
+  proj = dmap.MapProjector(**cfg)
+  d = depth.cuda()
+  fused, fmask = proj.orth_project_fused(d, cam_pose=pose)
+  torch.cuda.synchronize()
+  want, wmask = oracle.orth_project(depth.numpy(), fused=True,
+                                    **dict(project_kwargs(cfg, oracle.camera_intrinsics),
+                                           cam_pose=pose.numpy()))
+  np.testing.assert_array_equal(fmask.cpu().numpy(), wmask)
+  np.testing.assert_array_equal(fused.cpu().numpy(), want)
+  assert wmask.sum() > 50_000          # the trajectory really covers a large area
+  # running-map semantics (the multi-rank bench leg): start from fill, accumulate
+  acc = torch.full((1, mh, mw), -np.inf, device="cuda")
+  acc, amask = proj.orth_project_fused(d, cam_pose=pose, out=acc)
+  assert torch.equal(acc, fused) and torch.equal(amask, fmask)
+
+
+def test_cfg3_40_classes_full_geometry_several_channel_groups(dmap, oracle):
+  """BASELINE configs[2] geometry (640x480 -> 512x512, 40-class one-hot, fill 0) at B=4,
+  with the slab budget capped so that the 40 channels go through several channel groups
+  (the route a full batch takes: dm_window.hip window_pass, ch0 > 0)."""
+  from dungeon_maps_amd import _native
+  lib = _native.lib()
+  B, H, W, C, mh, mw = 4, 480, 640, 40, 512, 512
+  g = torch.Generator().manual_seed(4321)
+  depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g)
+  pose = torch.empty(B, 3).uniform_(-1, 1, generator=g)
+  pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)
+  labels = torch.randint(0, C, (B, H, W), generator=g)
+  value = torch.nn.functional.one_hot(labels, C).permute(0, 3, 1, 2).float().contiguous()
+  cfg = _cfg(H, W, mh, mw, 0.0)
+  proj = dmap.MapProjector(**cfg)
+  old = lib.dm_debug_slab_budget(8 << 20)
+  try:
+    top, mask, height = proj.orth_project(depth.cuda(), value_map=value.cuda(), cam_pose=pose,
+                                          get_height_map=True)
+    torch.cuda.synchronize()
+    split = (ctypes.c_int32 * 4)()
+    lib.dm_debug_last_split(split)
+  finally:
+    lib.dm_debug_slab_budget(old)
+  assert split[0] * split[1] * split[2] > 0, "the LDS-windowed path must be the one that ran"
+  want = oracle.orth_project(depth.numpy(), value_map=value.numpy(), get_height_map=True,
+                             nthreads=4, **dict(project_kwargs(cfg, oracle.camera_intrinsics),
+                                                cam_pose=pose.numpy()))
+  np.testing.assert_array_equal(mask.cpu().numpy(), want[1])
+  np.testing.assert_array_equal(top.cpu().numpy(), want[0])
+  np.testing.assert_array_equal(height.cpu().numpy(), np.ascontiguousarray(want[2]))
+  # the same call without the cap (one channel group) gives the same maps
+  top1, mask1 = proj.orth_project(depth.cuda(), value_map=value.cuda(), cam_pose=pose)
+  assert torch.equal(top1, top) and torch.equal(mask1, mask)
+
+
+def test_cfg5_ego_flow_grid_1280x960(dmap):
+  """camera_affine_grid at BASELINE configs[4]'s frame size against the reference's own grid
+  (fixture g8b keeps every 16th row / column; the depth map is regenerated from its seed)."""
+  g, cfg = load_golden("g8b_camera_affine_grid_1280x960_sampled")
+  h, w, stride = int(cfg["height"]), int(cfg["width"]), int(g["stride"])
+  depth = np.random.default_rng(int(g["seed"])).uniform(0.1, 10.0, (1, 1, h, w)).astype(np.float32)
+  assert float(depth.astype(np.float64).sum()) == float(g["depth_checksum"])
+  proj = dmap.MapProjector(**cfg)
+  grid = proj.camera_affine_grid(torch.from_numpy(depth).cuda(), torch.from_numpy(g["trans_pose"]))
+  torch.cuda.synchronize()
+  assert grid.shape == (1, 1, h, w, 2)
+  got = grid.cpu().numpy()
+  np.testing.assert_array_equal(got[:, :, ::stride, ::stride], g["grid_sampled"])
+  assert np.isfinite(got).all()
+  # a batch of 4 such frames with per-frame motion == the frames one by one
+  d4 = torch.from_numpy(np.concatenate([depth, depth[:, :, ::-1].copy(), depth * 0.5, depth])).cuda()
+  tp = torch.tensor([[0.05, 0.1, 0.02], [0., 0., 0.], [-0.2, 0.15, -0.4], [0.05, 0.1, 0.02]])
+  g4 = proj.camera_affine_grid(d4, tp)
+  for i in range(4):
+    assert torch.equal(g4[i:i + 1], proj.camera_affine_grid(d4[i:i + 1], tp[i]))
+  assert torch.equal(g4[3:4], grid)
+
+
+def _bench(args, launcher):
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+  cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py")] + args
+  out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, out.stdout[-2000:]
+  return json.loads(lines[0])
+
+
+def test_bench_rccl_leg_with_one_rank():
+  """bench.py launched the way the driver launches N > 1 (torch.distributed.run), with one
+  rank: `nccl` process group on real RCCL, the ring of partial maps, all_reduce(MAX),
+  mask_from_map -- and the fused map must equal the single-process one (checksums of the
+  last step's fused map and mask in the JSON line).  A fresh child process: the launcher
+  runs before anything in that child touches the GPU."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  common = ["--gpus", "1", "--steps", "40", "--warmup", "4", "--no-cpu-baseline", "--no-other-configs"]
+  port = 29650 + os.getpid() % 300
+  one = _bench(common, ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port)])
+  solo = _bench(common, [])
+  for r in (one, solo):
+    assert r["n_gpus"] == 1 and r["steps"] == 40 and r["value"] > 0
+    assert r["roofline"]["frac"] > 0 and r["unit"] == "frames/s"
+  assert "RCCL" in one["config"]["parallelism"]
+  assert one["fused_checksum"] == solo["fused_checksum"]
+  assert one["fused_checksum"]["cells"] > 0

@@ -21,7 +21,8 @@ def dmap():
   import dungeon_maps_amd as dmap
   from dungeon_maps_amd import _native
   _native.lib()  # the HIP library must be the thing under test
-  assert torch.cuda.is_available()
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU (run with -m gpu on an MI355X box)")
   return dmap
 
 
@@ -435,14 +436,14 @@ def test_cfg5_geometry_and_large_batches(dmap, oracle):
 
 
 # --------------------------------------------------------------------------
-# Table ring: the host writes each call's frame tables into one of 64 device slots through
-# the PCIe BAR and reuses a slot only after the GPU has signalled it free.
+# Back-to-back calls with the host running ahead of the GPU: every call stages its own frame
+# tables (stream-ordered), so calls in flight must not see each other's poses.
 # --------------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,W,mh,mw,calls", [
-    (3, 96, 128, 128, 128, 200),       # small calls: the host cycles the ring three times
-    (64, 480, 640, 512, 512, 300),     # cfg2: the host runs ahead of the GPU and has to wait for slots
+    (3, 96, 128, 128, 128, 200),       # small calls: dozens of them in flight
+    (64, 480, 640, 512, 512, 300),     # cfg2
 ])
-def test_table_ring_reuse(dmap, B, H, W, mh, mw, calls):
+def test_calls_in_flight_keep_their_poses(dmap, B, H, W, mh, mw, calls):
   from dungeon_maps_amd import _native
   lib = _native.lib()
   depth, _ = _synthetic(B, H, W, seed=99)
@@ -468,7 +469,7 @@ def test_table_ring_reuse(dmap, B, H, W, mh, mw, calls):
     ref = refs[i % 5]
     bad += (got[0] != ref[0]).sum() + (got[1] != ref[1]).sum() + (got[2] != ref[2]).sum()
   assert int(bad.item()) == 0
-  # the same through the batch-fused entry point (k_fuse_windows signals the slot)
+  # the same through the batch-fused entry point
   ref_f = [r[2] for r in refs]
   bad.zero_()
   for i in range(calls // 2):
@@ -478,7 +479,7 @@ def test_table_ring_reuse(dmap, B, H, W, mh, mw, calls):
 
 
 def test_two_threads_two_streams(dmap):
-  """The library keeps per-thread state (error string, table ring, remembered splits): two
+  """The library keeps per-thread state (error string, remembered splits): two
   Python threads, each on its own stream and with its own poses, must not disturb each other."""
   import threading
   from dungeon_maps_amd import _native

@@ -1,13 +1,15 @@
 """Host-side logic of the drop-in API on CPU: projector defaults/clone,
 Rodrigues matrices and intrinsics against the reference-generated fixture,
 frame-table packing, coordinate queries (golden g9), enums."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import dungeon_maps_amd as dmap
 from dungeon_maps_amd import frames, utils
-from conftest import load_golden
+from conftest import GOLDEN, load_golden
 
 
 def test_enums_and_known_answers():
@@ -136,3 +138,42 @@ def test_topdownmap_container_semantics():
   tm = dmap.TopdownMap(a, None, b)
   assert not tm.is_height_map and tm.height_map is b
   assert dmap.TopdownMap().is_empty
+
+
+def test_object_api_signatures_match_the_reference():
+  """inspect.signature of every public method the reference's MapProjector / TopdownMap /
+  MapBuilder declare (fixture g12, generated from maps.py:1253-1749, 1753-1955, 2289-2550):
+  same parameter names in the same order, the same ones required."""
+  import inspect
+  import json
+  import dungeon_maps_amd as dmap
+  with open(os.path.join(GOLDEN, "g12_api_signatures.json")) as f:
+    want = json.load(f)
+  problems = []
+  for qual, params in sorted(want.items()):
+    cls_name, meth = qual.split(".")
+    fn = getattr(getattr(dmap, cls_name), meth, None)
+    if fn is None:
+      problems.append(f"{qual}: missing")
+      continue
+    got = list(inspect.signature(fn).parameters.values())
+    got_names = [p.name for p in got]
+    want_names = [p["name"] for p in params]
+    if got_names[:len(want_names)] != want_names and got_names != want_names:
+      problems.append(f"{qual}: names {got_names} != {want_names}")
+      continue
+    for g, w in zip(got, params):
+      required = g.default is inspect.Parameter.empty and g.kind is not inspect.Parameter.VAR_KEYWORD
+      if required != w["required"]:
+        problems.append(f"{qual}: {g.name} required={required}, reference {w['required']}")
+    extra = got[len(want_names):]
+    if any(p.default is inspect.Parameter.empty and p.kind is not inspect.Parameter.VAR_KEYWORD
+           for p in extra):
+      problems.append(f"{qual}: extra required parameters {[p.name for p in extra]}")
+  assert not problems, "\n".join(problems)
+  # positional clone(width, height, ...) works as in maps.py:1349-1372
+  proj = dmap.MapProjector(64, 48, 1.2, map_res=0.1, map_width=32, map_height=32)
+  c = proj.clone(80, 60)
+  assert (c.width, c.height, c.map_width) == (80, 60, 32)
+  # private plumbing stays out of the public functional signature
+  assert "_fuse" not in inspect.signature(dmap.orth_project).parameters

@@ -57,7 +57,7 @@ def test_cfg4_trajectory_fused_into_1024_map(dmap, oracle):
                                            cam_pose=pose.numpy()))
   np.testing.assert_array_equal(fmask.cpu().numpy(), wmask)
   np.testing.assert_array_equal(fused.cpu().numpy(), want)
-  assert wmask.sum() > 50_000          # the trajectory really covers a large area
+  assert wmask.sum() > 30_000          # the trajectory covers more than any single frame
   # running-map semantics (the multi-rank bench leg): start from fill, accumulate
   acc = torch.full((1, mh, mw), -np.inf, device="cuda")
   acc, amask = proj.orth_project_fused(d, cam_pose=pose, out=acc)

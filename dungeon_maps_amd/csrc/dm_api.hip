@@ -80,7 +80,7 @@ size_t dm_orth_project_workspace_bytes(const dm_params* p) {
   if (check_params(p) != DM_OK) return 0;
   size_t n = dm::generic_workspace_bytes(*p);
   if (dm::window_path_supported(*p)) {
-    const size_t w = dm::window_workspace_bytes(*p);
+    const size_t w = dm::window_workspace_bytes(*p) + dm::strip_workspace_extra(*p);
     if (w > n) n = w;
   } else if (padded_route(*p)) {
     dm_params q = *p;
@@ -119,11 +119,15 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
   const hipEvent_t mid = g_mid_event, pre = g_pre_event;
   g_mid_event = nullptr;
   g_pre_event = nullptr;
-  if (dm::window_path_supported(*p) && !g_force_generic)
-    e = dm::run_window(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
-                       p->vc ? height_dev : nullptr, fused_dev, fused_mask_dev, workspace_dev,
-                       workspace_bytes, pre, mid, s);
-  else if (padded_route(*p) && !g_force_generic &&
+  if (dm::window_path_supported(*p) && !g_force_generic) {
+    e = dm::run_strip(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
+                      p->vc ? height_dev : nullptr, fused_dev, fused_mask_dev, workspace_dev,
+                      workspace_bytes, pre, mid, s);
+    if (e == hipErrorNotSupported)
+      e = dm::run_window(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
+                         p->vc ? height_dev : nullptr, fused_dev, fused_mask_dev, workspace_dev,
+                         workspace_bytes, pre, mid, s);
+  } else if (padded_route(*p) && !g_force_generic &&
            reinterpret_cast<uintptr_t>(workspace_dev) % 256 == 0) {
     // project into padded maps at the head of the workspace, then copy the real columns out
     dm_params q = *p;

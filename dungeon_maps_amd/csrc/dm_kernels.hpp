@@ -34,6 +34,14 @@ hipError_t run_window_fused(const dm_params& p, const dm_frame* frames_host, con
                             const float* value, const uint8_t* valid, float* out, uint8_t* mask,
                             int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 
+// dm_strip.hip -- column strips with device-side geometry: owned cells straight to the map,
+// shared cells through slabs (max / min).  hipErrorNotSupported: does not apply, nothing enqueued.
+size_t strip_workspace_extra(const dm_params& p);
+hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const float* depth,
+                     const float* value, const uint8_t* valid, float* out, uint8_t* mask,
+                     float* height, float* fused, uint8_t* fused_mask, void* ws, size_t ws_bytes,
+                     hipEvent_t before_projection, hipEvent_t after_projection, hipStream_t s);
+
 // dm_points.hip -- exact point-set primitives (affine, quantise, flat scatter)
 hipError_t run_affine_points(const float* pts, const float* R, const float* t, int B,
                              size_t n_per_batch, int translate_first, float* out, hipStream_t s);

@@ -289,6 +289,7 @@ Remembered& remembered(const dm_params& p) {
 }
 
 thread_local int g_last_split[4] = {0, 0, 0, 0};   // dm_debug_last_split
+thread_local int g_last_path = 0;                  // dm_debug_last_path
 thread_local bool g_force_bands = false;           // dm_debug_force_bands
 
 // Depth bands multiply the workgroups, each with a window to initialise and flush: with few
@@ -391,6 +392,7 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
   if (last.hopeless > 0 && !g_force_bands) {
     --last.hopeless;
     g_last_split[0] = g_last_split[1] = g_last_split[2] = 0;
+    g_last_path = 0;
     return hipErrorNotSupported;
   }
   const bool same_shape = last.valid && (last.parts.pd == 1 || can_band);
@@ -434,9 +436,11 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
   else last.hopeless = 63;       // the search is host time: not on every call of such a shape
   if (!fits) {
     g_last_split[0] = g_last_split[1] = g_last_split[2] = 0;
+    g_last_path = 0;
     return hipErrorNotSupported;
   }
   g_last_split[0] = st.parts.pc; g_last_split[1] = st.parts.pr; g_last_split[2] = st.parts.pd;
+  g_last_path = 1;
   st.slab_stride = (int)align_up((size_t)(max_area > 0 ? max_area : 4), 4) * planes;
   st.geom_bytes = geometry_bytes(p.B, st.nparts);
   if (ws_bytes < st.geom_bytes + (size_t)p.B * st.nparts * st.slab_stride * 4)
@@ -529,6 +533,7 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
   if (shape.hopeless > 0 && !g_force_bands) {
     --shape.hopeless;
     g_last_split[0] = g_last_split[1] = g_last_split[2] = 0;
+    g_last_path = 0;
     return hipErrorNotSupported;
   }
   hipError_t e = shape.halve && !fused && p.B >= 2
@@ -629,6 +634,17 @@ hipError_t run_window_fused(const dm_params& p, const dm_frame* frames_host, con
 }
 
 }  // namespace dm
+
+namespace dm {
+// which path the calling thread's last projection took, for dm_debug_last_split / _last_path:
+// 0 generic (global atomics), 1 LDS windows with host geometry, 2 strip path
+void note_split(int pc, int pr, int pd, int path) {
+  g_last_split[0] = pc; g_last_split[1] = pr; g_last_split[2] = pd;
+  g_last_path = path;
+}
+}  // namespace dm
+
+extern "C" __attribute__((visibility("default"))) int dm_debug_last_path(void) { return dm::g_last_path; }
 
 extern "C" __attribute__((visibility("default"))) void dm_debug_last_split(int32_t* out4) {
   for (int i = 0; i < 4; ++i) out4[i] = dm::g_last_split[i];

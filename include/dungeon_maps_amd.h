@@ -284,6 +284,40 @@ int dm_debug_windows(const dm_params* p, const dm_frame* frames, int min_parts, 
 int dm_debug_force_bands(int on);
 
 /*
+ * Test hooks of the strip path (dm_strip.hip: column strips whose map windows are derived on
+ * the device; cells only one strip can reach go straight to the map).
+ *   dm_debug_last_path           which path the calling thread's last projection took:
+ *                                0 generic (global atomics), 1 LDS windows with host geometry,
+ *                                2 strip path.
+ *   dm_debug_force_legacy_window non-zero keeps the calling thread's projections off the strip
+ *                                path (they take path 1 or 0); returns the previous setting.
+ *   dm_debug_force_strips        1..8: the calling thread's projections are cut into this many
+ *                                column strips whatever the cost model says (0 = back to the
+ *                                model); returns the previous setting.  Lets the tests run the
+ *                                strip path on small images.
+ *   dm_debug_strip_geometry      host only (no GPU needed): the strip path's geometry for `p` and
+ *                                the given frames exactly as the kernels derive it.
+ *                                out_geom (B, 8 + 4*8) int32 per frame: {ok, strips P, strip
+ *                                width, slack cells, union window x0, z0, w, h, then 8 strip
+ *                                windows {x0, z0, w, h}}; out_covers (B, mh, P) uint32 or NULL:
+ *                                per map row and strip the cells [lo, hi) the strip can reach,
+ *                                packed lo | hi << 16 (0 = none); out_bound[5] or NULL: {slack,
+ *                                fits LDS, window cells, union rows, union cells} the launch
+ *                                is sized with (valid for every yaw / position of the camera).
+ *                                Returns P, 0 when the strip path does not apply to `p`.
+ *   dm_debug_strip_geometry_dev  the same windows / edges from the device's own evaluation
+ *                                (geom_dev: B * 1024 bytes of device scratch, copied back by
+ *                                the caller); returns P, 0 (not applicable) or < 0.
+ */
+int dm_debug_last_path(void);
+int dm_debug_force_legacy_window(int on);
+int dm_debug_force_strips(int strips);
+int dm_debug_strip_geometry(const dm_params* p, const dm_frame* frames, int32_t* out_geom,
+                            uint32_t* out_covers, int32_t* out_bound);
+int dm_debug_strip_geometry_dev(const dm_params* p, const float* frames_dev, void* geom_dev,
+                                size_t geom_bytes, void* stream);
+
+/*
  * Test hook: caps the bytes of LDS-window slabs one channel group of the calling thread's
  * projections may use (0 = no cap; returns the previous cap), so that value maps of few
  * frames go through several channel groups -- the route a 40-class object map of a full

@@ -1,0 +1,163 @@
+"""The strip path (dm_strip.hip) on the GPU: device-side geometry == the host's, and its maps ==
+the CPU oracle, the host-geometry window path and the generic path, on shapes and flag
+combinations that exercise owned / shared / never-reached groups, with the split forced so
+that small images take it too."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import project_kwargs
+from test_strip_geometry import STRIDE, _case, _geometry
+from test_window_geometry import _params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dmap():
+  import dungeon_maps_amd as dmap
+  from dungeon_maps_amd import _native
+  _native.lib()
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU (run with -m gpu on an MI355X box)")
+  return dmap
+
+
+def _lib():
+  from dungeon_maps_amd import _native
+  return _native.lib()
+
+
+def test_device_geometry_equals_host_geometry(dmap, oracle):
+  """k_strip_geometry_dump evaluates the frame geometry the way k_strip_scatter does (one
+  wave, lane = strip * 8 + corner); windows, union window and the ok flag must equal the
+  host's serial evaluation bit for bit, and so must the cone edges (doubles)."""
+  from dungeon_maps_amd import frames
+  lib = _lib()
+  rng = np.random.default_rng(99)
+  compared = 0
+  for it in range(60):
+    B, H, W, depth, pose, cfg = _case(rng, big_offsets=it % 3 == 0)
+    mh = cfg["map_height"]
+    intr = oracle.camera_intrinsics(W, H, cfg["hfov"], cfg["vfov"])
+    p = _params(B, H, W, cfg, intr)
+    table = frames.build_frame_table(B, pose if cfg["to_global"] else None, cfg["cam_pitch"],
+                                     cfg["cam_height"], cfg["width_offset"], cfg["height_offset"])
+    lib.dm_debug_force_strips(int(rng.integers(1, 9)))
+    try:
+      P, geom, covers, bound = _geometry(lib, p, table, B, mh, with_covers=False)
+      if P <= 0:
+        continue
+      dev = torch.zeros(B * 1024, dtype=torch.uint8, device="cuda")
+      tab_d = table.cuda()
+      got = lib.dm_debug_strip_geometry_dev(ctypes.byref(p), tab_d.data_ptr(), dev.data_ptr(),
+                                            dev.numel(), None)
+      assert got == P
+    finally:
+      lib.dm_debug_force_strips(0)
+    torch.cuda.synchronize()
+    raw = dev.cpu().numpy().reshape(B, 1024)
+    # FrameGeom: Win16 win[8] (64 B), Win16 U (8 B), Line L[8], R[8] (4 doubles each), int ok
+    wins = raw[:, :64].copy().view(np.int16).reshape(B, 8, 4)
+    U = raw[:, 64:72].copy().view(np.int16).reshape(B, 4)
+    ok = raw[:, 72 + 2 * 8 * 32:72 + 2 * 8 * 32 + 4].copy().view(np.int32).reshape(B)
+    np.testing.assert_array_equal(ok != 0, geom[:, 0] != 0)
+    np.testing.assert_array_equal(U.astype(np.int32), geom[:, 4:8])
+    np.testing.assert_array_equal(wins.astype(np.int32).reshape(B, 32), geom[:, 8:40])
+    compared += B
+  assert compared > 40
+
+
+def _projector(dmap, cfg):
+  return dmap.MapProjector(**{k: v for k, v in cfg.items()})
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_strip_path_equals_oracle_and_other_paths(dmap, oracle, seed):
+  lib = _lib()
+  rng = np.random.default_rng(4000 + seed)
+  ran = 0
+  for it in range(14):
+    B, H, W, depth, pose, cfg = _case(rng, big_offsets=(it % 5 == 4))
+    if W % 4:
+      continue
+    value = valid = None
+    if it % 3 == 1:
+      C = int(rng.integers(2, 6))
+      value = rng.uniform(-1, 2, size=(B, C, H, W)).astype(np.float32)
+      cfg["fill_value"] = 0.0 if it % 2 else -np.inf
+    if it % 4 == 2:
+      valid = rng.uniform(0, 1, size=(B, 1, H, W)) > 0.2
+    if it % 7 == 3:
+      cfg["reduction"] = "min"; cfg["fill_value"] = np.inf
+    kw = dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose)
+    want = oracle.orth_project(depth, value_map=value, valid_map=valid, get_height_map=True, **kw)
+    proj = _projector(dmap, cfg)
+    d = torch.from_numpy(depth).cuda()
+    v = None if value is None else torch.from_numpy(value).cuda()
+    m = None if valid is None else torch.from_numpy(valid).cuda()
+    strips = int(rng.integers(1, 9))
+    lib.dm_debug_force_strips(strips)
+    try:
+      got = proj.orth_project(d, value_map=v, valid_map=m, cam_pose=pose, get_height_map=True)
+      path = lib.dm_debug_last_path()
+      fused = proj.orth_project_and_fuse(d, value_map=v, valid_map=m, cam_pose=pose)
+    finally:
+      lib.dm_debug_force_strips(0)
+    torch.cuda.synchronize()
+    if path != 2:
+      continue                     # (a frame the strip path refuses: covered by the other tests)
+    ran += 1
+    np.testing.assert_array_equal(got[1].cpu().numpy(), want[1], err_msg=str((cfg, strips)))
+    np.testing.assert_array_equal(got[0].cpu().numpy(), want[0], err_msg=str((cfg, strips)))
+    np.testing.assert_array_equal(got[2].cpu().numpy(), np.ascontiguousarray(want[2]))
+    assert torch.equal(fused[0], got[0]) and torch.equal(fused[1], got[1])
+    red = torch.amin if cfg["reduction"] == "min" else torch.amax
+    assert torch.equal(fused[2], red(got[0], dim=0))
+    lib.dm_debug_force_legacy_window(1)
+    try:
+      legacy = proj.orth_project(d, value_map=v, valid_map=m, cam_pose=pose)
+      assert lib.dm_debug_last_path() != 2
+    finally:
+      lib.dm_debug_force_legacy_window(0)
+    assert torch.equal(legacy[0], got[0]) and torch.equal(legacy[1], got[1])
+  assert ran >= 6
+
+
+def test_cfg2_full_size_strip_path_vs_oracle(dmap, oracle):
+  """BASELINE configs[1] at full size through the strip path (the path bench.py measures):
+  64 x 640x480 -> 512x512 against the oracle on 8 of the frames, and == the generic path on all."""
+  lib = _lib()
+  B, H, W, mh, mw = 64, 480, 640, 512, 512
+  g = torch.Generator().manual_seed(1234)
+  depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g)
+  pose = torch.empty(B, 3).uniform_(-1, 1, generator=g)
+  pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)
+  cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
+             width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
+             trunc_depth_min=0.15, trunc_depth_max=5.05, clip_border=0, to_global=True,
+             fill_value=-np.inf)
+  proj = dmap.MapProjector(**cfg)
+  d = depth.cuda()
+  top, mask, fused, fmask = proj.orth_project_and_fuse(d, cam_pose=pose)
+  assert lib.dm_debug_last_path() == 2
+  torch.cuda.synchronize()
+  idx = [0, 1, 7, 13, 31, 32, 50, 63]
+  want = oracle.orth_project(depth[idx].numpy(), nthreads=8,
+                             **dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose[idx].numpy()))
+  np.testing.assert_array_equal(mask[idx].cpu().numpy(), want[1])
+  np.testing.assert_array_equal(top[idx].cpu().numpy(), want[0])
+  lib.dm_debug_force_generic_path(1)
+  try:
+    gtop, gmask, gfused, gfmask = proj.orth_project_and_fuse(d, cam_pose=pose)
+  finally:
+    lib.dm_debug_force_generic_path(0)
+  assert torch.equal(gtop, top) and torch.equal(gmask, mask)
+  assert torch.equal(gfused, fused) and torch.equal(gfmask, fmask)
+  # every cell of every map is written on every call: poison the outputs' memory first
+  for _ in range(3):
+    junk = torch.full((B, 1, mh, mw), 123.0, device="cuda"); del junk
+    t2, m2 = proj.orth_project(d, cam_pose=pose)
+    assert torch.equal(t2, top) and torch.equal(m2, mask)

@@ -227,6 +227,7 @@ struct Layout {               // workspace of the strip path
   Win16* g_wins;              // (B, kMaxStrips)
   Win16* g_unions;            // (B)
   int* status;
+  float* sink;                // kSinks x 64 B
   uint32_t* g_covers;         // (B, max_rows, P)
   float* slabs;
   size_t slab_bytes;
@@ -234,7 +235,7 @@ struct Layout {               // workspace of the strip path
 
 size_t tables_bytes(int B, int rows, int P) {
   return up256((size_t)B * sizeof(dm_frame)) + up256((size_t)B * strip::kMaxStrips * sizeof(Win16)) +
-         up256((size_t)B * sizeof(Win16)) + 256 + up256((size_t)B * rows * P * 4);
+         up256((size_t)B * sizeof(Win16)) + 256 + kSinks * 64 + up256((size_t)B * rows * P * 4);
 }
 
 bool carve(void* ws, size_t ws_bytes, int B, int rows, int P, Layout& l) {
@@ -246,6 +247,7 @@ bool carve(void* ws, size_t ws_bytes, int B, int rows, int P, Layout& l) {
   l.g_wins = reinterpret_cast<Win16*>(base); base += up256((size_t)B * strip::kMaxStrips * sizeof(Win16));
   l.g_unions = reinterpret_cast<Win16*>(base); base += up256((size_t)B * sizeof(Win16));
   l.status = reinterpret_cast<int*>(base); base += 256;
+  l.sink = reinterpret_cast<float*>(base); base += kSinks * 64;
   l.g_covers = reinterpret_cast<uint32_t*>(base); base += up256((size_t)B * rows * P * 4);
   l.slabs = reinterpret_cast<float*>(base);
   l.slab_bytes = ws_bytes - t;
@@ -300,7 +302,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const RigBound& rb, 
   sa.depth = depth; sa.value = value; sa.valid = valid;
   sa.slabs = l.slabs;
   sa.out = out; sa.mask = mask; sa.mh = p.mh; sa.mw = p.mw;
-  sa.g_wins = l.g_wins; sa.g_unions = l.g_unions; sa.g_covers = l.g_covers; sa.status = l.status;
+  sa.g_wins = l.g_wins; sa.g_unions = l.g_unions; sa.g_covers = l.g_covers; sa.status = l.status; sa.sink = l.sink;
   sa.cfg = plan.cfg;
   const bool has_valid = valid != nullptr, has_value = value != nullptr;
   const StripKernel kfn = pick_strip_kernel(is_max, has_valid, has_value, plan.lean);

@@ -16,8 +16,9 @@
 namespace dm {
 namespace {
 
+constexpr unsigned kSinks = 256;
 constexpr int kGeomBytes = 1024;          // LDS reserved for the FrameGeom in front of the cover table
-static_assert(sizeof(strip::FrameGeom) <= kGeomBytes, "FrameGeom must fit its LDS slot");
+static_assert(sizeof(strip::FrameGeom) == 592 && sizeof(strip::FrameGeom) <= kGeomBytes, "FrameGeom layout (tests/test_hip_strip.py reads it) and its LDS slot");
 
 struct StripArgs {
   int W, H;
@@ -46,6 +47,7 @@ struct StripArgs {
   Win16* g_unions;            // (B)                 ... and the batch fuse
   uint32_t* g_covers;         // (B, max_rows, P)
   int* status;                // set non-zero when a frame's geometry does not fit the launch
+  float* sink;                // kSinks x 64 bytes: where fill stores with nothing to write go
   strip::Cfg cfg;
 };
 
@@ -223,15 +225,13 @@ k_strip_scatter(StripArgs a) {
   }
 
   // Fill duty (as in k_window_scatter): map rows part, part + P, ... outside the union window
+  // (a store that has nothing to write -- inside U, or past the end -- goes to this workgroup's
+  // sink in the workspace: unlike k_window_scatter's merge, nothing rewrites all of U later, and
+  // other workgroups write owned groups of U while this one fills)
   const int g4 = a.mw >> 2;
   const int fill_rows = (a.mh - part + nparts - 1) / nparts;
   const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
-  int alt_cell = part * a.mw;
-  if (fill_rows > 0 && U.w > 0 && U.h > 0 && U.x0 == 0) {
-    const int last_row = part + (fill_rows - 1) * nparts;
-    if (U.x0 + U.w < a.mw) alt_cell = part * a.mw + U.x0 + U.w;
-    else if (part >= U.z0 && last_row >= U.z0 + U.h) alt_cell = last_row * a.mw;
-  }
+  float* const sink = a.sink + (((unsigned)part + (unsigned)nparts * ((unsigned)chl + (unsigned)bl)) % kSinks) * 16u;
   const bool do_fill = a.out != nullptr && fill_rows > 0;
   const int fill_total = do_fill ? fill_rows * g4 : 0;
   const int fill_steps = (fill_total + kScatterThreads - 1) / kScatterThreads;
@@ -247,11 +247,13 @@ k_strip_scatter(StripArgs a) {
     const int r = part + k * nparts, x = g << 2;
     const bool skip = i >= fill_total || ((unsigned)(r - U.z0) < (unsigned)U.h &&
                                           (unsigned)(x - U.x0) < (unsigned)U.w);
-    int cell = r * a.mw + x;
-    asm("" : "+v"(cell));
-    cell = skip ? alt_cell : cell;
-    *reinterpret_cast<float4*>(a.out + map_base + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
-    *reinterpret_cast<uint32_t*>(a.mask + map_base + cell) = 0u;
+    const size_t cell = map_base + (size_t)(r * a.mw + x);
+    float* po = a.out + cell;
+    uint8_t* pm = a.mask + cell;
+    po = skip ? sink : po;
+    pm = skip ? reinterpret_cast<uint8_t*>(sink + 8) : pm;
+    *reinterpret_cast<float4*>(po) = make_float4(a.fill, a.fill, a.fill, a.fill);
+    *reinterpret_cast<uint32_t*>(pm) = 0u;
   };
   auto publish_geometry = [&]() {
     if (publisher && threadIdx.x < strip::kMaxStrips)

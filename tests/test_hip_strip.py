@@ -58,8 +58,8 @@ def test_device_geometry_equals_host_geometry(dmap, oracle):
     finally:
       lib.dm_debug_force_strips(0)
     torch.cuda.synchronize()
-    raw = dev.cpu().numpy().reshape(B, 1024)
-    # FrameGeom: Win16 win[8] (64 B), Win16 U (8 B), Line L[8], R[8] (4 doubles each), int ok
+    # FrameGeom (592 B): Win16 win[8] (64 B), Win16 U (8 B), Line L[8], R[8] (4 doubles each), int ok
+    raw = dev.cpu().numpy()[:B * 592].reshape(B, 592)
     wins = raw[:, :64].copy().view(np.int16).reshape(B, 8, 4)
     U = raw[:, 64:72].copy().view(np.int16).reshape(B, 4)
     ok = raw[:, 72 + 2 * 8 * 32:72 + 2 * 8 * 32 + 4].copy().view(np.int32).reshape(B)

@@ -69,7 +69,8 @@ _SIGNATURES = {
     "dm_debug_strip_geometry": (ctypes.c_int, [
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dm_debug_strip_geometry_dev": (ctypes.c_int, [
-        ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+        ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+        ctypes.c_void_p]),
     "dm_debug_last_split": (None, [ctypes.POINTER(ctypes.c_int32)]),
     "dm_debug_windows": (ctypes.c_int, [ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),

@@ -24,22 +24,28 @@ void note_split(int pc, int pr, int pd, int path);     // dm_window.hip (dm_debu
 namespace {
 
 inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+constexpr size_t kCfgBytes = 1024;
+static_assert(sizeof(strip::Cfg) <= kCfgBytes, "Cfg slot");
 
-// Pose-independent plan of a call.
+// Pose-independent plan of a call (the parameters alone).
 struct Plan {
-  strip::Cfg cfg;
   int P, wp;
   float res_inv, fx_inv, fy_inv;
   bool lean;
+  int live[strip::kMaxStrips];
+  float ax_lo[strip::kMaxStrips], ax_hi[strip::kMaxStrips];   // ray slopes of each strip's live columns
+  float ay_lo, ay_hi;                                         // ... and of the live rows
 };
 
-// Sizes that hold for every camera yaw / position (same pitch): what the launch is sized with.
-struct RigBound {
+// The plan plus the batch's camera pitch: the device-side Cfg, and launch sizes that hold for
+// every camera yaw / position.
+struct Rig {
   dm_params key;
   float pitch[4];               // Rp[4], Rp[5], Rp[7], Rp[8]
   int slack;                    // cells of slack the bound was computed for
   int P;
   bool valid, fits;
+  strip::Cfg cfg;
   int slab_stride;              // cells of the largest window any strip can have
   int max_rows;                 // rows of the largest union window
   int max_union;                // cells of the largest union window
@@ -67,13 +73,8 @@ bool make_plan(const dm_params& p, Plan& plan) {
     return false;
   plan.P = parts.pc;
   plan.wp = parts.wp;
-  strip::Cfg& c = plan.cfg;
-  memset(&c, 0, sizeof(c));
-  c.P = plan.P; c.mw = p.mw; c.mh = p.mh; c.flip_h = p.flip_h != 0; c.to_global = p.to_global != 0;
-  c.dmin = p.dmin; c.dmax = p.dmax;
-  c.res_inv = 1.0 / (double)p.res;
   const int clip = p.clip_border > 0 ? p.clip_border : 0;
-  int r0 = clip, r1 = p.H - clip;
+  const int r0 = clip, r1 = p.H - clip;
   if (r0 >= r1) return false;
   double ay[2];
   const int rs[2] = {r0, r1 - 1};
@@ -82,18 +83,20 @@ bool make_plan(const dm_params& p, Plan& plan) {
     if (p.flip_h) yr = (double)(p.H - 1) - yr;
     ay[i] = (yr - (double)p.cy) / (double)p.fy;
   }
-  c.ay_lo = ay[0] < ay[1] ? ay[0] : ay[1];
-  c.ay_hi = ay[0] < ay[1] ? ay[1] : ay[0];
+  plan.ay_lo = (float)(ay[0] < ay[1] ? ay[0] : ay[1]);
+  plan.ay_hi = (float)(ay[0] < ay[1] ? ay[1] : ay[0]);
   bool any = false;
-  for (int s = 0; s < plan.P; ++s) {
+  for (int s = 0; s < strip::kMaxStrips; ++s) {
+    plan.live[s] = 0; plan.ax_lo[s] = plan.ax_hi[s] = 0.0f;
+    if (s >= plan.P) continue;
     int q0 = s * plan.wp, q1 = q0 + plan.wp < p.W ? q0 + plan.wp : p.W;
     if (q0 < clip) q0 = clip;
     if (q1 > p.W - clip) q1 = p.W - clip;
-    c.live[s] = q0 < q1;
-    if (!c.live[s]) continue;
+    plan.live[s] = q0 < q1;
+    if (!plan.live[s]) continue;
     any = true;
-    c.ax_lo[s] = ((double)q0 - (double)p.cx) / (double)p.fx;
-    c.ax_hi[s] = ((double)(q1 - 1) - (double)p.cx) / (double)p.fx;
+    plan.ax_lo[s] = (float)(((double)q0 - (double)p.cx) / (double)p.fx);
+    plan.ax_hi[s] = (float)(((double)(q1 - 1) - (double)p.cx) / (double)p.fx);
   }
   if (!any) return false;
   plan.lean = !p.valid_c && isfinite(p.dmin) && !p.has_hmax && p.clip_border <= 0;
@@ -103,9 +106,9 @@ bool make_plan(const dm_params& p, Plan& plan) {
 // The frame records the strip path can take: axis-aligned rotations (the fast arithmetic),
 // one pitch for the batch, finite values; returns the cells of slack that cover every frame
 // (>= what the device computes for it) or -1.
-int validate_frames(const dm_params& p, const strip::Cfg& c, const dm_frame* f, int B) {
+int validate_frames(const dm_params& p, const dm_frame* f, int B) {
   double worst = 0.0;
-  const double inv = c.res_inv;
+  const double inv = 1.0 / (double)p.res;
   for (int b = 0; b < B; ++b) {
     const float* rp = f[b].Rp;
     const float* ry = f[b].Ry;
@@ -115,68 +118,51 @@ int validate_frames(const dm_params& p, const strip::Cfg& c, const dm_frame* f, 
       return -1;
     if (rp[4] != f[0].Rp[4] || rp[5] != f[0].Rp[5] || rp[7] != f[0].Rp[7] || rp[8] != f[0].Rp[8]) return -1;
     double m = fabs((double)f[b].width_offset) + fabs((double)f[b].height_offset) + (double)p.mh;
-    double rot = fabs((double)rp[4]) + fabs((double)rp[5]) + fabs((double)rp[7]) + fabs((double)rp[8]) + 2.0;
-    if (p.to_global) {
-      m += 2.0 * (fabs((double)f[b].tx) + fabs((double)f[b].tz)) * inv;
-      rot *= fabs((double)ry[0]) + fabs((double)ry[2]) + fabs((double)ry[6]) + fabs((double)ry[8]) + 1.0;
-    }
-    m = 2.0 * m + (double)p.dmax * inv * rot * 2.0 + fabs((double)f[b].cam_height) * inv;
+    if (p.to_global) m += 2.0 * (fabs((double)f[b].tx) + fabs((double)f[b].tz)) * inv;
+    m = 2.0 * m;
     if (!(m == m) || !isfinite(m)) return -1;
     if (m > worst) worst = m;
   }
-  const double slack = 2.0 + 8.0 * worst * (1.0 / 8388608.0);
-  if (slack > 16.0) return -1;
-  return (int)ceil(slack);
+  return worst > 1e9 ? -1 : (int)worst;       // (magnitude; the rig adds its reach)
 }
 
-// Bound of the window / union sizes over every yaw (and any position): the truncated cones are
-// rotated in 1440 steps; between two steps an extent grows by at most Rmax * dtheta.
-void compute_bound(const dm_params& p, const Plan& plan, const dm_frame& f0, int slack, RigBound& rb) {
-  const strip::Cfg& c = plan.cfg;
-  rb.key = p; rb.slack = slack; rb.P = plan.P; rb.valid = true; rb.fits = false;
-  rb.pitch[0] = f0.Rp[4]; rb.pitch[1] = f0.Rp[5]; rb.pitch[2] = f0.Rp[7]; rb.pitch[3] = f0.Rp[8];
-  // the cone model must hold (every row looks forward): checked with a neutral pose
-  float rec[23] = {0};
-  memcpy(rec, f0.Rp, 9 * sizeof(float));
-  rec[9] = f0.cam_height;
-  rec[10] = 1.0f; rec[14] = 1.0f; rec[18] = 1.0f;
-  rec[21] = (float)(p.mw / 2); rec[22] = (float)(p.mh / 2);
-  strip::Cfg c0 = c;
-  c0.to_global = 0;
-  const strip::Affine a = strip::frame_affine_f(c0, rec);
-  if (!strip::cone_basis(c0, a).ok) return;
-  // corner vectors in the camera's local frame, in cells (the yaw rotates them rigidly)
-  std::vector<double> cx, cz;
-  std::vector<int> owner;
+// Cfg and launch bound of a rig.  The bound: the truncated cones are rotated in 1440 steps;
+// between two steps an extent grows by at most Rmax * dtheta.
+void compute_rig(const dm_params& p, const Plan& plan, const dm_frame& f0, int magnitude, Rig& rg) {
+  rg.key = p; rg.P = plan.P; rg.valid = true; rg.fits = false;
+  rg.pitch[0] = f0.Rp[4]; rg.pitch[1] = f0.Rp[5]; rg.pitch[2] = f0.Rp[7]; rg.pitch[3] = f0.Rp[8];
+  strip::Cfg& c = rg.cfg;
+  memset(&c, 0, sizeof(c));
+  c.P = plan.P; c.mw = p.mw; c.mh = p.mh; c.flip_h = p.flip_h != 0;
+  c.inv = (float)(1.0 / (double)p.res);
+  memcpy(c.live, plan.live, sizeof(c.live));
+  strip::cfg_rig(c, f0.Rp, plan.ax_lo, plan.ax_hi, plan.ay_lo, plan.ay_hi, p.dmin, p.dmax);
+  // slack that covers every frame of the batch (>= the device's own: same formula, larger m)
+  const double slack_d = 2.0 + 16.0 * ((double)magnitude + 2.0 * (double)c.reach) * (1.0 / 8388608.0) + 0.01;
+  rg.slack = slack_d > 16.0 ? -1 : (int)ceil(slack_d);
+  if (!c.cone_ok || rg.slack < 0) return;
   double rmax = 0.0;
-  for (int s = 0; s < plan.P; ++s) {
-    if (!c.live[s]) continue;
+  for (int s = 0; s < plan.P; ++s)
     for (int k = 0; k < 8; ++k) {
-      double xf, zf;
-      strip::cone_corner(c0, a, c.ax_lo[s], c.ax_hi[s], k, xf, zf);
-      xf -= a.xd; zf -= a.zd;
-      cx.push_back(xf); cz.push_back(zf); owner.push_back(s);
-      const double r = sqrt(xf * xf + zf * zf);
+      const double r = sqrt((double)c.cxl[s][k] * c.cxl[s][k] + (double)c.czl[s][k] * c.czl[s][k]);
       if (r > rmax) rmax = r;
     }
-  }
   if (!isfinite(rmax)) return;
   const int steps = 1440;
   const double dtheta = 2.0 * M_PI / steps;
   const double lip = rmax * dtheta;
-  const double pad_w = lip + 2.0 * slack + 9.0, pad_h = lip + 2.0 * slack + 3.0;
+  const double pad_w = lip + 2.0 * rg.slack + 10.0, pad_h = lip + 2.0 * rg.slack + 4.0;
   double area = 0.0, uw = 0.0, uh = 0.0;
   for (int i = 0; i < steps; ++i) {
     const double cs = cos(i * dtheta), sn = sin(i * dtheta);
     double ulx = INFINITY, uhx = -INFINITY, ulz = INFINITY, uhz = -INFINITY;
     for (int s = 0; s < plan.P; ++s) {
+      if (!c.live[s]) continue;
       double lx = INFINITY, hx = -INFINITY, lz = INFINITY, hz = -INFINITY;
-      for (size_t j = 0; j < cx.size(); ++j) {
-        if (owner[j] != s) continue;
-        const double x = cs * cx[j] + sn * cz[j], z = -sn * cx[j] + cs * cz[j];
+      for (int k = 0; k < 8; ++k) {
+        const double x = cs * c.cxl[s][k] + sn * c.czl[s][k], z = -sn * c.cxl[s][k] + cs * c.czl[s][k];
         lx = x < lx ? x : lx; hx = x > hx ? x : hx; lz = z < lz ? z : lz; hz = z > hz ? z : hz;
       }
-      if (!(hx >= lx)) continue;
       double w = hx - lx + pad_w, h = hz - lz + pad_h;
       if (w > p.mw) w = p.mw;
       if (h > p.mh) h = p.mh;
@@ -188,24 +174,32 @@ void compute_bound(const dm_params& p, const Plan& plan, const dm_frame& f0, int
   }
   if (uw > p.mw) uw = p.mw;
   if (uh > p.mh) uh = p.mh;
-  rb.slab_stride = ((int)ceil(area) + 3) & ~3;
-  rb.max_rows = (int)ceil(uh);
-  rb.max_union = (((int)ceil(uw) + 3) & ~3) * rb.max_rows;
-  const size_t lds = ((size_t)rb.slab_stride + 64) * 4 + kGeomBytes + (size_t)rb.max_rows * plan.P * 4;
-  rb.fits = lds <= (size_t)kMaxLdsBytes;
+  rg.slab_stride = ((int)ceil(area) + 3) & ~3;
+  rg.max_rows = (int)ceil(uh);
+  rg.max_union = (((int)ceil(uw) + 2 * strip::kSpanAlign + 3) & ~3) * rg.max_rows;
+  const size_t lds = ((size_t)rg.slab_stride + 64) * 4 + kGeomBytes + (size_t)rg.max_rows * plan.P * sizeof(strip::RowEntry);
+  rg.fits = lds <= (size_t)kMaxLdsBytes;
 }
 
-const RigBound* rig_bound(const dm_params& p, const Plan& plan, const dm_frame& f0, int slack) {
-  thread_local RigBound slots[4] = {};
+const Rig* rig_of(const dm_params& p, const Plan& plan, const dm_frame& f0, int magnitude) {
+  thread_local Rig slots[4] = {};
+  thread_local int slot_mag[4] = {0, 0, 0, 0};
   thread_local int next = 0;
-  for (RigBound& r : slots)
-    if (r.valid && r.slack == slack && r.P == plan.P && memcmp(&r.key, &p, sizeof(dm_params)) == 0 &&
-        r.pitch[0] == f0.Rp[4] && r.pitch[1] == f0.Rp[5] && r.pitch[2] == f0.Rp[7] && r.pitch[3] == f0.Rp[8])
+  // (the magnitude only matters through the slack it implies: reuse a rig computed for a
+  // magnitude at least as large and at most 2^20 larger -- the same slack up to 2 cells)
+  for (int i = 0; i < 4; ++i) {
+    Rig& r = slots[i];
+    if (r.valid && r.P == plan.P && memcmp(&r.key, &p, sizeof(dm_params)) == 0 &&
+        r.pitch[0] == f0.Rp[4] && r.pitch[1] == f0.Rp[5] && r.pitch[2] == f0.Rp[7] && r.pitch[3] == f0.Rp[8] &&
+        magnitude <= slot_mag[i] && slot_mag[i] - magnitude < (1 << 19))
       return &r;
-  RigBound& r = slots[next];
+  }
+  Rig& r = slots[next];
+  const int mag_up = magnitude < (1 << 18) ? (1 << 18) : magnitude + (1 << 17);   // a little headroom
+  slot_mag[next] = mag_up;
   next = (next + 1) % 4;
-  r = RigBound{};
-  compute_bound(p, plan, f0, slack, r);
+  r = Rig{};
+  compute_rig(p, plan, f0, mag_up, r);
   return &r;
 }
 
@@ -222,35 +216,54 @@ StripKernel pick_strip_kernel(bool is_max, bool has_valid, bool has_value, bool 
   return table[is_max ? 1 : 0][has_valid][has_value][lean && !has_valid];
 }
 
+using MergeKernel = void (*)(StripMergeArgs);
+
+MergeKernel pick_merge_kernel(bool is_max, int P) {
+#define DM_M(M) {k_strip_merge<M, 1>, k_strip_merge<M, 2>, k_strip_merge<M, 3>, k_strip_merge<M, 4>, \
+                 k_strip_merge<M, 5>, k_strip_merge<M, 6>, k_strip_merge<M, 7>, k_strip_merge<M, 8>}
+  static const MergeKernel table[2][strip::kMaxStrips] = {DM_M(kMin), DM_M(kMax)};
+#undef DM_M
+  return table[is_max ? 1 : 0][P - 1];
+}
+
 struct Layout {               // workspace of the strip path
+  strip::Cfg* cfg;            // kCfgBytes in front of the frame records: one copy stages both
   float* frames;              // (B, 32)
   Win16* g_wins;              // (B, kMaxStrips)
   Win16* g_unions;            // (B)
   int* status;
   float* sink;                // kSinks x 64 B
-  uint32_t* g_covers;         // (B, max_rows, P)
+  strip::RowEntry* g_rows;    // (B, max_rows, P)
   float* slabs;
   size_t slab_bytes;
 };
 
 size_t tables_bytes(int B, int rows, int P) {
-  return up256((size_t)B * sizeof(dm_frame)) + up256((size_t)B * strip::kMaxStrips * sizeof(Win16)) +
-         up256((size_t)B * sizeof(Win16)) + 256 + kSinks * 64 + up256((size_t)B * rows * P * 4);
+  return kCfgBytes + up256((size_t)B * sizeof(dm_frame)) + 256 + up256((size_t)B * strip::kMaxStrips * sizeof(Win16)) +
+         up256((size_t)B * sizeof(Win16)) + 256 + kSinks * 64 + up256((size_t)B * rows * P * sizeof(strip::RowEntry));
 }
 
+// [Cfg | frame records | identities] -- staged by ONE copy -- then the slabs, and at the end of
+// the workspace the tables the kernels write (windows, unions, status, sinks, row tables).
 bool carve(void* ws, size_t ws_bytes, int B, int rows, int P, Layout& l) {
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return false;
-  const size_t t = tables_bytes(B, rows, P);
-  if (ws_bytes < t) return false;
+  const size_t head = kCfgBytes + up256((size_t)B * sizeof(dm_frame)) + 256;
+  const size_t tail = up256((size_t)B * strip::kMaxStrips * sizeof(Win16)) + up256((size_t)B * sizeof(Win16)) +
+                      256 + kSinks * 64 + up256((size_t)B * rows * P * sizeof(strip::RowEntry));
+  ws_bytes = ws_bytes / 256 * 256;
+  if (ws_bytes < head + tail) return false;
   unsigned char* base = static_cast<unsigned char*>(ws);
+  l.cfg = reinterpret_cast<strip::Cfg*>(base); base += kCfgBytes;
   l.frames = reinterpret_cast<float*>(base); base += up256((size_t)B * sizeof(dm_frame));
+  base += 256;                                   // identities: the 8 floats in front of the slabs
+  l.slabs = reinterpret_cast<float*>(base);
+  l.slab_bytes = ws_bytes - head - tail;
+  base = static_cast<unsigned char*>(ws) + ws_bytes - tail;
   l.g_wins = reinterpret_cast<Win16*>(base); base += up256((size_t)B * strip::kMaxStrips * sizeof(Win16));
   l.g_unions = reinterpret_cast<Win16*>(base); base += up256((size_t)B * sizeof(Win16));
   l.status = reinterpret_cast<int*>(base); base += 256;
   l.sink = reinterpret_cast<float*>(base); base += kSinks * 64;
-  l.g_covers = reinterpret_cast<uint32_t*>(base); base += up256((size_t)B * rows * P * 4);
-  l.slabs = reinterpret_cast<float*>(base);
-  l.slab_bytes = ws_bytes - t;
+  l.g_rows = reinterpret_cast<strip::RowEntry*>(base);
   return true;
 }
 
@@ -276,7 +289,7 @@ hipError_t raise_lds_limit(const void* key) {
 }
 
 // One pass over the channels of `out`: scatter (+ owned groups straight to the map) and merge.
-hipError_t strip_pass(const dm_params& p, const Plan& plan, const RigBound& rb, const Layout& l,
+hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rb, const Layout& l,
                       const float* depth, const float* value, const uint8_t* valid, float* out,
                       uint8_t* mask, int oc_total, float fill, bool is_max, size_t slab_bytes,
                       hipStream_t s) {
@@ -284,7 +297,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const RigBound& rb, 
   memset(&sa, 0, sizeof(sa));
   sa.W = p.W; sa.H = p.H;
   sa.clip = p.clip_border > 0 ? p.clip_border : 0;
-  sa.flip_h = p.flip_h != 0; sa.to_global = p.to_global != 0;
+  sa.flip_h = p.flip_h != 0;
   sa.cx = p.cx; sa.cy = p.cy; sa.fx = p.fx; sa.fy = p.fy; sa.res = p.res;
   sa.res_inv = plan.res_inv; sa.fx_inv = plan.fx_inv; sa.fy_inv = plan.fy_inv;
   sa.dmin = p.dmin; sa.dmax = p.dmax;
@@ -302,20 +315,23 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const RigBound& rb, 
   sa.depth = depth; sa.value = value; sa.valid = valid;
   sa.slabs = l.slabs;
   sa.out = out; sa.mask = mask; sa.mh = p.mh; sa.mw = p.mw;
-  sa.g_wins = l.g_wins; sa.g_unions = l.g_unions; sa.g_covers = l.g_covers; sa.status = l.status; sa.sink = l.sink;
-  sa.cfg = plan.cfg;
+  sa.g_wins = l.g_wins; sa.g_unions = l.g_unions; sa.g_rows = l.g_rows; sa.status = l.status; sa.sink = l.sink;
+  sa.cfg = l.cfg;
+#ifdef DM_STAMPS
+  sa.stamps = g_stamp_buffer;
+#endif
   const bool has_valid = valid != nullptr, has_value = value != nullptr;
   const StripKernel kfn = pick_strip_kernel(is_max, has_valid, has_value, plan.lean);
   hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn));
   if (e != hipSuccess) return e;
-  const size_t lds_bytes = ((size_t)rb.slab_stride + 64) * 4 + kGeomBytes + (size_t)rb.max_rows * plan.P * 4;
+  const size_t lds_bytes = ((size_t)rb.slab_stride + 64) * 4 + kGeomBytes + (size_t)rb.max_rows * plan.P * sizeof(strip::RowEntry);
   // channel groups: the slabs of one group fit the slab region
   const size_t per_channel = (size_t)p.B * plan.P * rb.slab_stride * 4;
   int group = (int)(slab_bytes / (per_channel ? per_channel : 1));
   if (group < 1) return hipErrorNotSupported;
   if (group > oc_total) group = oc_total;
   if (group > 65535) group = 65535;
-  const int merge_blocks = (rb.max_union / 4 + kMergeThreads - 1) / kMergeThreads;
+  const int merge_blocks = (rb.max_rows + kMergeRowsPerBlock - 1) / kMergeRowsPerBlock;
   for (int ch0 = 0; ch0 < oc_total; ch0 += group) {
     const int oc = oc_total - ch0 < group ? oc_total - ch0 : group;
     sa.oc = oc; sa.ch0 = ch0;
@@ -324,7 +340,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const RigBound& rb, 
     StripMergeArgs ma;
     ma.b0 = 0; ma.oc = oc; ma.ch0 = ch0; ma.oc_total = oc_total; ma.mh = p.mh; ma.mw = p.mw;
     ma.P = plan.P; ma.slab_stride = rb.slab_stride; ma.max_rows = rb.max_rows; ma.fill = fill;
-    ma.g_wins = l.g_wins; ma.g_unions = l.g_unions; ma.g_covers = l.g_covers;
+    ma.g_wins = l.g_wins; ma.g_unions = l.g_unions; ma.g_rows = l.g_rows;
     ma.slabs = l.slabs; ma.out = out; ma.mask = mask;
     // grid.y = frames * channels <= 65535 per launch
     const int per_launch = 65535 / oc > 0 ? 65535 / oc : 1;
@@ -332,8 +348,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const RigBound& rb, 
       const int nb = p.B - b0 < per_launch ? p.B - b0 : per_launch;
       ma.b0 = b0;
       const dim3 g((unsigned)merge_blocks, (unsigned)(nb * oc));
-      e = is_max ? launch(k_strip_merge<kMax>, g, dim3(kMergeThreads), 0, s, ma)
-                 : launch(k_strip_merge<kMin>, g, dim3(kMergeThreads), 0, s, ma);
+      e = launch(pick_merge_kernel(is_max, plan.P), g, dim3(kMergeThreads), 0, s, ma);
       if (e != hipSuccess) return e;
     }
   }
@@ -373,9 +388,9 @@ hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const floa
     plan_valid = true;
   }
   if (!plan_ok) return hipErrorNotSupported;
-  const int slack = validate_frames(p, plan.cfg, frames_host, p.B);
-  if (slack < 0) return hipErrorNotSupported;
-  const RigBound* rb = rig_bound(p, plan, frames_host[0], slack);
+  const int magnitude = validate_frames(p, frames_host, p.B);
+  if (magnitude < 0) return hipErrorNotSupported;
+  const Rig* rb = rig_of(p, plan, frames_host[0], magnitude);
   if (!rb->fits) return hipErrorNotSupported;
   Layout l;
   if (!carve(ws, ws_bytes, p.B, rb->max_rows, plan.P, l)) return hipErrorNotSupported;
@@ -387,14 +402,33 @@ hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const floa
     e = hipEventRecord(before_projection, s);
     if (e != hipSuccess) return e;
   }
-  e = hipMemcpyAsync(l.frames, frames_host, (size_t)p.B * sizeof(dm_frame), hipMemcpyHostToDevice, s);
-  if (e != hipSuccess) return e;
+  {
+    // [Cfg (kCfgBytes) | frame records]: one stream-ordered copy.  The staging buffer is this
+    // thread's (the runtime has copied pageable memory out by the time the call returns).
+    thread_local std::vector<unsigned char> stage;
+    const size_t frames_bytes = up256((size_t)p.B * sizeof(dm_frame));
+    stage.resize(kCfgBytes + frames_bytes + 256);
+    memset(stage.data(), 0, kCfgBytes);
+    memcpy(stage.data(), &rb->cfg, sizeof(strip::Cfg));
+    {   // the reductions' identities, right in front of the slabs (k_strip_merge)
+      float* id = reinterpret_cast<float*>(stage.data() + kCfgBytes + frames_bytes + 256 - 32);
+      for (int i = 0; i < 4; ++i) { id[i] = -INFINITY; id[4 + i] = INFINITY; }
+    }
+    memcpy(stage.data() + kCfgBytes, frames_host, (size_t)p.B * sizeof(dm_frame));
+    if (!p.to_global) {       // local map: neutral yaw, no translation (exact: x * 1 + z * 0 + 0)
+      dm_frame* f = reinterpret_cast<dm_frame*>(stage.data() + kCfgBytes);
+      static const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      for (int b = 0; b < p.B; ++b) { memcpy(f[b].Ry, eye, sizeof(eye)); f[b].tx = 0.0f; f[b].tz = 0.0f; }
+    }
+    e = hipMemcpyAsync(l.cfg, stage.data(), stage.size(), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+  }
   const bool is_max = p.reduction == DM_REDUCE_MAX;
   e = strip_pass(p, plan, *rb, l, depth, value, valid, out, mask, oc_total, p.fill, is_max,
                  l.slab_bytes - hm, s);
   if (e != hipSuccess) return e;
   if (height && value) {      // maps.py:332-350: second projection of the heights, NINF fill, max
-    uint8_t* scratch_mask = static_cast<unsigned char*>(ws) + ws_bytes - hm;
+    uint8_t* scratch_mask = reinterpret_cast<uint8_t*>(l.slabs) + l.slab_bytes - hm;   // (tail of the slab region)
     e = strip_pass(p, plan, *rb, l, depth, nullptr, valid, height, scratch_mask, p.dc, -INFINITY, true,
                    l.slab_bytes - hm, s);
     if (e != hipSuccess) return e;
@@ -443,46 +477,81 @@ extern "C" __attribute__((visibility("default"))) int dm_debug_strip_geometry(
   if (!p || !frames || !out_geom || p->B < 1) return -1;
   Plan plan;
   if (!make_plan(*p, plan)) return 0;
-  const int slack = validate_frames(*p, plan.cfg, frames, p->B);
+  const int magnitude = validate_frames(*p, frames, p->B);
+  if (out_bound) out_bound[0] = out_bound[1] = out_bound[2] = out_bound[3] = out_bound[4] = 0;
+  if (magnitude < 0) {
+    if (out_bound) out_bound[0] = -1;
+    for (int b = 0; b < p->B; ++b) memset(out_geom + (size_t)b * (8 + 4 * strip::kMaxStrips), 0, (8 + 4 * strip::kMaxStrips) * 4);
+    return plan.P;
+  }
+  Rig rg = {};
+  compute_rig(*p, plan, frames[0], magnitude < (1 << 18) ? (1 << 18) : magnitude + (1 << 17), rg);
   if (out_bound) {
-    out_bound[0] = slack; out_bound[1] = out_bound[2] = out_bound[3] = out_bound[4] = 0;
-    if (slack >= 0) {
-      RigBound rb = {};
-      compute_bound(*p, plan, frames[0], slack, rb);
-      out_bound[1] = rb.fits; out_bound[2] = rb.slab_stride; out_bound[3] = rb.max_rows;
-      out_bound[4] = rb.max_union;
-    }
+    out_bound[0] = rg.slack; out_bound[1] = rg.fits; out_bound[2] = rg.slab_stride;
+    out_bound[3] = rg.max_rows; out_bound[4] = rg.max_union;
   }
   const int stride = 8 + 4 * strip::kMaxStrips;
   for (int b = 0; b < p->B; ++b) {
+    dm_frame f = frames[b];
+    if (!p->to_global) {      // as staged for the device: neutral yaw, no translation
+      static const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      memcpy(f.Ry, eye, sizeof(eye)); f.tx = 0.0f; f.tz = 0.0f;
+    }
     strip::FrameGeom g;
-    strip::frame_geometry(plan.cfg, frames[b].Rp, g);
+    strip::frame_geometry(rg.cfg, f.Rp, g);
     int32_t* o = out_geom + (size_t)b * stride;
-    o[0] = g.ok; o[1] = plan.P; o[2] = plan.wp; o[3] = slack;
+    o[0] = g.ok; o[1] = plan.P; o[2] = plan.wp; o[3] = rg.slack;
     o[4] = g.U.x0; o[5] = g.U.z0; o[6] = g.U.w; o[7] = g.U.h;
     for (int s = 0; s < strip::kMaxStrips; ++s) {
       o[8 + 4 * s] = g.win[s].x0; o[9 + 4 * s] = g.win[s].z0;
       o[10 + 4 * s] = g.win[s].w; o[11 + 4 * s] = g.win[s].h;
     }
-    if (out_covers)
-      for (int z = 0; z < p->mh; ++z)
-        for (int s = 0; s < plan.P; ++s)
-          out_covers[((size_t)b * p->mh + z) * plan.P + s] = strip::row_cover(g.win[s], g.L[s], g.R[s], z);
+    if (out_covers) {
+      // (B, mh, P, 2): cover and owned span of every strip on every map row
+      uint32_t cover[strip::kMaxStrips];
+      const int P2 = plan.P <= 4 ? 4 : 8;
+      for (int z = 0; z < p->mh; ++z) {
+        for (int s = 0; s < plan.P; ++s) cover[s] = strip::row_cover(g.win[s], g.L[s], g.R[s], z, p->mw);
+        for (int s = 0; s < plan.P; ++s) {
+          uint32_t* o2 = out_covers + (((size_t)b * p->mh + z) * plan.P + s) * 2;
+          o2[0] = cover[s];
+          o2[1] = strip::row_owned(cover, s, plan.P, P2);
+        }
+      }
+    }
   }
   return plan.P;
 }
 
 // GPU: the same geometry from k_strip_geometry_dump (the device's lane-parallel evaluation),
-// for the test that host and device agree bit for bit.  frames_dev (B, 32) f32, geom_dev
-// B * sizeof(FrameGeom) bytes of device scratch; copies back windows + union + ok as above.
+// for the test that host and device agree bit for bit.  frames_dev (B, 32) f32 (a local map's
+// records with a neutral yaw), frames_host: the same records on the host (for the rig);
+// geom_dev: B * sizeof(FrameGeom) + 1024 bytes of device scratch.
 extern "C" __attribute__((visibility("default"))) int dm_debug_strip_geometry_dev(
-    const dm_params* p, const float* frames_dev, void* geom_dev, size_t geom_bytes, void* stream) {
+    const dm_params* p, const dm_frame* frames_host, const float* frames_dev, void* geom_dev,
+    size_t geom_bytes, void* stream) {
   using namespace dm;
-  if (!p || !frames_dev || !geom_dev || p->B < 1) return -1;
-  if (geom_bytes < (size_t)p->B * sizeof(strip::FrameGeom)) return -(int)sizeof(strip::FrameGeom);
+  if (!p || !frames_host || !frames_dev || !geom_dev || p->B < 1) return -1;
   Plan plan;
   if (!make_plan(*p, plan)) return 0;
-  hipLaunchKernelGGL(k_strip_geometry_dump, dim3(p->B), dim3(64), 0, static_cast<hipStream_t>(stream),
-                     plan.cfg, frames_dev, static_cast<strip::FrameGeom*>(geom_dev));
+  const int magnitude = validate_frames(*p, frames_host, p->B);
+  if (magnitude < 0) return 0;
+  Rig rg = {};
+  compute_rig(*p, plan, frames_host[0], magnitude < (1 << 18) ? (1 << 18) : magnitude + (1 << 17), rg);
+  const size_t need = (size_t)p->B * sizeof(strip::FrameGeom) + kCfgBytes;
+  if (geom_bytes < need) return -(int)need;
+  strip::Cfg* cfg_dev = reinterpret_cast<strip::Cfg*>(static_cast<unsigned char*>(geom_dev) +
+                                                      (size_t)p->B * sizeof(strip::FrameGeom));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(cfg_dev, &rg.cfg, sizeof(strip::Cfg), hipMemcpyHostToDevice, s) != hipSuccess) return -2;
+  if (hipStreamSynchronize(s) != hipSuccess) return -2;       // (rg is a local)
+  hipLaunchKernelGGL(k_strip_geometry_dump, dim3(p->B), dim3(64), 0, s, cfg_dev, frames_dev,
+                     static_cast<strip::FrameGeom*>(geom_dev));
   return hipGetLastError() == hipSuccess ? plan.P : -2;
 }
+
+#ifdef DM_STAMPS
+extern "C" __attribute__((visibility("default"))) void dm_debug_strip_stamp_buffer(long long* dev) {
+  dm::g_stamp_buffer = dev;
+}
+#endif

@@ -5,9 +5,9 @@
 // A frame is cut into P column strips (pr = pd = 1).  With the projector's axis-aligned
 // rotations (pitch about X, yaw about Y) the map position of a pixel with ray slopes (ax, ay)
 // and depth d is
-//     c = A + d * (ax * U + g(ay) * C),     g(ay) = 1 + kappa * ay,
-// A = the camera's cell, U / C = the camera's right / forward direction in cells per metre.
-// So every pixel of a strip lies in the CONE  { A + b * (t * U + C) : b >= 0, t in [tmin, tmax] }
+//     c = A + d * (ax * U + g(ay) * F),     g(ay) = Rp[5] * ay + Rp[8],
+// A = the camera's cell, U / F = the camera's right / forward direction in cells per metre.
+// So every pixel of a strip lies in the CONE  { A + b * (t * U + F) : b >= 0, t in [tmin, tmax] }
 // with t = ax / g over the strip's corner rays, between its near and far depth.  From that:
 //
 //   window  W_p   bounding box of the truncated cone (+ slack), x aligned to 4: the strip's
@@ -22,8 +22,8 @@
 // identical covers -- this file -- and the covers to be supersets, which
 // tests/test_strip_geometry.py checks against per-pixel cells computed on the CPU.
 //
-// Double precision, no libm calls (IEEE +,-,*,/ and floor/ceil only): identical results on
-// host and device.
+// Float32, no libm calls beyond floorf / ceilf (IEEE +,-,*,/ with -ffp-contract=off and
+// correctly rounded division on both sides): identical results on host and device.
 #pragma once
 
 #include <math.h>
@@ -35,194 +35,167 @@ namespace dm {
 namespace strip {
 
 constexpr int kMaxStrips = 8;
+constexpr int kSpanAlign = 4;            // cells: covers / owned spans are whole float4 groups of the map
 
-// Pose-independent part of the geometry: one per call, a kernel argument.
+// Everything of the geometry that does not depend on the camera's yaw and position: the call's
+// parameters plus the batch's camera pitch (dm_strip.hip requires one pitch per batch and
+// builds this once per camera rig).  Lives in device memory in front of the frame records.
 struct Cfg {
   int P;                        // column strips
   int mw, mh;
-  int flip_h, to_global;
-  double ax_lo[kMaxStrips];     // (q - cx) / fx of the strip's first and last live column
-  double ax_hi[kMaxStrips];
+  int flip_h;
+  int cone_ok;                  // every image row looks forward (g > 0): the cone model holds
+  float inv;                    // cells per metre (1 / map_res)
+  float reach;                  // bound of a point's distance from the camera in cells
+  float pad;
   int live[kMaxStrips];         // 0: nothing left of the strip after clip_border
-  double ay_lo, ay_hi;          // min / max of (y - cy) / fy over the live rows
-  double dmin, dmax;            // depth range, 0 <= dmin <= dmax < inf
-  double res_inv;
+  float tmin[kMaxStrips];       // cone edges: t = ax / g over the strip's corner rays
+  float tmax[kMaxStrips];
+  // corners of the strip's truncated cone in the camera's local frame (x right, z forward), in
+  // cells: index bit 0 = near/far, bit 1 = ax lo/hi, bit 2 = ay lo/hi
+  float cxl[kMaxStrips][8];
+  float czl[kMaxStrips][8];
 };
 
 // One frame's geometry (L1): windows and cone edges of every strip.
 // Edge lines in cell coordinates: a cell centre (x, z) is inside the widened cone of strip p
 // iff  L.nx * x + L.nz * z + L.k >= 0  and  R.nx * x + R.nz * z + R.k >= 0.
-struct Line { double nx, nz, k, inv_nx; };
+struct Line { float nx, nz, k, inv_nx; };
 struct FrameGeom {
   Win16 win[kMaxStrips];
   Win16 U;                      // bounding box of the windows, x aligned to 4
   Line L[kMaxStrips], R[kMaxStrips];
   int ok;                       // 0: the cone model does not apply to this frame
+  int pad;
 };
 
-__host__ __device__ inline double dabs(double v) { return v < 0.0 ? -v : v; }
-__host__ __device__ inline double dmin2(double a, double b) { return a < b ? a : b; }
-__host__ __device__ inline double dmax2(double a, double b) { return a > b ? a : b; }
+// Per (map row of the union window, strip): what the strip can reach on that row and the part
+// of it nobody else can -- both [lo, hi) in cells, multiples of 4, packed lo | hi << 16
+// (0 = empty).  owned is a sub-interval of cover that no other strip's cover intersects.
+struct RowEntry { uint32_t cover, owned; };
 
-// Frame record (dm_frame's first 23 floats) -> affine coefficients, as frame_affine() in
-// dm_window_geometry.hpp:  xf = d * (xa*ax + xb*ay + xc) + xd,  zf = d * (za*ax + zb*ay + zc) + zd.
-struct Affine { double xa, xb, xc, xd, za, zb, zc, zd, mag; };
+__host__ __device__ inline float fabs_(float v) { return v < 0.0f ? -v : v; }
+__host__ __device__ inline float fmin2(float a, float b) { return a < b ? a : b; }
+__host__ __device__ inline float fmax2(float a, float b) { return a > b ? a : b; }
+__host__ __device__ inline bool finite_f(float v) { return v == v && v - v == 0.0f; }
 
-__host__ __device__ inline Affine frame_affine_f(const Cfg& c, const float* f) {
-  // f: Rp[0..8], cam_h [9], Ry[10..18], tx [19], tz [20], wo [21], ho [22]
-  double L[3][3], G[3][3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) L[i][j] = (double)f[3 * j + i];
-  const double t1[3] = {0.0, (double)f[9], 0.0};
-  double t2[3];
-  if (c.to_global) {
-    double Y[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) Y[i][j] = (double)f[10 + 3 * j + i];
-    const double tr[3] = {(double)f[19], 0.0, (double)f[20]};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) G[i][j] = Y[i][0] * L[0][j] + Y[i][1] * L[1][j] + Y[i][2] * L[2][j];
-      t2[i] = Y[i][0] * t1[0] + Y[i][1] * t1[1] + Y[i][2] * t1[2] + tr[i];
+// Host: the pitch-dependent part of Cfg from the pitch rotation Rp (row-major, utils.py:326-327;
+// axis-aligned: x1 = X, z1 = Rp[5] * Y + Rp[8] * Z) and the strips' ray slopes.
+//   ax_lo / ax_hi: (q - cx) / fx of each strip's first / last live column;  ay_lo / ay_hi: the
+//   extreme (y - cy) / fy of the live rows;  depth range [dmin, dmax].
+__host__ inline void cfg_rig(Cfg& c, const float* Rp, const float* ax_lo, const float* ax_hi,
+                             float ay_lo, float ay_hi, float dmin, float dmax) {
+  const float p5 = Rp[5], p8 = Rp[8];
+  const float g0 = p5 * ay_lo + p8, g1 = p5 * ay_hi + p8;   // z1 = g * depth
+  c.cone_ok = g0 > 1e-3f && g1 > 1e-3f && finite_f(g0) && finite_f(g1);
+  const float gmax = fmax2(fabs_(g0), fabs_(g1));
+  float amax = 0.0f;
+  for (int s = 0; s < kMaxStrips; ++s) {
+    c.tmin[s] = c.tmax[s] = 0.0f;
+    for (int k = 0; k < 8; ++k) c.cxl[s][k] = c.czl[s][k] = 0.0f;
+    if (s >= c.P || !c.live[s]) continue;
+    amax = fmax2(amax, fmax2(fabs_(ax_lo[s]), fabs_(ax_hi[s])));
+    if (c.cone_ok) {
+      const float t0 = ax_lo[s] / g0, t1 = ax_lo[s] / g1, t2 = ax_hi[s] / g0, t3 = ax_hi[s] / g1;
+      c.tmin[s] = fmin2(fmin2(t0, t1), fmin2(t2, t3));
+      c.tmax[s] = fmax2(fmax2(t0, t1), fmax2(t2, t3));
     }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) G[i][j] = L[i][j];
-      t2[i] = t1[i];
+    for (int k = 0; k < 8; ++k) {
+      const float d = (k & 1) ? dmax : dmin;
+      const float ax = (k & 2) ? ax_hi[s] : ax_lo[s];
+      const float g = (k & 4) ? g1 : g0;
+      c.cxl[s][k] = ax * d * c.inv;
+      c.czl[s][k] = g * d * c.inv;
     }
   }
-  Affine a;
-  const double inv = c.res_inv;
-  a.xa = G[0][0] * inv; a.xb = G[0][1] * inv; a.xc = G[0][2] * inv;
-  a.xd = t2[0] * inv + (double)f[21];
-  double za = G[2][0] * inv, zb = G[2][1] * inv, zc = G[2][2] * inv;
-  double zd = t2[2] * inv + (double)f[22];
-  // magnitude of the float32 intermediates the device's pixel arithmetic goes through
-  // (x2 / res before the offset is added): its rounding error is a few ulp of this
-  a.mag = dmax2(dmax2(dabs(t2[0] * inv), dabs(t2[2] * inv)), dmax2(dabs((double)f[21]), dabs((double)f[22])));
-  if (c.flip_h) { za = -za; zb = -zb; zc = -zc; zd = (double)(c.mh - 1) - zd; }
-  a.za = za; a.zb = zb; a.zc = zc; a.zd = zd;
-  return a;
+  c.reach = dmax * c.inv * (amax + gmax);
 }
 
-// Cells of slack around everything derived from exact arithmetic: the device computes cell
-// coordinates in float32 (error: a few ulp of the largest intermediate, i.e. of
-// mag + reach), the reference does the same float32 operations, so the "true" cell is the
-// float32 one.  2 cells cover map coordinates up to ~2^17; beyond that the slack grows with
-// the magnitude (8 ulp_f32), and past 16 cells the strip path is not used at all.
-__host__ __device__ inline double slack_cells(const Affine& a, double reach) {
-  const double m = a.mag + reach + dabs(a.xd) + dabs(a.zd);
-  return 2.0 + 8.0 * m * (1.0 / 8388608.0);
-}
+// The pose-dependent rest: the yaw rotation's four entries (identity for a local map), the
+// camera's cell A = (xd, zd), the slack in cells around everything derived here.  The device
+// computes cell coordinates in float32 (error: a few ulp of the largest intermediate), the
+// reference does the same float32 operations, so the "true" cell is the float32 one; this
+// geometry is float32 as well.  2 cells cover map coordinates up to ~2^17; beyond that the
+// slack grows with the magnitude (16 ulp_f32), and past 16 cells the strip path is not used.
+struct Pose { float y0, y2, y6, y8, xd, zd, slack; int ok; };
 
-__host__ __device__ inline bool finite_d(double v) { return v == v && v - v == 0.0; }
-
-// Corner k (0..7) of strip p's truncated cone: bit 0 = near/far, bit 1 = ax lo/hi, bit 2 = ay lo/hi.
-__host__ __device__ inline void cone_corner(const Cfg& c, const Affine& a, double ax_lo, double ax_hi,
-                                            int k, double& xf, double& zf) {
-  const double d = (k & 1) ? c.dmax : c.dmin;
-  const double ax = (k & 2) ? ax_hi : ax_lo;
-  const double ay = (k & 4) ? c.ay_hi : c.ay_lo;
-  xf = d * (a.xa * ax + a.xb * ay + a.xc) + a.xd;
-  zf = d * (a.za * ax + a.zb * ay + a.zc) + a.zd;
+__host__ __device__ inline Pose pose_of(const Cfg& c, float y0, float y2, float y6, float y8, float tx,
+                                        float tz, float wo, float ho) {
+  Pose p;
+  const float fs = c.flip_h ? -1.0f : 1.0f;                 // maps.py:1006-1009: zf -> (mh - 1) - zf
+  p.y0 = y0; p.y6 = y6; p.y2 = fs * y2; p.y8 = fs * y8;
+  const float txc = tx * c.inv, tzc = tz * c.inv;
+  p.xd = txc + wo;
+  const float zd = tzc + ho;
+  p.zd = c.flip_h ? (float)(c.mh - 1) - zd : zd;
+  const float mag = fmax2(fmax2(fabs_(txc), fabs_(tzc)), fmax2(fabs_(wo), fabs_(ho)));
+  const float m = mag + c.reach + fabs_(p.xd) + fabs_(p.zd);
+  p.slack = 2.0f + 16.0f * m * (1.0f / 8388608.0f);
+  p.ok = c.cone_ok && finite_f(p.xd) && finite_f(p.zd) && finite_f(y0) && finite_f(y2) &&
+         finite_f(y6) && finite_f(y8) && p.slack <= 16.0f;
+  return p;
 }
 
 // Window from the bounding box [lx, hx] x [lz, hz] of the eight corners.
-__host__ __device__ inline Win16 window_of(const Cfg& c, double lx, double hx, double lz, double hz,
-                                           double slack) {
-  double x0 = floor(lx + 0.5) - slack, x1 = floor(hx + 0.5) + slack + 1.0;
-  double z0 = floor(lz + 0.5) - slack, z1 = floor(hz + 0.5) + slack + 1.0;
-  x0 = floor(x0); z0 = floor(z0); x1 = ceil(x1); z1 = ceil(z1);
-  if (x0 < 0.0) x0 = 0.0;
-  if (z0 < 0.0) z0 = 0.0;
-  if (x1 > (double)c.mw) x1 = (double)c.mw;
-  if (z1 > (double)c.mh) z1 = (double)c.mh;
-  if (!(x0 < x1) || !(z0 < z1)) return Win16{0, 0, 0, 0};
+__host__ __device__ inline Win16 window_of(const Cfg& c, float lx, float hx, float lz, float hz,
+                                           float slack) {
+  float x0 = floorf(floorf(lx + 0.5f) - slack), x1 = ceilf(floorf(hx + 0.5f) + slack + 1.0f);
+  float z0 = floorf(floorf(lz + 0.5f) - slack), z1 = ceilf(floorf(hz + 0.5f) + slack + 1.0f);
+  x0 = x0 < 0.0f ? 0.0f : x0;
+  z0 = z0 < 0.0f ? 0.0f : z0;
+  x1 = x1 > (float)c.mw ? (float)c.mw : x1;
+  z1 = z1 > (float)c.mh ? (float)c.mh : z1;
+  const bool some = (x0 < x1) & (z0 < z1);
   const int ix0 = ((int)x0) & ~3;
   int ixe = ((int)x1 + 3) & ~3;                 // mw % 4 == 0 is a precondition
-  if (ixe > c.mw) ixe = c.mw;
-  return Win16{(short)ix0, (short)(int)z0, (short)(ixe - ix0), (short)((int)z1 - (int)z0)};
+  ixe = ixe > c.mw ? c.mw : ixe;
+  return some ? Win16{(short)ix0, (short)(int)z0, (short)(ixe - ix0), (short)((int)z1 - (int)z0)}
+              : Win16{0, 0, 0, 0};
 }
 
-// The cone's edge parameters of strip p: t = ax / g over the four corner rays.  Returns false
-// when some row of the image does not look forward (g <= 0): no cone then.
-struct ConeBasis { double Ux, Uz, Cx, Cz, kappa, sgn; bool ok; };
-
-__host__ __device__ inline ConeBasis cone_basis(const Cfg& c, const Affine& a) {
-  ConeBasis b;
-  b.Ux = a.xa; b.Uz = a.za; b.Cx = a.xc; b.Cz = a.zc;
-  const double cc = b.Cx * b.Cx + b.Cz * b.Cz;
-  const double vv = a.xb * a.xb + a.zb * a.zb;
-  const double uu = b.Ux * b.Ux + b.Uz * b.Uz;
-  // V = (xb, zb) must be parallel to C (true for pitch about X + yaw about Y): g = 1 + kappa * ay
-  const double cross_vc = a.xb * b.Cz - a.zb * b.Cx;
-  b.kappa = cc > 0.0 ? (a.xb * b.Cx + a.zb * b.Cz) / cc : 0.0;
-  const double sigma = b.Cx * b.Uz - b.Cz * b.Ux;           // cr(C, U)
-  b.sgn = sigma < 0.0 ? -1.0 : 1.0;
-  const double g0 = 1.0 + b.kappa * c.ay_lo, g1 = 1.0 + b.kappa * c.ay_hi;
-  b.ok = cc > 0.0 && uu > 0.0 && finite_d(cc) && finite_d(uu) && finite_d(vv) &&
-         cross_vc * cross_vc <= 1e-18 * vv * cc && dabs(sigma) * dabs(sigma) > 1e-6 * cc * uu &&
-         g0 > 1e-3 && g1 > 1e-3;
-  return b;
-}
-
-__host__ __device__ inline void cone_t_range(const Cfg& c, const ConeBasis& b, int p, double& tmin,
-                                             double& tmax) {
-  const double g0 = 1.0 + b.kappa * c.ay_lo, g1 = 1.0 + b.kappa * c.ay_hi;
-  const double t[4] = {c.ax_lo[p] / g0, c.ax_lo[p] / g1, c.ax_hi[p] / g0, c.ax_hi[p] / g1};
-  tmin = dmin2(dmin2(t[0], t[1]), dmin2(t[2], t[3]));
-  tmax = dmax2(dmax2(t[0], t[1]), dmax2(t[2], t[3]));
-}
-
-// Edge line of the cone through A with direction D = t * U + C.  left: the edge at tmin
-// (inside: t >= tmin), else the edge at tmax.  The margin (half a cell plus the slack, in
-// the line's own units) is folded into k.
-__host__ __device__ inline Line cone_edge(const ConeBasis& b, const Affine& a, double t, bool left,
-                                          double slack) {
-  const double Dx = t * b.Ux + b.Cx, Dz = t * b.Uz + b.Cz;
+// Edge line of the cone through A with direction D = t * U + F (U, F: the camera's right /
+// forward vectors in cells per metre).  left: the edge at tmin (inside: t >= tmin), else the
+// edge at tmax.  The margin (half a cell plus the slack, in the line's own units) is in k.
+__host__ __device__ inline Line cone_edge(const Cfg& c, const Pose& p, float t, bool left) {
+  const float Dx = (t * p.y0 + p.y6) * c.inv, Dz = (t * p.y2 + p.y8) * c.inv;
+  // sgn = sign of cr(F, U) = y6 * y2 - y8 * y0 (orientation: flips with flip_h)
+  const float sgn = (p.y6 * p.y2 - p.y8 * p.y0) < 0.0f ? -1.0f : 1.0f;
   Line l;
-  if (left) { l.nx = -b.sgn * Dz; l.nz = b.sgn * Dx; }      // sgn * cr(D, w)
-  else      { l.nx = b.sgn * Dz;  l.nz = -b.sgn * Dx; }     // sgn * cr(w, D)
-  l.k = -l.nx * a.xd - l.nz * a.zd + (0.5 + slack) * (dabs(l.nx) + dabs(l.nz));
-  l.inv_nx = l.nx != 0.0 ? 1.0 / l.nx : 0.0;
+  l.nx = left ? -sgn * Dz : sgn * Dz;                       // sgn * cr(D, w)  /  sgn * cr(w, D)
+  l.nz = left ? sgn * Dx : -sgn * Dx;
+  l.k = -l.nx * p.xd - l.nz * p.zd + (0.5f + p.slack) * (fabs_(l.nx) + fabs_(l.nz));
+  l.inv_nx = l.nx != 0.0f ? 1.0f / l.nx : 0.0f;
   return l;
 }
 
-// The whole L1 geometry of one frame, serially (host; the device spreads the same calls over
-// the lanes of a wave).
-__host__ __device__ inline void frame_geometry(const Cfg& c, const float* frame_rec, FrameGeom& g) {
-  const Affine a = frame_affine_f(c, frame_rec);
-  const ConeBasis b = cone_basis(c, a);
-  bool fin = finite_d(a.xa) && finite_d(a.xb) && finite_d(a.xc) && finite_d(a.xd) &&
-             finite_d(a.za) && finite_d(a.zb) && finite_d(a.zc) && finite_d(a.zd);
-  const double reach = c.dmax * (dabs(a.xa) + dabs(a.xb) + dabs(a.xc) + dabs(a.za) + dabs(a.zb) + dabs(a.zc));
-  const double slack = slack_cells(a, reach);
-  g.ok = b.ok && fin && slack <= 16.0;
-  int ux0 = c.mw, ux1 = 0, uz0 = c.mh, uz1 = 0;
-  for (int p = 0; p < kMaxStrips; ++p) {
-    g.win[p] = Win16{0, 0, 0, 0};
-    g.L[p] = Line{0.0, 0.0, 0.0, 0.0};
-    g.R[p] = Line{0.0, 0.0, 0.0, 0.0};
-    if (p >= c.P || !c.live[p] || !g.ok) continue;
-    double lx = INFINITY, hx = -INFINITY, lz = INFINITY, hz = -INFINITY;
-    for (int k = 0; k < 8; ++k) {
-      double xf, zf;
-      cone_corner(c, a, c.ax_lo[p], c.ax_hi[p], k, xf, zf);
-      lx = dmin2(lx, xf); hx = dmax2(hx, xf); lz = dmin2(lz, zf); hz = dmax2(hz, zf);
-    }
-    const Win16 w = window_of(c, lx, hx, lz, hz, slack);
-    g.win[p] = w;
-    double tmin, tmax;
-    cone_t_range(c, b, p, tmin, tmax);
-    g.L[p] = cone_edge(b, a, tmin, true, slack);
-    g.R[p] = cone_edge(b, a, tmax, false, slack);
+// One strip's window and cone edges for a pose: the strip's local corners rotated by the yaw.
+__host__ __device__ inline void strip_geometry(const Cfg& c, const Pose& p, const float* cxl,
+                                               const float* czl, float tmin, float tmax, bool live,
+                                               Win16& w, Line& L, Line& R) {
+  float lx = INFINITY, hx = -INFINITY, lz = INFINITY, hz = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float xf = p.y0 * cxl[k] + p.y6 * czl[k] + p.xd;    // maps.py:884-892 in cells
+    const float zf = p.y2 * cxl[k] + p.y8 * czl[k] + p.zd;
+    lx = fmin2(lx, xf); hx = fmax2(hx, xf); lz = fmin2(lz, zf); hz = fmax2(hz, zf);
+  }
+  const bool on = live & (p.ok != 0);
+  const Win16 ww = window_of(c, lx, hx, lz, hz, p.slack);
+  const Line l = cone_edge(c, p, tmin, true), r = cone_edge(c, p, tmax, false);
+  w = on ? ww : Win16{0, 0, 0, 0};
+  L = on ? l : Line{0.0f, 0.0f, 0.0f, 0.0f};
+  R = on ? r : Line{0.0f, 0.0f, 0.0f, 0.0f};
+}
+
+// The whole L1 geometry of one frame, serially (host; the device gives each strip a lane).
+// rec: dm_frame's floats (Ry at [10..18], tx [19], tz [20], offsets [21], [22]).
+__host__ inline void frame_geometry(const Cfg& c, const float* rec, FrameGeom& g) {
+  const Pose p = pose_of(c, rec[10], rec[12], rec[16], rec[18], rec[19], rec[20], rec[21], rec[22]);
+  g.ok = p.ok; g.pad = 0;
+  int ux0 = 32767, ux1 = 0, uz0 = 32767, uz1 = 0;
+  for (int s = 0; s < kMaxStrips; ++s) {
+    strip_geometry(c, p, c.cxl[s], c.czl[s], c.tmin[s], c.tmax[s], s < c.P && c.live[s], g.win[s], g.L[s], g.R[s]);
+    const Win16 w = g.win[s];
     if (w.w > 0) {
       if (w.x0 < ux0) ux0 = w.x0;
       if (w.x0 + w.w > ux1) ux1 = w.x0 + w.w;
@@ -233,34 +206,62 @@ __host__ __device__ inline void frame_geometry(const Cfg& c, const float* frame_
   g.U = ux1 > ux0 ? Win16{(short)ux0, (short)uz0, (short)(ux1 - ux0), (short)(uz1 - uz0)} : Win16{0, 0, 0, 0};
 }
 
-// Cover of strip p on map row z: [lo, hi) in cells, multiples of 4, inside the strip's window;
+// Cover of a strip on map row z: [lo, hi) in cells, multiples of 4, inside the strip's window;
 // packed lo | hi << 16 (0 = empty).
-__host__ __device__ inline uint32_t row_cover(const Win16& w, const Line& L, const Line& R, int z) {
-  if (w.w <= 0 || z < w.z0 || z >= w.z0 + w.h) return 0u;
-  double lo = (double)w.x0, hi = (double)(w.x0 + w.w);      // [lo, hi)
-  const Line* e[2] = {&L, &R};
+__host__ __device__ inline uint32_t row_cover(const Win16& w, const Line& L, const Line& R, int z, int mw) {
+  // (selects, no branches: the device runs this right in front of its pixel loop)
+  const int wx1 = w.x0 + w.w;
+  bool live = (w.w > 0) & (z >= w.z0) & (z < w.z0 + w.h);
+  float lo = (float)w.x0, hi = (float)wx1;                  // [lo, hi)
+#pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const Line& l = *e[i];
-    const double rest = l.nz * (double)z + l.k;             // f = nx * x + rest >= 0
-    if (l.nx > 0.0) {                                       // x >= -rest / nx
-      const double b = ceil(-rest * l.inv_nx - 1e-9);
-      if (b > lo) lo = b;
-    } else if (l.nx < 0.0) {                                // x <= -rest / nx
-      const double b = floor(-rest * l.inv_nx + 1e-9) + 1.0;
-      if (b < hi) hi = b;
-    } else if (rest < 0.0) {
-      return 0u;
-    }
+    const Line& l = i ? R : L;
+    const float rest = l.nz * (float)z + l.k;               // f = nx * x + rest >= 0
+    const float xb = -rest * l.inv_nx;
+    const float bl = ceilf(xb - 0.25f);                     // nx > 0: x >= -rest / nx
+    const float bh = floorf(xb + 0.25f) + 1.0f;             // nx < 0: x <= -rest / nx
+    lo = ((l.nx > 0.0f) & (bl > lo)) ? bl : lo;
+    hi = ((l.nx < 0.0f) & (bh < hi)) ? bh : hi;
+    live = live & !((l.nx == 0.0f) & (rest < 0.0f));
   }
-  if (!(lo < hi)) return 0u;
-  const int ilo = ((int)lo) & ~3;
-  int ihi = ((int)hi + 3) & ~3;
-  if (ihi > w.x0 + w.w) ihi = w.x0 + w.w;
-  return (uint32_t)ilo | ((uint32_t)ihi << 16);
+  live = live & (lo < hi);
+  lo = lo < (float)wx1 ? lo : (float)wx1;                   // (keeps the conversions in range)
+  hi = hi > (float)w.x0 ? hi : (float)w.x0;
+  // Whole 128-byte lines of the map (32 cells): the span may reach past the window, where
+  // nothing can land (the flush writes the fill value there).  Spans that end inside a line
+  // make every kernel that shares the line write a part of it.
+  const int ilo = ((int)lo) & ~(kSpanAlign - 1);
+  int ihi = ((int)hi + kSpanAlign - 1) & ~(kSpanAlign - 1);
+  ihi = ihi > mw ? mw : ihi;
+  return live ? (uint32_t)ilo | ((uint32_t)ihi << 16) : 0u;
 }
 
-__host__ __device__ inline bool in_cover(uint32_t cover, int x) {
-  return x >= (int)(cover & 0xffffu) && x < (int)(cover >> 16);
+// Cuts the span [lo, hi) of one strip's cover down to a part the cover q does not intersect
+// (one step of the owned-span computation; the larger piece is kept when q lies strictly inside).
+__host__ __device__ inline void cut_span(int& lo, int& hi, uint32_t q) {
+  const int ql = (int)(q & 0xffffu), qh = (int)(q >> 16);
+  const bool hit = (qh > lo) & (ql < hi);                   // (an empty cover has qh = 0)
+  const bool left = ql <= lo, right = qh >= hi;             // q reaches over this end of the span
+  const bool keep_left = (ql - lo) >= (hi - qh);            // q strictly inside: keep the larger piece
+  const int nlo = (left & right) ? hi : left ? qh : right ? lo : keep_left ? lo : qh;
+  const int nhi = (left & right) ? hi : left ? hi : right ? ql : keep_left ? ql : hi;
+  lo = hit ? nlo : lo;
+  hi = hit ? nhi : hi;
+}
+
+// The owned span of strip p on a row: its cover cut by the other strips' covers, taken in the
+// order p ^ 1, p ^ 2, ... (the order in which the device's lanes see them).  P2 = 4 or 8.
+__host__ __device__ inline uint32_t row_owned(const uint32_t* cover, int p, int P, int P2) {
+  int lo = (int)(cover[p] & 0xffffu), hi = (int)(cover[p] >> 16);
+  for (int m = 1; m < P2; ++m) {
+    const int q = p ^ m;
+    if (q < P) cut_span(lo, hi, cover[q]);
+  }
+  return hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
+}
+
+__host__ __device__ inline bool in_span(uint32_t span, int x) {
+  return x >= (int)(span & 0xffffu) && x < (int)(span >> 16);
 }
 
 }  // namespace strip

@@ -17,12 +17,12 @@ namespace dm {
 namespace {
 
 constexpr unsigned kSinks = 256;
-constexpr int kGeomBytes = 1024;          // LDS reserved for the FrameGeom in front of the cover table
-static_assert(sizeof(strip::FrameGeom) == 592 && sizeof(strip::FrameGeom) <= kGeomBytes, "FrameGeom layout (tests/test_hip_strip.py reads it) and its LDS slot");
+constexpr int kGeomBytes = 512;           // LDS reserved for the FrameGeom in front of the cover table
+static_assert(sizeof(strip::FrameGeom) == 336 && sizeof(strip::FrameGeom) <= kGeomBytes, "FrameGeom layout (tests/test_hip_strip.py reads it) and its LDS slot");
 
 struct StripArgs {
   int W, H;
-  int clip, flip_h, to_global;
+  int clip, flip_h;
   float cx, cy, fx, fy, res;
   float fx_inv, fy_inv, res_inv;
   float dmin, dmax, hmax;
@@ -45,71 +45,46 @@ struct StripArgs {
   int mh, mw;
   Win16* g_wins;              // (B, kMaxStrips)     published for k_strip_merge
   Win16* g_unions;            // (B)                 ... and the batch fuse
-  uint32_t* g_covers;         // (B, max_rows, P)
+  strip::RowEntry* g_rows;    // (B, max_rows, P)   per row and strip: cover, owned
   int* status;                // set non-zero when a frame's geometry does not fit the launch
   float* sink;                // kSinks x 64 bytes: where fill stores with nothing to write go
-  strip::Cfg cfg;
+#ifdef DM_STAMPS
+  long long* stamps;
+#endif
+  const strip::Cfg* cfg;      // device copy (in front of the frame records): read by wave 0 only
 };
 
-// 64-lane min / max of doubles over groups of `width` lanes (width = 4 or 8: lanes of one strip)
-__device__ inline double wave_min(double v, int width) {
-  for (int m = 1; m < width; m <<= 1) { const double o = __shfl_xor(v, m, 64); v = o < v ? o : v; }
-  return v;
-}
-__device__ inline double wave_max(double v, int width) {
-  for (int m = 1; m < width; m <<= 1) { const double o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
-  return v;
-}
-
-// L1 geometry of one frame by ONE wave: lane = strip * 8 + corner.  Same calls as
-// strip::frame_geometry (the host's serial version), spread over the lanes.
-__device__ inline void strip_geometry_wave(const strip::Cfg& c, const float (&fr)[23], int lane,
+// L1 geometry of one frame by ONE wave: lane s < kMaxStrips derives strip s (the same calls as
+// strip::frame_geometry, the host's serial version), the union window is reduced over the lanes.
+// y0..ho: the frame record's yaw entries, translation and offsets.
+__device__ inline void strip_geometry_wave(const strip::Cfg& c, float y0, float y2, float y6, float y8,
+                                           float tx, float tz, float wo, float ho, int lane,
                                            strip::FrameGeom* g) {
   using namespace strip;
-  const Affine a = frame_affine_f(c, fr);
-  const ConeBasis b = cone_basis(c, a);
-  const bool fin = finite_d(a.xa) && finite_d(a.xb) && finite_d(a.xc) && finite_d(a.xd) &&
-                   finite_d(a.za) && finite_d(a.zb) && finite_d(a.zc) && finite_d(a.zd);
-  const double reach = c.dmax * (dabs(a.xa) + dabs(a.xb) + dabs(a.xc) + dabs(a.za) + dabs(a.zb) + dabs(a.zc));
-  const double slack = slack_cells(a, reach);
-  const int ok = b.ok && fin && slack <= 16.0;
-  const int p = lane >> 3, k = lane & 7;
-  // this lane's strip: selected by compares (a lane-indexed kernel-argument array would go
-  // through scratch memory)
-  double ax_lo = 0.0, ax_hi = 0.0;
-  int live_p = 0;
+  const int s = lane < kMaxStrips ? lane : kMaxStrips - 1;
+  float cx[8], cz[8];
 #pragma unroll
-  for (int s = 0; s < kMaxStrips; ++s) {
-    ax_lo = p == s ? c.ax_lo[s] : ax_lo;
-    ax_hi = p == s ? c.ax_hi[s] : ax_hi;
-    live_p = p == s ? c.live[s] : live_p;
-  }
-  const bool live = p < c.P && live_p && ok;
-  double xf, zf;
-  cone_corner(c, a, ax_lo, ax_hi, k, xf, zf);
-  const double lx = wave_min(xf, 8), hx = wave_max(xf, 8), lz = wave_min(zf, 8), hz = wave_max(zf, 8);
-  Win16 w = window_of(c, lx, hx, lz, hz, slack);
-  if (!live) w = Win16{0, 0, 0, 0};
-  // t = ax / g over the four corner rays (lanes k = 0..3 of the strip), then the two edges
-  const double g0 = 1.0 + b.kappa * c.ay_lo, g1 = 1.0 + b.kappa * c.ay_hi;
-  const double t = ((k & 2) ? ax_hi : ax_lo) / ((k & 1) ? g1 : g0);
-  const double tmin = wave_min(t, 4), tmax = wave_max(t, 4);
-  if (k == 0) {
-    g->win[p] = w;
-    g->L[p] = live ? cone_edge(b, a, tmin, true, slack) : Line{0.0, 0.0, 0.0, 0.0};
-  }
-  if (k == 1) g->R[p] = live ? cone_edge(b, a, tmax, false, slack) : Line{0.0, 0.0, 0.0, 0.0};
-  // union window: over the strips (lanes 0, 8, 16, ...)
-  int ux0 = w.w > 0 ? w.x0 : 32767, ux1 = w.w > 0 ? w.x0 + w.w : 0;
-  int uz0 = w.w > 0 ? w.z0 : 32767, uz1 = w.w > 0 ? w.z0 + w.h : 0;
-  for (int m = 8; m < 64; m <<= 1) {
+  for (int k = 0; k < 8; ++k) { cx[k] = c.cxl[s][k]; cz[k] = c.czl[s][k]; }
+  const float tmin = c.tmin[s], tmax = c.tmax[s];
+  const bool live = (lane < c.P) & (c.live[s] != 0);
+  const Pose p = pose_of(c, y0, y2, y6, y8, tx, tz, wo, ho);
+  Win16 w;
+  Line L, R;
+  strip_geometry(c, p, cx, cz, tmin, tmax, live, w, L, R);
+  if (lane < kMaxStrips) { g->win[lane] = w; g->L[lane] = L; g->R[lane] = R; }
+  const bool some = (lane < kMaxStrips) & (w.w > 0);
+  int ux0 = some ? w.x0 : 32767, ux1 = some ? w.x0 + w.w : 0;
+  int uz0 = some ? w.z0 : 32767, uz1 = some ? w.z0 + w.h : 0;
+#pragma unroll
+  for (int m = 1; m < kMaxStrips; m <<= 1) {
     ux0 = min(ux0, __shfl_xor(ux0, m, 64)); ux1 = max(ux1, __shfl_xor(ux1, m, 64));
     uz0 = min(uz0, __shfl_xor(uz0, m, 64)); uz1 = max(uz1, __shfl_xor(uz1, m, 64));
   }
   if (lane == 0) {
     g->U = ux1 > ux0 ? Win16{(short)ux0, (short)uz0, (short)(ux1 - ux0), (short)(uz1 - uz0)}
                      : Win16{0, 0, 0, 0};
-    g->ok = ok;
+    g->ok = p.ok;
+    g->pad = 0;
   }
 }
 
@@ -167,32 +142,38 @@ k_strip_scatter(StripArgs a) {
     first_rows_loaded = true;
   }
 
-  // the frame record: one batch of scalar loads, pinned
-  float fr[23];
-  {
-    const float* tf = a.frames + (size_t)b * 32;
-#pragma unroll
-    for (int i = 0; i < 23; ++i) fr[i] = tf[i];
-    asm volatile("" : "+s"(fr[0]), "+s"(fr[1]), "+s"(fr[2]), "+s"(fr[3]), "+s"(fr[4]), "+s"(fr[5]),
-                      "+s"(fr[6]), "+s"(fr[7]), "+s"(fr[8]), "+s"(fr[9]), "+s"(fr[10]), "+s"(fr[11]),
-                      "+s"(fr[12]), "+s"(fr[13]), "+s"(fr[14]), "+s"(fr[15]), "+s"(fr[16]),
-                      "+s"(fr[17]), "+s"(fr[18]), "+s"(fr[19]), "+s"(fr[20]), "+s"(fr[21]),
-                      "+s"(fr[22]));
-  }
+  // what the pixel loop needs of the frame record: one batch of scalar loads, pinned (the rest
+  // of the record is read by wave 0 only, for the geometry)
+  const float* tf = a.frames + (size_t)b * 32;
+  float p4 = tf[4], p5 = tf[5], p7 = tf[7], p8 = tf[8], cam_h = tf[9];
+  float fy0 = tf[10], fy2 = tf[12], fy6 = tf[16], fy8 = tf[18], ftx = tf[19], ftz = tf[20];
+  float wo = tf[21], ho = tf[22];
+  asm volatile("" : "+s"(p4), "+s"(p5), "+s"(p7), "+s"(p8), "+s"(cam_h), "+s"(fy0), "+s"(fy2),
+                    "+s"(fy6), "+s"(fy8), "+s"(ftx), "+s"(ftz), "+s"(wo), "+s"(ho));
+#ifdef DM_STAMPS
+  long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  DM_STAMP(0);
   strip::FrameGeom* geom = reinterpret_cast<strip::FrameGeom*>(lds + a.table_off);
-  uint32_t* covers = reinterpret_cast<uint32_t*>(lds + a.table_off + kGeomBytes / 4);
+  strip::RowEntry* rows = reinterpret_cast<strip::RowEntry*>(lds + a.table_off + kGeomBytes / 4);
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const float lds_init = a.fill;
   // Wave 0 derives the frame's geometry while the others initialise the whole window region
   // of LDS (the window's size is not known before the geometry is).
-  if (wave == 0) {
-    strip_geometry_wave(a.cfg, fr, (int)threadIdx.x & 63, geom);
-  }
+  if (wave == 0)
+    strip_geometry_wave(*a.cfg, fy0, fy2, fy6, fy8, ftx, ftz, wo, ho, (int)threadIdx.x & 63, geom);
+  DM_STAMP(1);
   for (int i = threadIdx.x * 4; i < a.slab_stride + 64; i += kScatterThreads * 4)
     *reinterpret_cast<float4*>(lds + i) = make_float4(lds_init, lds_init, lds_init, lds_init);
   lds_barrier();
+  DM_STAMP(2);
   Window w = widen(geom->win[part]);
   Window U = widen(geom->U);
+  {   // the union window in whole 128-byte lines (covers reach that far)
+    const int ux1 = min((U.x0 + U.w + strip::kSpanAlign - 1) & ~(strip::kSpanAlign - 1), a.mw);
+    U.x0 &= ~(strip::kSpanAlign - 1);
+    U.w = U.w > 0 ? ux1 - U.x0 : 0;
+  }
   {
     // wave-uniform values: keep them in SGPRs
     w.x0 = __builtin_amdgcn_readfirstlane(w.x0); w.z0 = __builtin_amdgcn_readfirstlane(w.z0);
@@ -208,22 +189,29 @@ k_strip_scatter(StripArgs a) {
     U = Window{0, 0, 0, 0};
   }
   const int area = w.w * w.h;
-  {
-    const int wv = wave;
-    if (wv >= 12) __builtin_amdgcn_s_setprio(3);
-    else if (wv >= 8) __builtin_amdgcn_s_setprio(2);
-    else if (wv >= 4) __builtin_amdgcn_s_setprio(1);
-  }
-  // cover table of the frame: one map row of the union window per thread, every strip's cover
+  // Row table of the frame (cover and owned span of every strip on every row of the union
+  // window): built right before the pixel loop, under the first depth loads in flight, by all
+  // threads -- thread = (row, strip), the strips of a row in neighbouring lanes, which
+  // exchange their covers by shuffles.  Read back only behind the barrier that ends the loop.
   const bool publisher = part == 0 && chl == 0;
-  for (int r = threadIdx.x; r < U.h; r += kScatterThreads) {
-    for (int p = 0; p < nparts; ++p) {
-      const uint32_t cv = strip::row_cover(geom->win[p], geom->L[p], geom->R[p], U.z0 + r);
-      covers[r * nparts + p] = cv;
-      if (publisher) a.g_covers[((size_t)b * a.max_rows + r) * nparts + p] = cv;
+  auto build_rows = [&]() {
+    const int P2 = nparts <= 4 ? 4 : 8;
+    const int sub = (int)threadIdx.x & (P2 - 1);
+    const int per_pass = kScatterThreads / P2;
+    for (int r = (int)threadIdx.x / P2; r < U.h; r += per_pass) {
+      const int ps = sub < nparts ? sub : 0;
+      uint32_t cover = strip::row_cover(geom->win[ps], geom->L[ps], geom->R[ps], U.z0 + r, a.mw);
+      cover = sub < nparts ? cover : 0u;
+      int lo = (int)(cover & 0xffffu), hi = (int)(cover >> 16);
+      for (int m = 1; m < P2; ++m) strip::cut_span(lo, hi, (uint32_t)__shfl_xor((int)cover, m, 64));
+      const strip::RowEntry e = {cover, hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u};
+      if (sub < nparts) {
+        rows[r * nparts + sub] = e;
+        if (publisher) a.g_rows[((size_t)b * a.max_rows + r) * nparts + sub] = e;
+      }
     }
-  }
-
+  };
+  DM_STAMP(3);
   // Fill duty (as in k_window_scatter): map rows part, part + P, ... outside the union window
   // (a store that has nothing to write -- inside U, or past the end -- goes to this workgroup's
   // sink in the workspace: unlike k_window_scatter's merge, nothing rewrites all of U later, and
@@ -245,8 +233,8 @@ k_strip_scatter(StripArgs a) {
     k += ((k + 1) * g4 <= i);
     const int g = i - k * g4;
     const int r = part + k * nparts, x = g << 2;
-    const bool skip = i >= fill_total || ((unsigned)(r - U.z0) < (unsigned)U.h &&
-                                          (unsigned)(x - U.x0) < (unsigned)U.w);
+    const bool skip = (i >= fill_total) | (((unsigned)(r - U.z0) < (unsigned)U.h) &
+                                           ((unsigned)(x - U.x0) < (unsigned)U.w));   // (no branch)
     const size_t cell = map_base + (size_t)(r * a.mw + x);
     float* po = a.out + cell;
     uint8_t* pm = a.mask + cell;
@@ -261,12 +249,8 @@ k_strip_scatter(StripArgs a) {
     if (publisher && threadIdx.x == 0) a.g_unions[b] = narrow16(U);
   };
 
-  const bool glob = a.to_global != 0;
-  const float p4 = fr[4], p5 = fr[5], p7 = fr[7], p8 = fr[8];
-  const float y0 = glob ? fr[10] : 1.0f, y2r = glob ? fr[12] : 0.0f;
-  const float y6 = glob ? fr[16] : 0.0f, y8 = glob ? fr[18] : 1.0f;
-  const float cam_h = fr[9], tx = glob ? fr[19] : 0.0f, tz = glob ? fr[20] : 0.0f;
-  const float wo = fr[21], ho = fr[22];
+  // (a local map's records carry a neutral yaw and no translation: dm_strip.hip stage_frames)
+  const float y0 = fy0, y2r = fy2, y6 = fy6, y8 = fy8, tx = ftx, tz = ftz;
   const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
   const unsigned dummy = (unsigned)a.slab_stride + (threadIdx.x & 63u);   // 64 scratch cells
 
@@ -327,10 +311,12 @@ k_strip_scatter(StripArgs a) {
             // maps.py:537-544, 286-288, 1150-1158
             const unsigned ux = (unsigned)(floor_to_int(xf) - w.x0);
             const unsigned uz = (unsigned)(floor_to_int(zf) - w.z0);
-            bool ok = ux < (unsigned)w.w && uz < (unsigned)w.h && zz >= a.dmin && zz <= a.dmax;
-            if (!LEAN) ok = ok && !__builtin_isunordered(xf, zf) && h1 <= a.hmax;
+            // (bitwise &: the short-circuit form compiles to a branch per pixel, and a branch in
+            // this loop costs its counted waits)
+            bool ok = (ux < (unsigned)w.w) & (uz < (unsigned)w.h) & (zz >= a.dmin) & (zz <= a.dmax);
+            if (!LEAN) ok = ok & !__builtin_isunordered(xf, zf) & (h1 <= a.hmax);
             const float sval = HAS_VALUE ? sv[u][k] : h1;
-            if (HAS_VALUE) ok = ok && (sval == sval);            // NaN never replaces a number
+            if (HAS_VALUE) ok = ok & (sval == sval);             // NaN never replaces a number
             unsigned cell = __umul24(uz, (unsigned)w.w) + ux;
             asm("" : "+v"(cell));
             li[k] = ok ? cell : dummy;
@@ -355,8 +341,21 @@ k_strip_scatter(StripArgs a) {
         int r = r0 + gy;
         if (!first_rows_loaded) load_rows(za, va, r);
         first_rows_loaded = false;
+        // (the row table is built here, under the first depth rows in flight, and NOT inside the
+        // loop: a branch in the loop body makes the compiler drain its counted waits)
+        // two groups of rows in flight while the row table is built (VALU + LDS only)
+        load_rows(zb_, vb_, r + step);
+        DM_STAMP(7);
+        if (g == gx) build_rows();
+        DM_STAMP(8);
+        // younger waves of a SIMD get the higher issue priority in the loop (age arbitration
+        // favours the oldest wave otherwise, and the last wave left on a SIMD runs latency
+        // bound).  Only now: under static priorities the four waves of a SIMD run the code
+        // above one after the other instead of hiding each other's latencies.
+        if (wave >= 12) __builtin_amdgcn_s_setprio(3);
+        else if (wave >= 8) __builtin_amdgcn_s_setprio(2);
+        else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
         for (int it = 0; it < niter; it += 2) {
-          load_rows(zb_, vb_, r + step);
           if (kFill) {
 #pragma unroll
             for (int t = 0; t < kFillPerHalf; ++t) fill_step();
@@ -369,6 +368,7 @@ k_strip_scatter(StripArgs a) {
               for (int t = 0; t < kFillPerHalf; ++t) fill_step();
             }
             project_rows(zb_, vb_, r + step);
+            load_rows(zb_, vb_, r + 3 * step);        // (past the end: the last row again, unused)
           }
           r += 2 * step;
         }
@@ -376,39 +376,45 @@ k_strip_scatter(StripArgs a) {
       if (do_fill) pipeline(std::true_type{}); else pipeline(std::false_type{});
     }
   }
+  if (area == 0 || nx == 0) build_rows();     // (no pixel loop ran: the table is still owed to k_strip_merge)
+  DM_STAMP(4);
   while (fs < fill_steps) fill_step();
+  __builtin_amdgcn_s_setprio(0);
   lds_barrier();
+  DM_STAMP(5);
   if (area > 0) {
-    // Flush: a group of the window inside this strip's cover goes straight to the map when no
-    // other strip's cover holds it, else to the slab (k_strip_merge combines those).
+    // Flush: 16 lanes per window row.  The groups of this strip's cover go straight to the map
+    // where the strip owns them (no other strip's cover reaches them), else to the slab, which
+    // k_strip_merge combines with the other strips'.
     const int pid = (b * a.oc + chl) * nparts + part;
     float* slab = a.slabs + (size_t)pid * a.slab_stride;
-    const int wg4 = w.w >> 2;
-    const int groups = wg4 * w.h;
-    const float wg4_inv = 1.0f / (float)wg4;
-    for (int i = threadIdx.x; i < groups; i += kScatterThreads) {
-      int row = (int)((float)i * wg4_inv);
-      row -= (row * wg4 > i);
-      row += ((row + 1) * wg4 <= i);
-      const int x = w.x0 + ((i - row * wg4) << 2), z = w.z0 + row;
-      const uint32_t* cv = covers + (z - U.z0) * nparts;
-      if (!strip::in_cover(cv[part], x)) continue;
-      bool shared = false;
-      for (int p = 0; p < nparts; ++p) shared = shared || (p != part && strip::in_cover(cv[p], x));
-      const float4 v = *reinterpret_cast<const float4*>(lds + i * 4);
-      if (shared || a.out == nullptr) {
-        *reinterpret_cast<float4*>(slab + i * 4) = v;
-      } else {
-        const size_t cell = map_base + (size_t)z * a.mw + x;
-        *reinterpret_cast<float4*>(a.out + cell) = v;
-        const uint32_t mk = (uint32_t)mask_of(v.x, a.fill) | ((uint32_t)mask_of(v.y, a.fill) << 8) |
-                            ((uint32_t)mask_of(v.z, a.fill) << 16) |
-                            ((uint32_t)mask_of(v.w, a.fill) << 24);
-        *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+    const int l16 = (int)threadIdx.x & 15;
+    for (int row = (int)threadIdx.x >> 4; row < w.h; row += kScatterThreads / 16) {
+      const int z = w.z0 + row;
+      const strip::RowEntry e = rows[(z - U.z0) * nparts + part];
+      const int lo = (int)(e.cover & 0xffffu), hi = (int)(e.cover >> 16);
+      const int cell0 = row * w.w - w.x0;
+      for (int x = lo + (l16 << 2); x < hi; x += 64) {
+        // (a span is whole 128-byte lines: outside the window nothing landed)
+        const bool inside = (unsigned)(x - w.x0) < (unsigned)w.w;
+        float4 v = make_float4(a.fill, a.fill, a.fill, a.fill);
+        if (inside) v = *reinterpret_cast<const float4*>(lds + cell0 + x);
+        if (strip::in_span(e.owned, x) && a.out != nullptr) {
+          const size_t cell = map_base + (size_t)z * a.mw + x;
+          *reinterpret_cast<float4*>(a.out + cell) = v;
+          const uint32_t mk = (uint32_t)mask_of(v.x, a.fill) | ((uint32_t)mask_of(v.y, a.fill) << 8) |
+                              ((uint32_t)mask_of(v.z, a.fill) << 16) |
+                              ((uint32_t)mask_of(v.w, a.fill) << 24);
+          *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+        } else if (inside) {
+          *reinterpret_cast<float4*>(slab + cell0 + x) = v;
+        }
       }
     }
   }
   publish_geometry();
+  DM_STAMP(6);
+  DM_STAMPS_OUT();
 }
 
 struct StripMergeArgs {
@@ -417,62 +423,125 @@ struct StripMergeArgs {
   float fill;
   const Win16* g_wins;
   const Win16* g_unions;
-  const uint32_t* g_covers;
-  const float* slabs;
+  const strip::RowEntry* g_rows;
+  const float* slabs;         // (the 8 floats in front of it: -inf x 4, +inf x 4)
   float* out;
   uint8_t* mask;
 };
 
-// One thread per float4 group of a frame's union window: groups in exactly one cover were
-// written by k_strip_scatter; groups in none get the fill value; the others the max / min of
-// the slabs of the strips covering them.
-template <int RED>
+constexpr int kMergeRowsPerWave = 4;
+constexpr int kMergeRowsPerBlock = kMergeThreads / 64 * kMergeRowsPerWave;
+static_assert(strip::kSpanAlign == 4, "k_strip_merge reads a slab wherever a cover is: covers must lie inside the windows");
+
+// One wave per kMergeRowsPerWave map rows of a frame's union window, lanes along the row: a
+// group inside some strip's owned span was written by k_strip_scatter; every other group gets
+// the max / min of the slabs of the strips whose covers hold it (the fill value where none
+// does).  The kernel is bound by instruction issue (16 K rows of a few groups each), so what a
+// row needs is kept wave-uniform -- lane p fetches strip p's row entry and window in one batch
+// of loads, the values are broadcast from the lanes, the span arithmetic runs on the scalar
+// unit -- and P is a template parameter: P slab loads in flight per row, no loop.  Strips with
+// nothing for a group load `ident` (a float4 of the reduction's identity) instead.
+template <int RED, int P>
 __global__ void __launch_bounds__(kMergeThreads)
 k_strip_merge(StripMergeArgs a) {
   const int fcl = blockIdx.y;                  // (frame of the launch) * oc + channel of the group
   const int bl = fcl / a.oc, b = a.b0 + bl;
   const int chl = fcl - bl * a.oc;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = (int)threadIdx.x & 63;
+  const int row0 = (blockIdx.x * (kMergeThreads / 64) + wave) * kMergeRowsPerWave;
+  if (row0 >= a.max_rows) return;
+  const int pi = lane < P ? lane : P - 1;
+  const Win16 wv = a.g_wins[(size_t)b * strip::kMaxStrips + pi];
   const Window U = widen(a.g_unions[b]);
-  const int ug4 = U.w >> 2;
-  const int total = ug4 * U.h;
-  const int i = blockIdx.x * kMergeThreads + threadIdx.x;
-  if (i >= total) return;
-  const int row = i / ug4;
-  const int zb = U.z0 + row, x = U.x0 + ((i - row * ug4) << 2);
-  const uint32_t* cv = a.g_covers + ((size_t)b * a.max_rows + row) * a.P;
-  int count = 0;
-  for (int p = 0; p < a.P; ++p) count += strip::in_cover(cv[p], x) ? 1 : 0;
-  if (count == 1) return;
-  float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
-  if (count >= 2) {
-    const float* slabs = a.slabs + ((size_t)(b * a.oc + chl) * a.P) * a.slab_stride;
-    for (int p = 0; p < a.P; ++p) {
-      if (!strip::in_cover(cv[p], x)) continue;
-      const Window w = widen(a.g_wins[(size_t)b * strip::kMaxStrips + p]);
-      const float4 s = *reinterpret_cast<const float4*>(
-          slabs + (size_t)p * a.slab_stride + (size_t)(zb - w.z0) * w.w + (x - w.x0));
-      acc.x = combine<RED>(acc.x, s.x);
-      acc.y = combine<RED>(acc.y, s.y);
-      acc.z = combine<RED>(acc.z, s.z);
-      acc.w = combine<RED>(acc.w, s.w);
-    }
+  const strip::RowEntry* re = a.g_rows + ((size_t)b * a.max_rows + row0) * P + pi;
+  strip::RowEntry ev[kMergeRowsPerWave];
+#pragma unroll
+  for (int k = 0; k < kMergeRowsPerWave; ++k)   // (rows past max_rows: clamped, unused)
+    ev[k] = re[(size_t)(row0 + k < a.max_rows ? k : 0) * P];
+  int wxz = (int)(uint16_t)wv.x0 | ((int)(uint16_t)wv.z0 << 16), www = (int)(uint16_t)wv.w;
+  // The lanes' values are read across lanes inside divergent code below: they must exist in
+  // EVERY lane, i.e. be loaded here, where all lanes are active (left to itself the compiler
+  // sinks the loads to their uses, where only the lanes of the row's groups execute them).
+  asm volatile("" : "+v"(wxz), "+v"(www));
+#pragma unroll
+  for (int k = 0; k < kMergeRowsPerWave; ++k) asm volatile("" : "+v"(ev[k].cover), "+v"(ev[k].owned));
+  // Lane p prepares strip p's numbers for every row (vector ALU, all strips at once: the scalar
+  // unit is shared by the CU's waves and would be the bottleneck of this kernel); they are
+  // broadcast from the lanes where they are used.
+  //   base: where cell (0, 0) of the map would lie in the strip's slab, as a 32-bit float index
+  //         relative to `slabs` (the slabs of one channel group hold fewer than 2^31 floats)
+  const int ww_l = www;
+  const int base_l = pi * a.slab_stride - (wxz >> 16) * ww_l - (int)(int16_t)(wxz & 0xffff);
+  int clo_l[kMergeRowsPerWave], olo_l[kMergeRowsPerWave], ohi_l[kMergeRowsPerWave],
+      chi_l[kMergeRowsPerWave], off_l[kMergeRowsPerWave];
+#pragma unroll
+  for (int k = 0; k < kMergeRowsPerWave; ++k) {
+    const uint32_t cover = ev[k].cover, owned = ev[k].owned;
+    clo_l[k] = (int)(cover & 0xffffu); chi_l[k] = (int)(cover >> 16);
+    olo_l[k] = owned ? (int)(owned & 0xffffu) : clo_l[k];      // (no owned span: an empty one at clo)
+    ohi_l[k] = owned ? (int)(owned >> 16) : clo_l[k];
+    off_l[k] = base_l + (U.z0 + row0 + k) * ww_l;
+    // (read across lanes inside divergent code below: must be computed here, in every lane)
+    asm volatile("" : "+v"(clo_l[k]), "+v"(olo_l[k]), "+v"(ohi_l[k]), "+v"(chi_l[k]), "+v"(off_l[k]));
   }
   const size_t fo = (size_t)b * a.oc_total + a.ch0 + chl;
-  const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw + x;
-  *reinterpret_cast<float4*>(a.out + cell) = acc;
-  const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
-                      ((uint32_t)mask_of(acc.z, a.fill) << 16) |
-                      ((uint32_t)mask_of(acc.w, a.fill) << 24);
-  *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
+  const float* slabs = a.slabs + ((size_t)(b * a.oc + chl) * P) * a.slab_stride;
+  // the reduction's identity as a float4 in memory, 8 (max) / 4 (min) floats in front of the slabs
+  const int ident_at = (int)(a.slabs - slabs) - (RED == kMax ? 8 : 4);
+  const float ident = RED == kMax ? -INFINITY : INFINITY;
+#pragma unroll
+  for (int k = 0; k < kMergeRowsPerWave; ++k) {
+    const int row = row0 + k;
+    if (row >= U.h) break;                     // wave-uniform
+    const int zb = U.z0 + row;
+    float* const out_row = a.out + fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw;
+    uint8_t* const mask_row = a.mask + fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw;
+    // per strip: the two pieces of its cover around its owned span, its slab row's offset
+    int clo[P], olo[P], ohi[P], chi[P], off[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      clo[p] = __builtin_amdgcn_readlane(clo_l[k], p); olo[p] = __builtin_amdgcn_readlane(olo_l[k], p);
+      ohi[p] = __builtin_amdgcn_readlane(ohi_l[k], p); chi[p] = __builtin_amdgcn_readlane(chi_l[k], p);
+      off[p] = __builtin_amdgcn_readlane(off_l[k], p);
+    }
+    for (int x = U.x0 + (lane << 2); x < U.x0 + U.w; x += 256) {
+      bool is_owned = false;
+      float4 sv[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        is_owned = is_owned | ((x >= olo[p]) & (x < ohi[p]));
+        const bool hit = ((x >= clo[p]) & (x < olo[p])) | ((x >= ohi[p]) & (x < chi[p]));
+        const int at = hit ? off[p] + x : ident_at;
+        sv[p] = *reinterpret_cast<const float4*>(slabs + at);
+      }
+      float4 acc = make_float4(ident, ident, ident, ident);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        acc.x = combine<RED>(acc.x, sv[p].x);
+        acc.y = combine<RED>(acc.y, sv[p].y);
+        acc.z = combine<RED>(acc.z, sv[p].z);
+        acc.w = combine<RED>(acc.w, sv[p].w);
+      }
+      // (the fill value takes part: utils.py:470-477 reduces INTO the filled canvas)
+      acc.x = combine<RED>(acc.x, a.fill); acc.y = combine<RED>(acc.y, a.fill);
+      acc.z = combine<RED>(acc.z, a.fill); acc.w = combine<RED>(acc.w, a.fill);
+      if (is_owned) continue;
+      *reinterpret_cast<float4*>(out_row + x) = acc;
+      const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+                          ((uint32_t)mask_of(acc.z, a.fill) << 16) |
+                          ((uint32_t)mask_of(acc.w, a.fill) << 24);
+      *reinterpret_cast<uint32_t*>(mask_row + x) = mk;
+    }
+  }
 }
 
 // Test hook kernel: the geometry of every frame exactly as k_strip_scatter derives it.
 __global__ void __launch_bounds__(64)
-k_strip_geometry_dump(strip::Cfg cfg, const float* frames, strip::FrameGeom* out) {
+k_strip_geometry_dump(const strip::Cfg* cfg, const float* frames, strip::FrameGeom* out) {
   __shared__ strip::FrameGeom g;
-  float fr[23];
-  for (int i = 0; i < 23; ++i) fr[i] = frames[(size_t)blockIdx.x * 32 + i];
-  strip_geometry_wave(cfg, fr, (int)threadIdx.x, &g);
+  const float* f = frames + (size_t)blockIdx.x * 32;
+  strip_geometry_wave(*cfg, f[10], f[12], f[16], f[18], f[19], f[20], f[21], f[22], (int)threadIdx.x, &g);
   __syncthreads();
   if (threadIdx.x == 0) out[blockIdx.x] = g;
 }

@@ -299,14 +299,16 @@ int dm_debug_force_bands(int on);
  *                                the given frames exactly as the kernels derive it.
  *                                out_geom (B, 8 + 4*8) int32 per frame: {ok, strips P, strip
  *                                width, slack cells, union window x0, z0, w, h, then 8 strip
- *                                windows {x0, z0, w, h}}; out_covers (B, mh, P) uint32 or NULL:
- *                                per map row and strip the cells [lo, hi) the strip can reach,
- *                                packed lo | hi << 16 (0 = none); out_bound[5] or NULL: {slack,
+ *                                windows {x0, z0, w, h}}; out_covers (B, mh, P, 2) uint32 or NULL:
+ *                                per map row and strip the cells [lo, hi) the strip can reach
+ *                                and the sub-span only it can reach (written straight to the
+ *                                map), packed lo | hi << 16 (0 = none); out_bound[5] or NULL: {slack,
  *                                fits LDS, window cells, union rows, union cells} the launch
  *                                is sized with (valid for every yaw / position of the camera).
  *                                Returns P, 0 when the strip path does not apply to `p`.
  *   dm_debug_strip_geometry_dev  the same windows / edges from the device's own evaluation
- *                                (geom_dev: B * 1024 bytes of device scratch, copied back by
+ *                                (frames on the host and on the device; geom_dev: B * 336 + 1024 bytes of 8-byte
+ *                                aligned device scratch, copied back by
  *                                the caller); returns P, 0 (not applicable) or < 0.
  */
 int dm_debug_last_path(void);
@@ -314,8 +316,9 @@ int dm_debug_force_legacy_window(int on);
 int dm_debug_force_strips(int strips);
 int dm_debug_strip_geometry(const dm_params* p, const dm_frame* frames, int32_t* out_geom,
                             uint32_t* out_covers, int32_t* out_bound);
-int dm_debug_strip_geometry_dev(const dm_params* p, const float* frames_dev, void* geom_dev,
-                                size_t geom_bytes, void* stream);
+int dm_debug_strip_geometry_dev(const dm_params* p, const dm_frame* frames_host,
+                                const float* frames_dev, void* geom_dev, size_t geom_bytes,
+                                void* stream);
 
 /*
  * Test hook: caps the bytes of LDS-window slabs one channel group of the calling thread's

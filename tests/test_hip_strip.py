@@ -50,19 +50,22 @@ def test_device_geometry_equals_host_geometry(dmap, oracle):
       P, geom, covers, bound = _geometry(lib, p, table, B, mh, with_covers=False)
       if P <= 0:
         continue
-      dev = torch.zeros(B * 1024, dtype=torch.uint8, device="cuda")
-      tab_d = table.cuda()
-      got = lib.dm_debug_strip_geometry_dev(ctypes.byref(p), tab_d.data_ptr(), dev.data_ptr(),
-                                            dev.numel(), None)
+      dev = torch.zeros(B * 336 + 1024, dtype=torch.uint8, device="cuda")
+      tab = table.clone()
+      if not cfg["to_global"]:        # as the library stages a local map: neutral yaw
+        tab[:, 10:19] = torch.tensor([1., 0, 0, 0, 1, 0, 0, 0, 1]); tab[:, 19:21] = 0
+      tab_d = tab.cuda()
+      got = lib.dm_debug_strip_geometry_dev(ctypes.byref(p), table.data_ptr(), tab_d.data_ptr(),
+                                            dev.data_ptr(), dev.numel(), None)
       assert got == P
     finally:
       lib.dm_debug_force_strips(0)
     torch.cuda.synchronize()
-    # FrameGeom (592 B): Win16 win[8] (64 B), Win16 U (8 B), Line L[8], R[8] (4 doubles each), int ok
-    raw = dev.cpu().numpy()[:B * 592].reshape(B, 592)
+    # FrameGeom (336 B): Win16 win[8] (64 B), Win16 U (8 B), Line L[8], R[8] (4 floats each), int ok, pad
+    raw = dev.cpu().numpy()[:B * 336].reshape(B, 336)
     wins = raw[:, :64].copy().view(np.int16).reshape(B, 8, 4)
     U = raw[:, 64:72].copy().view(np.int16).reshape(B, 4)
-    ok = raw[:, 72 + 2 * 8 * 32:72 + 2 * 8 * 32 + 4].copy().view(np.int32).reshape(B)
+    ok = raw[:, 72 + 2 * 8 * 16:72 + 2 * 8 * 16 + 4].copy().view(np.int32).reshape(B)
     np.testing.assert_array_equal(ok != 0, geom[:, 0] != 0)
     np.testing.assert_array_equal(U.astype(np.int32), geom[:, 4:8])
     np.testing.assert_array_equal(wins.astype(np.int32).reshape(B, 32), geom[:, 8:40])

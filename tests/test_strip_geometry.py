@@ -15,6 +15,7 @@ from conftest import project_kwargs
 from test_window_geometry import _params
 
 STRIDE = 8 + 4 * 8
+ALIGN = 4
 
 
 def _geometry(lib, p, table, B, mh, with_covers=True):
@@ -26,9 +27,10 @@ def _geometry(lib, p, table, B, mh, with_covers=True):
     return P, geom, None, bound
   covers = None
   if with_covers:
-    covers = np.zeros((B, mh, P), dtype=np.uint32)
+    both = np.zeros((B, mh, P, 2), dtype=np.uint32)
     assert lib.dm_debug_strip_geometry(ctypes.byref(p), table.data_ptr(), geom.ctypes.data,
-                                       covers.ctypes.data, bound.ctypes.data) == P
+                                       both.ctypes.data, bound.ctypes.data) == P
+    covers = (both[..., 0].copy(), both[..., 1].copy())
   return P, geom, covers, bound
 
 
@@ -97,18 +99,29 @@ def test_every_valid_pixel_lands_inside_its_strips_window_and_cover(oracle, big_
       applied += 1
       U = geom[b, 4:8]
       wins = geom[b, 8:8 + 4 * P].reshape(P, 4)
-      lo = (covers[b] & 0xffff).astype(np.int64); hi = (covers[b] >> 16).astype(np.int64)   # (mh, P)
-      assert ((lo % 4 == 0) & (hi % 4 == 0)).all()
+      lo = (covers[0][b] & 0xffff).astype(np.int64); hi = (covers[0][b] >> 16).astype(np.int64)   # (mh, P)
+      olo = (covers[1][b] & 0xffff).astype(np.int64); ohi = (covers[1][b] >> 16).astype(np.int64)
+      assert ((lo % 4 == 0) & (hi % 4 == 0) & (olo % 4 == 0) & (ohi % 4 == 0)).all()
+      # an owned span lies inside its strip's cover and meets no other strip's cover
+      has = ohi > olo
+      assert (olo[has] >= lo[has]).all() and (ohi[has] <= hi[has]).all()
+      for s in range(P):
+        for q in range(P):
+          if q != s:
+            meet = has[:, s] & (hi[:, q] > lo[:, q]) & (lo[:, q] < ohi[:, s]) & (hi[:, q] > olo[:, s])
+            assert not meet.any()
       for s in range(P):
         x0, z0, w, h = wins[s]
         assert x0 % 4 == 0 and w % 4 == 0 and x0 >= 0 and x0 + w <= mw and z0 >= 0 and z0 + h <= mh
-        if w:       # inside the union window, covers inside the window
+        if w:       # inside the union window; covers inside the window widened to whole spans of ALIGN cells
           assert U[0] <= x0 and x0 + w <= U[0] + U[2] and U[1] <= z0 and z0 + h <= U[1] + U[3]
           rows = np.arange(mh)
           outside = (rows < z0) | (rows >= z0 + h)
           assert (hi[outside, s] == 0).all()
           live = hi[:, s] > 0
-          assert (lo[live, s] >= x0).all() and (hi[live, s] <= x0 + w).all()
+          A = ALIGN        # kSpanAlign of dm_strip_geometry.hpp
+          assert (lo[live, s] >= (x0 & ~(A - 1))).all() and (hi[live, s] <= min((x0 + w + A - 1) & ~(A - 1), mw)).all()
+          assert (lo[live, s] % A == 0).all() and ((hi[live, s] % A == 0) | (hi[live, s] == mw)).all()
         cols = slice(s * wp, min((s + 1) * wp, W))
         sel = ok[b, :, cols]
         xs, zs = xb[b, :, cols][sel], zb[b, :, cols][sel]
@@ -123,7 +136,9 @@ def test_every_valid_pixel_lands_inside_its_strips_window_and_cover(oracle, big_
       # ownership statistics: groups in exactly one cover vs. in several
       gx = np.arange(0, mw, 4)
       n = ((gx[None, :, None] >= lo[:, None, :]) & (gx[None, :, None] < hi[:, None, :])).sum(-1)
-      owned_groups += int((n == 1).sum()); shared_groups += int((n > 1).sum())
+      no = ((gx[None, :, None] >= olo[:, None, :]) & (gx[None, :, None] < ohi[:, None, :])).sum(-1)
+      assert (no <= 1).all() and (n[no == 1] == 1).all()     # owned => in exactly one cover
+      owned_groups += int((no == 1).sum()); shared_groups += int(((n >= 1) & (no == 0)).sum())
   assert checked > 200_000 and applied > 60
   # most reachable groups have one owner (that is the point of the path)
   assert owned_groups > shared_groups > 0
@@ -151,10 +166,13 @@ def test_cfg2_plan_and_bound():
   areas = geom[:, 8:8 + 16].reshape(B, 4, 4)
   assert (areas[..., 2] * areas[..., 3]).max() <= cells <= 40_000
   assert geom[:, 7].max() <= rows <= 512 and (geom[:, 6] * geom[:, 7]).max() <= ucells
-  lo = (covers & 0xffff).astype(np.int64); hi = (covers >> 16).astype(np.int64)
+  lo = (covers[0] & 0xffff).astype(np.int64); hi = (covers[0] >> 16).astype(np.int64)
+  olo = (covers[1] & 0xffff).astype(np.int64); ohi = (covers[1] >> 16).astype(np.int64)
   gx = np.arange(0, 512, 4)
   n = ((gx[None, None, :, None] >= lo[:, :, None, :]) & (gx[None, None, :, None] < hi[:, :, None, :])).sum(-1)
-  owned, shared = int((n == 1).sum()), int((n > 1).sum())
+  no = ((gx[None, None, :, None] >= olo[:, :, None, :]) & (gx[None, None, :, None] < ohi[:, :, None, :])).sum(-1)
+  owned, shared = int((no == 1).sum()), int(((n >= 1) & (no == 0)).sum())
+  assert int((n == 1).sum()) - owned < 0.02 * owned    # nearly every group in one cover is owned
   assert owned > 2.5 * shared        # ~75 % of the reachable groups go straight to the map
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/build_variant.sh NAME [extra hipcc flags]: an experimental build of the library
-# (dm_window.hip recompiled with the flags) -> tools/tmp/libdm_NAME.so; select it with
+# (dm_window.hip and dm_strip.hip recompiled with the flags) -> tools/tmp/libdm_NAME.so; select it with
 # DUNGEON_MAPS_AMD_LIB=$PWD/tools/tmp/libdm_NAME.so
 set -e
 name=$1; shift
@@ -10,6 +10,8 @@ mkdir -p $here/tools/tmp
 make -C $src >/dev/null
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
   "$@" -c $src/dm_window.hip -o /tmp/dm_window_$name.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
+  "$@" -c $src/dm_strip.hip -o /tmp/dm_strip_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $here/tools/tmp/libdm_$name.so \
-  $src/dm_api.o $src/dm_generic.o /tmp/dm_window_$name.o $src/dm_points.o
+  $src/dm_api.o $src/dm_generic.o /tmp/dm_window_$name.o /tmp/dm_strip_$name.o $src/dm_points.o
 echo $here/tools/tmp/libdm_$name.so

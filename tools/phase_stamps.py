@@ -15,6 +15,7 @@ proj = dmap.MapProjector(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.r
                          width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
                          trunc_depth_min=0.15, trunc_depth_max=5.05, to_global=True, fill_value=-np.inf)
 lib = _native.lib()
+lib.dm_debug_force_legacy_window(1)      # k_window_scatter (host geometry), not the strip path
 buf = torch.zeros(4096 * 12, dtype=torch.int64, device="cuda")
 lib.dm_debug_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
 for _ in range(5):

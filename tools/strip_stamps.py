@@ -1,0 +1,43 @@
+"""Per-phase timing of k_strip_scatter from an instrumented build:
+    tools/build_variant.sh stamps -DDM_STAMPS
+    DUNGEON_MAPS_AMD_LIB=$PWD/tools/tmp/libdm_stamps.so python tools/strip_stamps.py
+Thread 0 of every workgroup records the 100 MHz real-time counter at phase boundaries."""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dungeon_maps_amd as dmap
+from dungeon_maps_amd import _native
+B, H, W, mh, mw = 64, 480, 640, 512, 512
+g = torch.Generator().manual_seed(1234)
+depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g).cuda()
+pose = torch.empty(B, 3).uniform_(-1, 1, generator=g); pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)
+proj = dmap.MapProjector(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
+                         width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
+                         trunc_depth_min=0.15, trunc_depth_max=5.05, to_global=True, fill_value=-np.inf)
+lib = ctypes.CDLL(_native.LIB_PATH)
+_native.lib()
+buf = torch.zeros(4096 * 12, dtype=torch.int64, device="cuda")
+lib.dm_debug_strip_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+if os.environ.get("DM_STAMPS_LEGACY"):
+  _native.lib().dm_debug_force_legacy_window(1)
+for _ in range(5):
+  top, mask = proj.orth_project(depth, cam_pose=pose)
+torch.cuda.synchronize()
+raw = buf.cpu().numpy().reshape(-1, 12)
+raw = raw[raw[:, 0] != 0]
+st = raw[:, :7]
+names = ["frame record + geometry (wave 0)", "lds init + barrier", "cover table", "scatter loop",
+         "fill rest + barrier", "flush + publish"]
+d = np.diff(st, axis=1).astype(np.float64) * 0.01     # us
+print("workgroups: %d   per-WG phase time in us (median / max):" % len(st))
+for i, n in enumerate(names):
+  print(f"  {n:34s} {np.median(d[:, i]):8.2f} {d[:, i].max():8.2f}")
+if raw[:, 7].any():
+  print("  (inside 'scatter loop': row table %.2f / %.2f, loop proper %.2f / %.2f)" % (
+      np.median(raw[:, 8] - raw[:, 7]) * 0.01, (raw[:, 8] - raw[:, 7]).max() * 0.01,
+      np.median(raw[:, 4] - raw[:, 8]) * 0.01, (raw[:, 4] - raw[:, 8]).max() * 0.01))
+tot = (st[:, -1] - st[:, 0]) * 0.01
+print("  total                              %8.2f %8.2f" % (np.median(tot), tot.max()))
+print("kernel span us: %.2f   start skew: %.2f   end skew: %.2f" % (
+    (st[:, -1].max() - st[:, 0].min()) * 0.01, (st[:, 0].max() - st[:, 0].min()) * 0.01,
+    (st[:, -1].max() - st[:, -1].min()) * 0.01))

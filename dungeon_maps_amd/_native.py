@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DUNGEON_MAPS_AMD_LIB") or os.path.join(
     HERE, "csrc", "libdungeon_maps_amd.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # dm_reduction
 REDUCE_MAX, REDUCE_MIN, REDUCE_SUM, REDUCE_MEAN, REDUCE_PROD = range(5)
@@ -44,6 +44,13 @@ class FuseSrc(ctypes.Structure):
       ("g2l", (ctypes.c_float * 12) * FUSE_MAX_BATCH)]
 
 
+class FramesPlan(ctypes.Structure):
+  """dm_frames_plan"""
+  _fields_ = [(n, ctypes.c_int32) for n in (
+      "strips", "strip_width", "slab_cells", "max_rows", "max_union_cells", "slack_cells")] + [
+      ("reserved", ctypes.c_int32 * 2)]
+
+
 class NativeError(RuntimeError):
   pass
 
@@ -55,6 +62,14 @@ _SIGNATURES = {
     "dm_orth_project_f32": (ctypes.c_int, [
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "dm_frames_prepared_bytes": (ctypes.c_size_t, [ctypes.POINTER(Params)]),
+    "dm_frames_prepare_f32": (ctypes.c_int, [
+        ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+        ctypes.POINTER(FramesPlan), ctypes.c_void_p]),
+    "dm_orth_project_prepared_f32": (ctypes.c_int, [
+        ctypes.POINTER(Params), ctypes.POINTER(FramesPlan), ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dm_orth_project_fused_f32": (ctypes.c_int, [
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

@@ -178,6 +178,60 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
   return DM_OK;
 }
 
+size_t dm_frames_prepared_bytes(const dm_params* p) {
+  if (check_params(p) != DM_OK || p->B < 1) return 0;
+  return dm::strip_prepared_bytes(*p);
+}
+
+int dm_frames_prepare_f32(const dm_params* p, const dm_frame* frames, void* prepared_dev,
+                          size_t prepared_bytes, dm_frames_plan* plan_out, void* stream) {
+  int rc = check_params(p);
+  if (rc != DM_OK) return rc;
+  if (!frames || !prepared_dev || !plan_out || p->B < 1)
+    return fail(DM_ERR_INVALID_ARGUMENT, "frames/prepared/plan must not be NULL, B >= 1");
+  const hipError_t e = dm::strip_prepare(*p, frames, prepared_dev, prepared_bytes, plan_out,
+                                         static_cast<hipStream_t>(stream));
+  if (e == hipErrorNotSupported)
+    return fail(DM_ERR_UNSUPPORTED, "these parameters / frames cannot be prepared (the strip path does "
+                                    "not apply): use dm_orth_project_f32");
+  if (e == hipErrorInvalidValue)
+    return fail(DM_ERR_WORKSPACE_TOO_SMALL, "prepared buffer: %zu B given, %zu B (256-byte aligned) needed",
+                prepared_bytes, dm::strip_prepared_bytes(*p));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP copy failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
+int dm_orth_project_prepared_f32(const dm_params* p, const dm_frames_plan* plan, void* prepared_dev,
+                                 const float* depth_dev, const float* value_dev,
+                                 const uint8_t* valid_dev, float* out_dev, uint8_t* mask_dev,
+                                 float* height_dev, float* fused_dev, uint8_t* fused_mask_dev,
+                                 void* workspace_dev, size_t workspace_bytes, void* stream) {
+  int rc = check_params(p);
+  if (rc != DM_OK) return rc;
+  if (!plan || !prepared_dev || !depth_dev || !out_dev || !mask_dev || p->B < 1)
+    return fail(DM_ERR_INVALID_ARGUMENT, "plan/prepared/depth/out/mask must not be NULL, B >= 1");
+  if ((p->vc > 0) != (value_dev != nullptr))
+    return fail(DM_ERR_INVALID_ARGUMENT, "value pointer and vc=%d disagree", p->vc);
+  if ((p->valid_c > 0) != (valid_dev != nullptr))
+    return fail(DM_ERR_INVALID_ARGUMENT, "valid pointer and valid_c=%d disagree", p->valid_c);
+  if ((fused_dev != nullptr) != (fused_mask_dev != nullptr))
+    return fail(DM_ERR_INVALID_ARGUMENT, "fused map and fused mask must be given together");
+  const size_t need = dm_orth_project_workspace_bytes(p);
+  if (need > workspace_bytes || !workspace_dev)
+    return fail(DM_ERR_WORKSPACE_TOO_SMALL, "workspace %zu B < required %zu B", workspace_bytes, need);
+  const hipEvent_t mid = g_mid_event, pre = g_pre_event;
+  g_mid_event = nullptr;
+  g_pre_event = nullptr;
+  const hipError_t e = dm::run_strip_prepared(*p, *plan, prepared_dev, depth_dev, value_dev, valid_dev,
+                                              out_dev, mask_dev, p->vc ? height_dev : nullptr, fused_dev,
+                                              fused_mask_dev, workspace_dev, workspace_bytes, pre, mid,
+                                              static_cast<hipStream_t>(stream));
+  if (e == hipErrorNotSupported)
+    return fail(DM_ERR_UNSUPPORTED, "plan does not match the parameters, or misaligned pointers");
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
 int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames,
                               const float* depth_dev, const float* value_dev,
                               const uint8_t* valid_dev, float* out_dev, uint8_t* mask_dev,

@@ -226,42 +226,50 @@ MergeKernel pick_merge_kernel(bool is_max, int P) {
   return table[is_max ? 1 : 0][P - 1];
 }
 
+// Device copy of a batch's camera state as the kernels read it ("prepared frames"):
+// [Cfg (kCfgBytes) | status word (256 B) | frame records].  Lives at the head of the workspace
+// for dm_orth_project_f32 (staged by one copy per call) or in a buffer of the caller's that
+// dm_frames_prepare_f32 filled once (dm_orth_project_prepared_f32: no copy, no host geometry).
+struct PreparedView {
+  const strip::Cfg* cfg;
+  int* status;
+  const float* frames;        // (B, 32)
+};
+constexpr size_t kStatusBytes = 256;
+inline size_t prepared_bytes(int B) { return kCfgBytes + kStatusBytes + up256((size_t)B * sizeof(dm_frame)); }
+inline PreparedView view_prepared(void* dev) {
+  unsigned char* base = static_cast<unsigned char*>(dev);
+  return PreparedView{reinterpret_cast<const strip::Cfg*>(base), reinterpret_cast<int*>(base + kCfgBytes),
+                      reinterpret_cast<const float*>(base + kCfgBytes + kStatusBytes)};
+}
+
 struct Layout {               // workspace of the strip path
-  strip::Cfg* cfg;            // kCfgBytes in front of the frame records: one copy stages both
-  float* frames;              // (B, 32)
+  float* slabs;               // (the 8 floats in front of them: the reductions' identities)
+  size_t slab_bytes;
   Win16* g_wins;              // (B, kMaxStrips)
   Win16* g_unions;            // (B)
-  int* status;
   float* sink;                // kSinks x 64 B
   strip::RowEntry* g_rows;    // (B, max_rows, P)
-  float* slabs;
-  size_t slab_bytes;
 };
 
 size_t tables_bytes(int B, int rows, int P) {
-  return kCfgBytes + up256((size_t)B * sizeof(dm_frame)) + 256 + up256((size_t)B * strip::kMaxStrips * sizeof(Win16)) +
-         up256((size_t)B * sizeof(Win16)) + 256 + kSinks * 64 + up256((size_t)B * rows * P * sizeof(strip::RowEntry));
+  return 256 + up256((size_t)B * strip::kMaxStrips * sizeof(Win16)) + up256((size_t)B * sizeof(Win16)) +
+         kSinks * 64 + up256((size_t)B * rows * P * sizeof(strip::RowEntry));
 }
 
-// [Cfg | frame records | identities] -- staged by ONE copy -- then the slabs, and at the end of
-// the workspace the tables the kernels write (windows, unions, status, sinks, row tables).
+// [identities (256 B) | slabs ...] and, at the end of the region, the tables the kernels write
+// (windows, unions, sinks, row tables).
 bool carve(void* ws, size_t ws_bytes, int B, int rows, int P, Layout& l) {
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return false;
-  const size_t head = kCfgBytes + up256((size_t)B * sizeof(dm_frame)) + 256;
-  const size_t tail = up256((size_t)B * strip::kMaxStrips * sizeof(Win16)) + up256((size_t)B * sizeof(Win16)) +
-                      256 + kSinks * 64 + up256((size_t)B * rows * P * sizeof(strip::RowEntry));
+  const size_t tail = tables_bytes(B, rows, P) - 256;
   ws_bytes = ws_bytes / 256 * 256;
-  if (ws_bytes < head + tail) return false;
+  if (ws_bytes < 256 + tail) return false;
   unsigned char* base = static_cast<unsigned char*>(ws);
-  l.cfg = reinterpret_cast<strip::Cfg*>(base); base += kCfgBytes;
-  l.frames = reinterpret_cast<float*>(base); base += up256((size_t)B * sizeof(dm_frame));
-  base += 256;                                   // identities: the 8 floats in front of the slabs
-  l.slabs = reinterpret_cast<float*>(base);
-  l.slab_bytes = ws_bytes - head - tail;
-  base = static_cast<unsigned char*>(ws) + ws_bytes - tail;
+  l.slabs = reinterpret_cast<float*>(base + 256);
+  l.slab_bytes = ws_bytes - 256 - tail;
+  base += ws_bytes - tail;
   l.g_wins = reinterpret_cast<Win16*>(base); base += up256((size_t)B * strip::kMaxStrips * sizeof(Win16));
   l.g_unions = reinterpret_cast<Win16*>(base); base += up256((size_t)B * sizeof(Win16));
-  l.status = reinterpret_cast<int*>(base); base += 256;
   l.sink = reinterpret_cast<float*>(base); base += kSinks * 64;
   l.g_rows = reinterpret_cast<strip::RowEntry*>(base);
   return true;
@@ -289,7 +297,8 @@ hipError_t raise_lds_limit(const void* key) {
 }
 
 // One pass over the channels of `out`: scatter (+ owned groups straight to the map) and merge.
-hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rb, const Layout& l,
+hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan& rb, const PreparedView& pv,
+                      const Layout& l,
                       const float* depth, const float* value, const uint8_t* valid, float* out,
                       uint8_t* mask, int oc_total, float fill, bool is_max, size_t slab_bytes,
                       hipStream_t s) {
@@ -306,17 +315,17 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rb, const
   sa.wp = plan.wp; sa.P = plan.P;
   sa.dc = p.dc; sa.valid_c = p.valid_c;
   sa.oc_total = oc_total;
-  sa.slab_stride = rb.slab_stride;
-  sa.table_off = rb.slab_stride + 64;
+  sa.slab_stride = rb.slab_cells;
+  sa.table_off = rb.slab_cells + 64;
   sa.max_rows = rb.max_rows;
   sa.fill = fill;
   sa.b0 = 0;
-  sa.frames = l.frames;
+  sa.frames = pv.frames;
   sa.depth = depth; sa.value = value; sa.valid = valid;
   sa.slabs = l.slabs;
   sa.out = out; sa.mask = mask; sa.mh = p.mh; sa.mw = p.mw;
-  sa.g_wins = l.g_wins; sa.g_unions = l.g_unions; sa.g_rows = l.g_rows; sa.status = l.status; sa.sink = l.sink;
-  sa.cfg = l.cfg;
+  sa.g_wins = l.g_wins; sa.g_unions = l.g_unions; sa.g_rows = l.g_rows; sa.status = pv.status; sa.sink = l.sink;
+  sa.cfg = pv.cfg;
 #ifdef DM_STAMPS
   sa.stamps = g_stamp_buffer;
 #endif
@@ -324,9 +333,9 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rb, const
   const StripKernel kfn = pick_strip_kernel(is_max, has_valid, has_value, plan.lean);
   hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn));
   if (e != hipSuccess) return e;
-  const size_t lds_bytes = ((size_t)rb.slab_stride + 64) * 4 + kGeomBytes + (size_t)rb.max_rows * plan.P * sizeof(strip::RowEntry);
+  const size_t lds_bytes = ((size_t)rb.slab_cells + 64) * 4 + kGeomBytes + (size_t)rb.max_rows * plan.P * sizeof(strip::RowEntry);
   // channel groups: the slabs of one group fit the slab region
-  const size_t per_channel = (size_t)p.B * plan.P * rb.slab_stride * 4;
+  const size_t per_channel = (size_t)p.B * plan.P * rb.slab_cells * 4;
   int group = (int)(slab_bytes / (per_channel ? per_channel : 1));
   if (group < 1) return hipErrorNotSupported;
   if (group > oc_total) group = oc_total;
@@ -339,7 +348,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rb, const
     if (e != hipSuccess) return e;
     StripMergeArgs ma;
     ma.b0 = 0; ma.oc = oc; ma.ch0 = ch0; ma.oc_total = oc_total; ma.mh = p.mh; ma.mw = p.mw;
-    ma.P = plan.P; ma.slab_stride = rb.slab_stride; ma.max_rows = rb.max_rows; ma.fill = fill;
+    ma.P = plan.P; ma.slab_stride = rb.slab_cells; ma.max_rows = rb.max_rows; ma.fill = fill;
     ma.g_wins = l.g_wins; ma.g_unions = l.g_unions; ma.g_rows = l.g_rows;
     ma.slabs = l.slabs; ma.out = out; ma.mask = mask;
     // grid.y = frames * channels <= 65535 per launch
@@ -362,21 +371,12 @@ thread_local int g_force_legacy = 0;       // dm_debug_force_legacy_window
 size_t strip_workspace_extra(const dm_params& p) {
   Plan plan;
   if (!make_plan(p, plan)) return 0;
-  return tables_bytes(p.B, p.mh, strip::kMaxStrips);
+  return prepared_bytes(p.B) + tables_bytes(p.B, p.mh, strip::kMaxStrips);
 }
 
-// hipErrorNotSupported: the strip path does not apply to this call (nothing enqueued).
-hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const float* depth,
-                     const float* value, const uint8_t* valid, float* out, uint8_t* mask,
-                     float* height, float* fused, uint8_t* fused_mask, void* ws, size_t ws_bytes,
-                     hipEvent_t before_projection, hipEvent_t after_projection, hipStream_t s) {
-  if (g_force_legacy || p.B > 65535) return hipErrorNotSupported;
-  const int oc_total = p.vc ? p.vc : p.dc;
-  if (reinterpret_cast<uintptr_t>(out) % 16 != 0 || reinterpret_cast<uintptr_t>(mask) % 4 != 0 ||
-      reinterpret_cast<uintptr_t>(fused) % 16 != 0 || reinterpret_cast<uintptr_t>(fused_mask) % 4 != 0 ||
-      reinterpret_cast<uintptr_t>(height) % 16 != 0 || reinterpret_cast<uintptr_t>(depth) % 16 != 0 ||
-      reinterpret_cast<uintptr_t>(value) % 16 != 0)
-    return hipErrorNotSupported;
+namespace {
+
+const Plan* cached_plan(const dm_params& p) {
   thread_local dm_params plan_key = {};
   thread_local Plan plan;
   thread_local bool plan_ok = false, plan_valid = false;
@@ -387,49 +387,49 @@ hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const floa
     plan_ok = make_plan(p, plan);
     plan_valid = true;
   }
-  if (!plan_ok) return hipErrorNotSupported;
-  const int magnitude = validate_frames(p, frames_host, p.B);
-  if (magnitude < 0) return hipErrorNotSupported;
-  const Rig* rb = rig_of(p, plan, frames_host[0], magnitude);
-  if (!rb->fits) return hipErrorNotSupported;
-  Layout l;
-  if (!carve(ws, ws_bytes, p.B, rb->max_rows, plan.P, l)) return hipErrorNotSupported;
-  const size_t hm = (height && value) ? up256((size_t)p.B * p.dc * p.mh * p.mw) : 0;
-  if (l.slab_bytes < hm + (size_t)p.B * plan.P * rb->slab_stride * 4) return hipErrorNotSupported;
+  return plan_ok ? &plan : nullptr;
+}
 
-  hipError_t e = hipSuccess;
-  if (before_projection) {
-    e = hipEventRecord(before_projection, s);
-    if (e != hipSuccess) return e;
+bool aligned_for_strips(const float* depth, const float* value, float* out, uint8_t* mask, float* height,
+                        float* fused, uint8_t* fused_mask) {
+  return reinterpret_cast<uintptr_t>(out) % 16 == 0 && reinterpret_cast<uintptr_t>(mask) % 4 == 0 &&
+         reinterpret_cast<uintptr_t>(fused) % 16 == 0 && reinterpret_cast<uintptr_t>(fused_mask) % 4 == 0 &&
+         reinterpret_cast<uintptr_t>(height) % 16 == 0 && reinterpret_cast<uintptr_t>(depth) % 16 == 0 &&
+         reinterpret_cast<uintptr_t>(value) % 16 == 0;
+}
+
+// [Cfg | status | frame records] of a batch as one block of host memory (thread-local staging).
+const std::vector<unsigned char>& stage_prepared(const dm_params& p, const Rig& rg, const dm_frame* frames_host) {
+  thread_local std::vector<unsigned char> stage;
+  stage.resize(prepared_bytes(p.B));
+  memset(stage.data(), 0, kCfgBytes + kStatusBytes);
+  memcpy(stage.data(), &rg.cfg, sizeof(strip::Cfg));
+  dm_frame* f = reinterpret_cast<dm_frame*>(stage.data() + kCfgBytes + kStatusBytes);
+  memcpy(f, frames_host, (size_t)p.B * sizeof(dm_frame));
+  if (!p.to_global) {       // local map: neutral yaw, no translation (exact: x * 1 + z * 0 + 0)
+    static const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int b = 0; b < p.B; ++b) { memcpy(f[b].Ry, eye, sizeof(eye)); f[b].tx = 0.0f; f[b].tz = 0.0f; }
   }
-  {
-    // [Cfg (kCfgBytes) | frame records]: one stream-ordered copy.  The staging buffer is this
-    // thread's (the runtime has copied pageable memory out by the time the call returns).
-    thread_local std::vector<unsigned char> stage;
-    const size_t frames_bytes = up256((size_t)p.B * sizeof(dm_frame));
-    stage.resize(kCfgBytes + frames_bytes + 256);
-    memset(stage.data(), 0, kCfgBytes);
-    memcpy(stage.data(), &rb->cfg, sizeof(strip::Cfg));
-    {   // the reductions' identities, right in front of the slabs (k_strip_merge)
-      float* id = reinterpret_cast<float*>(stage.data() + kCfgBytes + frames_bytes + 256 - 32);
-      for (int i = 0; i < 4; ++i) { id[i] = -INFINITY; id[4 + i] = INFINITY; }
-    }
-    memcpy(stage.data() + kCfgBytes, frames_host, (size_t)p.B * sizeof(dm_frame));
-    if (!p.to_global) {       // local map: neutral yaw, no translation (exact: x * 1 + z * 0 + 0)
-      dm_frame* f = reinterpret_cast<dm_frame*>(stage.data() + kCfgBytes);
-      static const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-      for (int b = 0; b < p.B; ++b) { memcpy(f[b].Ry, eye, sizeof(eye)); f[b].tx = 0.0f; f[b].tz = 0.0f; }
-    }
-    e = hipMemcpyAsync(l.cfg, stage.data(), stage.size(), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return e;
-  }
+  return stage;
+}
+
+// The launch sequence proper: nothing here depends on the poses (graph capturable).
+hipError_t launch_strips(const dm_params& p, const Plan& plan, const dm_frames_plan& fp, const PreparedView& pv,
+                         const float* depth, const float* value, const uint8_t* valid, float* out,
+                         uint8_t* mask, float* height, float* fused, uint8_t* fused_mask, void* ws,
+                         size_t ws_bytes, hipEvent_t after_projection, hipStream_t s) {
+  const int oc_total = p.vc ? p.vc : p.dc;
+  Layout l;
+  if (!carve(ws, ws_bytes, p.B, fp.max_rows, plan.P, l)) return hipErrorNotSupported;
+  const size_t hm = (height && value) ? up256((size_t)p.B * p.dc * p.mh * p.mw) : 0;
+  if (l.slab_bytes < hm + (size_t)p.B * plan.P * fp.slab_cells * 4) return hipErrorNotSupported;
   const bool is_max = p.reduction == DM_REDUCE_MAX;
-  e = strip_pass(p, plan, *rb, l, depth, value, valid, out, mask, oc_total, p.fill, is_max,
-                 l.slab_bytes - hm, s);
+  hipError_t e = strip_pass(p, plan, fp, pv, l, depth, value, valid, out, mask, oc_total, p.fill, is_max,
+                            l.slab_bytes - hm, s);
   if (e != hipSuccess) return e;
   if (height && value) {      // maps.py:332-350: second projection of the heights, NINF fill, max
     uint8_t* scratch_mask = reinterpret_cast<uint8_t*>(l.slabs) + l.slab_bytes - hm;   // (tail of the slab region)
-    e = strip_pass(p, plan, *rb, l, depth, nullptr, valid, height, scratch_mask, p.dc, -INFINITY, true,
+    e = strip_pass(p, plan, fp, pv, l, depth, nullptr, valid, height, scratch_mask, p.dc, -INFINITY, true,
                    l.slab_bytes - hm, s);
     if (e != hipSuccess) return e;
   }
@@ -450,6 +450,87 @@ hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const floa
   }
   note_split(plan.P, 1, 1, 2);
   return hipSuccess;
+}
+
+dm_frames_plan plan_of(const Plan& plan, const Rig& rg) {
+  dm_frames_plan fp;
+  memset(&fp, 0, sizeof(fp));
+  fp.strips = plan.P; fp.strip_width = plan.wp; fp.slab_cells = rg.slab_stride;
+  fp.max_rows = rg.max_rows; fp.max_union_cells = rg.max_union; fp.slack_cells = rg.slack;
+  return fp;
+}
+
+}  // namespace
+
+// hipErrorNotSupported: the strip path does not apply to this call (nothing enqueued).
+hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const float* depth,
+                     const float* value, const uint8_t* valid, float* out, uint8_t* mask,
+                     float* height, float* fused, uint8_t* fused_mask, void* ws, size_t ws_bytes,
+                     hipEvent_t before_projection, hipEvent_t after_projection, hipStream_t s) {
+  if (g_force_legacy || p.B > 65535) return hipErrorNotSupported;
+  if (!aligned_for_strips(depth, value, out, mask, height, fused, fused_mask)) return hipErrorNotSupported;
+  const Plan* plan = cached_plan(p);
+  if (!plan) return hipErrorNotSupported;
+  const int magnitude = validate_frames(p, frames_host, p.B);
+  if (magnitude < 0) return hipErrorNotSupported;
+  const Rig* rg = rig_of(p, *plan, frames_host[0], magnitude);
+  if (!rg->fits) return hipErrorNotSupported;
+  const size_t head = prepared_bytes(p.B);
+  if (reinterpret_cast<uintptr_t>(ws) % 256 != 0 || ws_bytes < head) return hipErrorNotSupported;
+  const dm_frames_plan fp = plan_of(*plan, *rg);
+  {   // would the rest fit?  (nothing may be enqueued before the answer is yes)
+    Layout l;
+    if (!carve(static_cast<unsigned char*>(ws) + head, ws_bytes - head, p.B, fp.max_rows, plan->P, l)) return hipErrorNotSupported;
+    const size_t hm = (height && value) ? up256((size_t)p.B * p.dc * p.mh * p.mw) : 0;
+    if (l.slab_bytes < hm + (size_t)p.B * plan->P * fp.slab_cells * 4) return hipErrorNotSupported;
+  }
+  hipError_t e = hipSuccess;
+  if (before_projection) {
+    e = hipEventRecord(before_projection, s);
+    if (e != hipSuccess) return e;
+  }
+  // one stream-ordered copy (the runtime has copied pageable memory out by the time it returns)
+  const std::vector<unsigned char>& stage = stage_prepared(p, *rg, frames_host);
+  e = hipMemcpyAsync(ws, stage.data(), stage.size(), hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  return launch_strips(p, *plan, fp, view_prepared(ws), depth, value, valid, out, mask, height, fused,
+                       fused_mask, static_cast<unsigned char*>(ws) + head, ws_bytes - head, after_projection, s);
+}
+
+size_t strip_prepared_bytes(const dm_params& p) { return cached_plan(p) ? prepared_bytes(p.B) : 0; }
+
+// dm_frames_prepare_f32: validate the batch's camera state, size the launches, upload.
+hipError_t strip_prepare(const dm_params& p, const dm_frame* frames_host, void* prepared_dev,
+                         size_t prepared_size, dm_frames_plan* plan_out, hipStream_t s) {
+  if (g_force_legacy || p.B > 65535 || p.B < 1) return hipErrorNotSupported;
+  const Plan* plan = cached_plan(p);
+  if (!plan) return hipErrorNotSupported;
+  const int magnitude = validate_frames(p, frames_host, p.B);
+  if (magnitude < 0) return hipErrorNotSupported;
+  const Rig* rg = rig_of(p, *plan, frames_host[0], magnitude);
+  if (!rg->fits) return hipErrorNotSupported;
+  if (reinterpret_cast<uintptr_t>(prepared_dev) % 256 != 0 || prepared_size < prepared_bytes(p.B))
+    return hipErrorInvalidValue;
+  *plan_out = plan_of(*plan, *rg);
+  const std::vector<unsigned char>& stage = stage_prepared(p, *rg, frames_host);
+  return hipMemcpyAsync(prepared_dev, stage.data(), stage.size(), hipMemcpyHostToDevice, s);
+}
+
+// dm_orth_project_prepared_f32
+hipError_t run_strip_prepared(const dm_params& p, const dm_frames_plan& fp, void* prepared_dev,
+                              const float* depth, const float* value, const uint8_t* valid, float* out,
+                              uint8_t* mask, float* height, float* fused, uint8_t* fused_mask, void* ws,
+                              size_t ws_bytes, hipEvent_t before_projection, hipEvent_t after_projection,
+                              hipStream_t s) {
+  if (!aligned_for_strips(depth, value, out, mask, height, fused, fused_mask)) return hipErrorNotSupported;
+  const Plan* plan = cached_plan(p);
+  if (!plan || plan->P != fp.strips || plan->wp != fp.strip_width) return hipErrorNotSupported;
+  if (before_projection) {
+    const hipError_t e = hipEventRecord(before_projection, s);
+    if (e != hipSuccess) return e;
+  }
+  return launch_strips(p, *plan, fp, view_prepared(prepared_dev), depth, value, valid, out, mask, height,
+                       fused, fused_mask, ws, ws_bytes, after_projection, s);
 }
 
 }  // namespace dm

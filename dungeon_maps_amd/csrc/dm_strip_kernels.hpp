@@ -243,6 +243,10 @@ k_strip_scatter(StripArgs a) {
     *reinterpret_cast<float4*>(po) = make_float4(a.fill, a.fill, a.fill, a.fill);
     *reinterpret_cast<uint32_t*>(pm) = 0u;
   };
+  // the reductions' identities as float4s in front of the slabs (k_strip_merge reads them where
+  // a strip has nothing for a group)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8)
+    a.slabs[(int)threadIdx.x - 8] = threadIdx.x < 4 ? -INFINITY : INFINITY;
   auto publish_geometry = [&]() {
     if (publisher && threadIdx.x < strip::kMaxStrips)
       a.g_wins[(size_t)b * strip::kMaxStrips + threadIdx.x] = geom->win[threadIdx.x];

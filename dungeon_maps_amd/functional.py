@@ -21,6 +21,7 @@ from .utils import NINF, Reduction
 
 __all__ = [
     "CenterMode", "get", "orth_project", "orth_project_and_fuse", "orth_project_fused", "fuse_batch", "mask_from_map", "camera_affine_grid",
+    "PreparedProjection", "prepare_orth_project",
     "depth_map_to_point_cloud", "height_map_to_point_cloud", "image_to_camera_space",
     "camera_to_image_space", "camera_to_local_space", "local_to_camera_space",
     "local_to_global_space", "global_to_local_space", "map_quantize",
@@ -344,6 +345,147 @@ def orth_project_fused(
   if call.target != call.dev:       # outputs live on the depth map's device (maps.py:227-232)
     out, mask = out.to(call.target), mask.to(call.target)
   return out, mask
+
+
+class PreparedProjection:
+  """The camera state of a batch uploaded and analysed once (``dm_frames_prepare_f32``), then
+  projected any number of times: ``orth_project`` / ``orth_project_and_fuse`` on it enqueue the
+  kernels and nothing else -- no host-side geometry, no copy, nothing that depends on the
+  poses -- so the calls are cheap on the host and may be captured into a HIP graph
+  (``torch.cuda.graph``) and replayed.  New poses for the same shapes: ``update(cam_pose=...)``
+  re-uploads into the same buffers (stream ordered; a captured graph stays valid as long as
+  the plan does not change, which ``update`` checks).
+
+  Made by ``MapProjector.prepare`` / ``prepare_orth_project``.  Applies where the library's
+  strip path does (max / min, ``trunc_depth_min >= 0`` and ``trunc_depth_max`` given, map and
+  image widths multiples of 4, one camera pitch for the batch); otherwise preparing raises
+  ``NativeError`` and plain ``orth_project`` is the way.  One projection at a time per object
+  (its workspace is its own).  Results are those of ``orth_project`` bit for bit.
+  """
+
+  def __init__(self, batch, height, width, depth_channels, value_channels, valid_channels, cam_pose,
+               width_offset, height_offset, cam_pitch, cam_height, map_res, map_width, map_height,
+               focal_x, focal_y, center_x, center_y, trunc_depth_min, trunc_depth_max,
+               trunc_height_max, clip_border, to_global, flip_h, fill_value, reduction, device):
+    import ctypes
+    dev = _compute_device(torch.device(device) if device is not None else torch.device("cuda"))
+    self.dev = dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
+    self.shape_in = (int(batch), int(depth_channels), int(height), int(width))
+    self.vc, self.valid_c = int(value_channels), int(valid_channels)
+    key = (int(batch), int(depth_channels), self.vc, int(height), int(width), int(map_height),
+           int(map_width), int(clip_border) if clip_border is not None else 0, bool(flip_h),
+           bool(to_global), _reduction_code(reduction), trunc_depth_min, trunc_depth_max,
+           trunc_height_max, self.valid_c, float(center_x), float(center_y), float(focal_x),
+           float(focal_y), float(map_res), fill_value)
+    self.params, self.ws_bytes = _make_params(key)
+    self.oc = self.vc if self.vc else int(depth_channels)
+    self.fill_value = fill_value
+    self._camera = dict(cam_pitch=cam_pitch, cam_height=cam_height, width_offset=width_offset,
+                        height_offset=height_offset)
+    lib = _native.lib()
+    nbytes = int(lib.dm_frames_prepared_bytes(ctypes.byref(self.params)))
+    if nbytes == 0:
+      raise _native.NativeError("these parameters cannot be prepared (the strip path does not "
+                                "apply to them): use orth_project")
+    with _on_device(self.dev):
+      self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+      self.ws = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=self.dev)
+    self.plan = _native.FramesPlan()
+    self._frames = None
+    self.update(cam_pose)
+
+  def update(self, cam_pose=None, **camera) -> "PreparedProjection":
+    """Upload other poses (and optionally ``cam_pitch`` / ``cam_height`` / offsets) for the same
+    shapes; raises if they need a different launch plan than the one already in use."""
+    import ctypes
+    self._camera.update({k: v for k, v in camera.items() if v is not None})
+    table = frames.build_frame_table(self.shape_in[0], cam_pose, self._camera["cam_pitch"],
+                                     self._camera["cam_height"], self._camera["width_offset"],
+                                     self._camera["height_offset"])
+    plan = _native.FramesPlan()
+    with _on_device(self.dev):
+      _native.check(_native.lib().dm_frames_prepare_f32(
+          ctypes.byref(self.params), _ptr(table), _ptr(self.buf), self.buf.numel(),
+          ctypes.byref(plan), _stream_ptr(self.dev)))
+    had = self._frames is not None
+    if had and bytes(plan) != bytes(self.plan):
+      raise _native.NativeError("the new camera state needs a different launch plan than the "
+                                "prepared one: make a new PreparedProjection")
+    self.plan, self._frames = plan, table        # (the host table must outlive the async copy)
+    return self
+
+  def status(self) -> int:
+    """0 unless a projection found a frame whose geometry did not fit the plan (synchronises)."""
+    return int(self.buf[1024:1028].view(torch.int32).item())
+
+  def _check(self, t, channels, dtype, what):
+    B, _, H, W = self.shape_in
+    if not (torch.is_tensor(t) and t.device == self.dev and t.dtype == dtype and t.is_contiguous()
+            and tuple(t.shape) == (B, channels, H, W)):
+      raise ValueError(f"{what} must be a contiguous {dtype} tensor of shape "
+                       f"{(B, channels, H, W)} on {self.dev}")
+
+  def _run(self, depth_map, value_map, valid_map, out, height, fused):
+    import ctypes
+    p = self.params
+    self._check(depth_map, self.shape_in[1], torch.float32, "depth_map")
+    if (value_map is not None) != bool(self.vc):
+      raise ValueError(f"prepared for {self.vc} value channels")
+    if value_map is not None:
+      self._check(value_map, self.vc, torch.float32, "value_map")
+    if (valid_map is not None) != bool(self.valid_c):
+      raise ValueError(f"prepared for {self.valid_c} valid-map channels")
+    if valid_map is not None:
+      self._check(valid_map, self.valid_c, torch.bool, "valid_map")
+    shape = (p.B, self.oc, p.mh, p.mw)
+    if out is None:
+      out = (torch.empty(shape, dtype=torch.float32, device=self.dev),
+             torch.empty(shape, dtype=torch.bool, device=self.dev))
+    top, mask = out
+    with _on_device(self.dev):
+      _native.check(_native.lib().dm_orth_project_prepared_f32(
+          ctypes.byref(p), ctypes.byref(self.plan), _ptr(self.buf), _ptr(depth_map), _ptr(value_map),
+          _ptr(valid_map), _ptr(top), _ptr(mask), _ptr(height),
+          None if fused is None else _ptr(fused[0]), None if fused is None else _ptr(fused[1]),
+          _ptr(self.ws), self.ws.numel(), _stream_ptr(self.dev)))
+    return top, mask
+
+  def orth_project(self, depth_map, value_map=None, valid_map=None, get_height_map=False, out=None):
+    """``orth_project`` of GPU tensors with the prepared camera state: ``(topdown, mask[,
+    height_map])``.  ``out`` = (float32, bool) tensors of shape (b, C, mh, mw) to write into
+    (static outputs, e.g. under graph capture)."""
+    height = None
+    if get_height_map and self.vc:
+      height = torch.empty((self.params.B, self.shape_in[1], self.params.mh, self.params.mw),
+                           dtype=torch.float32, device=self.dev)
+    top, mask = self._run(depth_map, value_map, valid_map, out, height, None)
+    if not get_height_map:
+      return top, mask
+    return top, mask, (top if height is None else torch.broadcast_to(height, top.shape))
+
+  def orth_project_and_fuse(self, depth_map, value_map=None, valid_map=None, out=None, fused_out=None):
+    """Per-frame maps plus the batch-fused map (max / min over the frames):
+    ``(topdown, mask, fused, fused_mask)``."""
+    p = self.params
+    if fused_out is None:
+      fused_out = (torch.empty((self.oc, p.mh, p.mw), dtype=torch.float32, device=self.dev),
+                   torch.empty((self.oc, p.mh, p.mw), dtype=torch.bool, device=self.dev))
+    top, mask = self._run(depth_map, value_map, valid_map, out, None, fused_out)
+    return top, mask, fused_out[0], fused_out[1]
+
+
+def prepare_orth_project(batch, height, width, cam_pose, width_offset, height_offset, cam_pitch,
+                         cam_height, map_res, map_width, map_height, focal_x, focal_y, center_x,
+                         center_y, trunc_depth_min, trunc_depth_max, trunc_height_max, clip_border,
+                         to_global, flip_h=True, fill_value=None, reduction=None, device=None,
+                         depth_channels=1, value_channels=0, valid_channels=0) -> PreparedProjection:
+  """Upload the camera state of ``batch`` frames of ``height`` x ``width`` pixels once; see
+  ``PreparedProjection``.  Arguments as ``orth_project``'s (reference maps.py:127-153)."""
+  return PreparedProjection(batch, height, width, depth_channels, value_channels, valid_channels,
+                            cam_pose, width_offset, height_offset, cam_pitch, cam_height, map_res,
+                            map_width, map_height, focal_x, focal_y, center_x, center_y,
+                            trunc_depth_min, trunc_depth_max, trunc_height_max, clip_border,
+                            to_global, flip_h, fill_value, reduction, device)
 
 
 def fuse_batch(maps: torch.Tensor, reduction=None, out: Optional[torch.Tensor] = None

@@ -84,6 +84,28 @@ class MapProjector:
                            for name in self._FIELDS})
 
 
+  def prepare(self, batch: int, cam_pose=None, value_channels: int = 0, valid_channels: int = 0,
+              depth_channels: int = 1, **overrides) -> "F.PreparedProjection":
+    """Upload the camera state of ``batch`` frames once and get an object whose
+    ``orth_project`` / ``orth_project_and_fuse`` only enqueue kernels (cheap on the host, HIP
+    graph capturable): see ``PreparedProjection``.  ``overrides``: any ``orth_project`` keyword
+    (``cam_pitch``, ``map_res``, ``fill_value``, ...), default = this projector's field."""
+    cam = self.cam_params
+    intr = {"focal_x": cam.fx, "focal_y": cam.fy, "center_x": cam.cx, "center_y": cam.cy}
+    names = ("width_offset", "height_offset", "cam_pitch", "cam_height", "map_res", "map_width",
+             "map_height", "focal_x", "focal_y", "center_x", "center_y", "trunc_depth_min",
+             "trunc_depth_max", "trunc_height_max", "clip_border", "to_global", "flip_h",
+             "fill_value", "reduction", "device")
+    unknown = set(overrides) - set(names) - {"height", "width"}
+    if unknown:
+      raise TypeError(f"prepare() got unexpected keyword arguments {sorted(unknown)}")
+    kw = {n: get(overrides.get(n), intr[n] if n in intr else getattr(self, n)) for n in names}
+    return F.prepare_orth_project(batch, get(overrides.get("height"), self.height),
+                                  get(overrides.get("width"), self.width),
+                                  get(cam_pose, self.cam_pose), depth_channels=depth_channels,
+                                  value_channels=value_channels, valid_channels=valid_channels, **kw)
+
+
 def _forwarding_method(fn, doc_ref: str):
   params = inspect.signature(fn).parameters
   names = tuple(params)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 4
+#define DM_ABI_VERSION 5
 
 typedef enum dm_status {
   DM_OK = 0,
@@ -247,6 +247,48 @@ int dm_scatter_f32(const float* values_dev, const int64_t* index_dev, float* can
                    uint8_t* mask_dev, int64_t R, int32_t C, int32_t Ci, size_t N, size_t M,
                    float fill, int32_t has_fill, int32_t reduction, void* workspace_dev,
                    size_t workspace_bytes, void* stream);
+
+/*
+ * Prepared frames: the camera state of a batch uploaded and analysed ONCE, then projected any
+ * number of times with nothing pose dependent left on the host -- the launch sequence of
+ * dm_orth_project_prepared_f32 depends only on `p`, `plan` and the pointers (no host-side
+ * geometry, no copy), so it may be captured into a HIP graph and replayed; to project other
+ * poses through a captured graph, call dm_frames_prepare_f32 again on the same buffer (stream
+ * ordered) -- the replay is valid when the new plan equals the captured one.
+ *
+ * Applies where the strip path does (max / min, trunc_depth_min >= 0 and a finite
+ * trunc_depth_max, map_width and image width multiples of 4, one camera pitch per batch, and the
+ * windows of all strips fit in LDS for every yaw); otherwise dm_frames_prepare_f32 returns
+ * DM_ERR_UNSUPPORTED and the caller stays with dm_orth_project_f32.
+ *
+ *   dm_frames_prepared_bytes     device bytes a prepared batch of p->B frames needs (0: the strip
+ *                                path never applies to `p`); the buffer must be 256-byte aligned.
+ *   dm_frames_prepare_f32        validates `frames` (host, as for dm_orth_project_f32), fills
+ *                                `plan_out` and enqueues ONE copy into `prepared_dev`.
+ *   dm_orth_project_prepared_f32 dm_orth_project_f32 with the frames taken from `prepared_dev`.
+ *                                A batch whose geometry does not fit `plan` (frames changed behind
+ *                                the plan's back) projects nothing for the frames concerned and
+ *                                sets the int32 at byte 1024 of `prepared_dev` non-zero.
+ *                                One projection at a time per prepared buffer (stream ordered).
+ */
+typedef struct dm_frames_plan {
+  int32_t strips;            /* column strips per frame */
+  int32_t strip_width;       /* pixels */
+  int32_t slab_cells;        /* cells of the largest map window a strip can have, any yaw */
+  int32_t max_rows;          /* rows / cells of the largest union window of a frame */
+  int32_t max_union_cells;
+  int32_t slack_cells;       /* float32 slack the windows carry */
+  int32_t reserved[2];
+} dm_frames_plan;
+
+size_t dm_frames_prepared_bytes(const dm_params* p);
+int dm_frames_prepare_f32(const dm_params* p, const dm_frame* frames, void* prepared_dev,
+                          size_t prepared_bytes, dm_frames_plan* plan_out, void* stream);
+int dm_orth_project_prepared_f32(const dm_params* p, const dm_frames_plan* plan, void* prepared_dev,
+                                 const float* depth_dev, const float* value_dev,
+                                 const uint8_t* valid_dev, float* out_dev, uint8_t* mask_dev,
+                                 float* height_dev, float* fused_dev, uint8_t* fused_mask_dev,
+                                 void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /*
  * Test hook: non-zero forces dm_orth_project_f32 onto the generic

@@ -164,3 +164,95 @@ def test_cfg2_full_size_strip_path_vs_oracle(dmap, oracle):
     junk = torch.full((B, 1, mh, mw), 123.0, device="cuda"); del junk
     t2, m2 = proj.orth_project(d, cam_pose=pose)
     assert torch.equal(t2, top) and torch.equal(m2, mask)
+
+
+def _cfg2_like(B=8, H=480, W=640, mh=512, mw=512):
+  g = torch.Generator().manual_seed(77)
+  depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g)
+  poses = []
+  for _ in range(3):
+    pose = torch.empty(B, 3).uniform_(-1, 1, generator=g)
+    pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)
+    poses.append(pose)
+  cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
+             width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
+             trunc_depth_min=0.15, trunc_depth_max=5.05, clip_border=0, to_global=True,
+             fill_value=-np.inf)
+  return depth, poses, cfg
+
+
+def test_prepared_frames_equal_plain_calls(dmap):
+  """MapProjector.prepare: the camera state uploaded once, then projections that only enqueue
+  kernels -- bit-equal to orth_project / orth_project_and_fuse, also after update()."""
+  lib = _lib()
+  depth, poses, cfg = _cfg2_like()
+  proj = dmap.MapProjector(**cfg)
+  d = depth.cuda()
+  lib.dm_debug_force_strips(4)          # (8 frames: the cost model would cut rows too)
+  try:
+    _prepared_checks(dmap, lib, proj, d, depth, poses, cfg)
+  finally:
+    lib.dm_debug_force_strips(0)
+
+
+def _prepared_checks(dmap, lib, proj, d, depth, poses, cfg):
+  prep = proj.prepare(depth.shape[0], cam_pose=poses[0])
+  for pose in poses:
+    prep.update(cam_pose=pose)
+    want = proj.orth_project_and_fuse(d, cam_pose=pose)
+    assert lib.dm_debug_last_path() == 2
+    got = prep.orth_project_and_fuse(d)
+    for a, b in zip(got, want):
+      assert torch.equal(a, b)
+    top, mask, height = prep.orth_project(d, get_height_map=True)
+    assert torch.equal(top, want[0]) and torch.equal(mask, want[1]) and height is top
+  assert prep.status() == 0
+  # value maps + valid maps + height map through the same object type
+  C = 3
+  g = torch.Generator().manual_seed(5)
+  value = torch.empty(depth.shape[0], C, 480, 640).uniform_(-1, 2, generator=g).cuda()
+  valid = (torch.empty(depth.shape[0], 1, 480, 640).uniform_(0, 1, generator=g) > 0.3).cuda()
+  prep2 = proj.prepare(depth.shape[0], cam_pose=poses[1], value_channels=C, valid_channels=1, fill_value=0.0)
+  got = prep2.orth_project(d, value_map=value, valid_map=valid, get_height_map=True)
+  want = proj.orth_project(d, value_map=value, valid_map=valid, cam_pose=poses[1], fill_value=0.0,
+                           get_height_map=True)
+  for a, b in zip(got, want):
+    assert torch.equal(a, b)
+  # parameters the strip path does not take cannot be prepared
+  from dungeon_maps_amd import _native
+  with pytest.raises(_native.NativeError):
+    proj.prepare(depth.shape[0], cam_pose=poses[0], reduction="sum")
+  with pytest.raises(_native.NativeError):
+    dmap.MapProjector(**dict(cfg, trunc_depth_max=None)).prepare(depth.shape[0], cam_pose=poses[0])
+
+
+def test_prepared_projection_replays_from_a_hip_graph(dmap):
+  """dm_orth_project_prepared_f32's launch sequence depends only on the parameters and the
+  pointers: captured into a HIP graph it replays bit-equal, and after update() (new poses into
+  the same buffers) the SAME graph projects the new poses."""
+  depth, poses, cfg = _cfg2_like(B=64)
+  proj = dmap.MapProjector(**cfg)
+  d = depth.cuda()
+  prep = proj.prepare(depth.shape[0], cam_pose=poses[0])
+  B, mh, mw = depth.shape[0], cfg["map_height"], cfg["map_width"]
+  out = (torch.empty(B, 1, mh, mw, device="cuda"), torch.empty(B, 1, mh, mw, dtype=torch.bool, device="cuda"))
+  fout = (torch.empty(1, mh, mw, device="cuda"), torch.empty(1, mh, mw, dtype=torch.bool, device="cuda"))
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(side):
+    for _ in range(2):                      # warm-up outside the capture (kernel attributes, allocations)
+      prep.orth_project_and_fuse(d, out=out, fused_out=fout)
+  torch.cuda.current_stream().wait_stream(side)
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    prep.orth_project_and_fuse(d, out=out, fused_out=fout)
+  for pose in poses:
+    prep.update(cam_pose=pose)
+    for t in out + fout:
+      t.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    want = proj.orth_project_and_fuse(d, cam_pose=pose)
+    assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
+    assert torch.equal(fout[0], want[2]) and torch.equal(fout[1], want[3])
+  assert prep.status() == 0

@@ -53,17 +53,20 @@ struct Rig {
 
 thread_local int g_force_strips = 0;       // dm_debug_force_strips
 
-bool make_plan(const dm_params& p, Plan& plan) {
+bool make_plan(const dm_params& p, Plan& plan, int strips = 0) {
   if (p.reduction != DM_REDUCE_MAX && p.reduction != DM_REDUCE_MIN) return false;
   if (p.mw % 4 != 0 || p.W % 4 != 0) return false;
-  if (p.mw > 32767 || p.mh > 32767) return false;
+  if (p.mw > 32767 || p.mh > 32767 || (int64_t)p.mh * p.mw >= (1ll << 28)) return false;   // (32-bit byte offsets)
   if (!(p.fill == p.fill)) return false;
   if (!p.has_dmin || !p.has_dmax || !(p.dmin >= 0.0f) || !(p.dmax >= p.dmin) || !isfinite(p.dmax))
     return false;
   Parts parts = choose_parts(p, 1, 1);
-  if (g_force_strips > 0) {      // tests: this many column strips whatever the cost model says
-    parts.pc = g_force_strips; parts.pr = 1; parts.pd = 1;
+  if (g_force_strips > 0) strips = g_force_strips;   // tests: whatever the cost model says
+  if (strips > 0) {              // this many column strips (more than the model's: narrower windows)
+    parts.pc = strips; parts.pr = 1; parts.pd = 1;
     parts.wp = ((p.W + parts.pc - 1) / parts.pc + 3) & ~3;
+    const int wp32 = (parts.wp + 31) & ~31;     // whole 128-byte lines where that keeps every strip
+    if (p.W % 32 == 0 && (parts.pc - 1) * wp32 < p.W) parts.wp = wp32;
     parts.hp = p.H;
   }
   if (parts.pr != 1 || parts.pd != 1 || parts.pc > strip::kMaxStrips || parts.wp % 4 != 0) return false;
@@ -248,17 +251,16 @@ struct Layout {               // workspace of the strip path
   size_t slab_bytes;
   Win16* g_wins;              // (B, kMaxStrips)
   Win16* g_unions;            // (B)
-  float* sink;                // kSinks x 64 B
   strip::RowEntry* g_rows;    // (B, max_rows, P)
 };
 
 size_t tables_bytes(int B, int rows, int P) {
   return 256 + up256((size_t)B * strip::kMaxStrips * sizeof(Win16)) + up256((size_t)B * sizeof(Win16)) +
-         kSinks * 64 + up256((size_t)B * rows * P * sizeof(strip::RowEntry));
+         up256((size_t)B * rows * P * sizeof(strip::RowEntry));
 }
 
 // [identities (256 B) | slabs ...] and, at the end of the region, the tables the kernels write
-// (windows, unions, sinks, row tables).
+// (windows, unions, row tables).
 bool carve(void* ws, size_t ws_bytes, int B, int rows, int P, Layout& l) {
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return false;
   const size_t tail = tables_bytes(B, rows, P) - 256;
@@ -270,7 +272,6 @@ bool carve(void* ws, size_t ws_bytes, int B, int rows, int P, Layout& l) {
   base += ws_bytes - tail;
   l.g_wins = reinterpret_cast<Win16*>(base); base += up256((size_t)B * strip::kMaxStrips * sizeof(Win16));
   l.g_unions = reinterpret_cast<Win16*>(base); base += up256((size_t)B * sizeof(Win16));
-  l.sink = reinterpret_cast<float*>(base); base += kSinks * 64;
   l.g_rows = reinterpret_cast<strip::RowEntry*>(base);
   return true;
 }
@@ -324,7 +325,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
   sa.depth = depth; sa.value = value; sa.valid = valid;
   sa.slabs = l.slabs;
   sa.out = out; sa.mask = mask; sa.mh = p.mh; sa.mw = p.mw;
-  sa.g_wins = l.g_wins; sa.g_unions = l.g_unions; sa.g_rows = l.g_rows; sa.status = pv.status; sa.sink = l.sink;
+  sa.g_wins = l.g_wins; sa.g_unions = l.g_unions; sa.g_rows = l.g_rows; sa.status = pv.status;
   sa.cfg = pv.cfg;
 #ifdef DM_STAMPS
   sa.stamps = g_stamp_buffer;
@@ -371,23 +372,52 @@ thread_local int g_force_legacy = 0;       // dm_debug_force_legacy_window
 size_t strip_workspace_extra(const dm_params& p) {
   Plan plan;
   if (!make_plan(p, plan)) return 0;
-  return prepared_bytes(p.B) + tables_bytes(p.B, p.mh, strip::kMaxStrips);
+  // Value maps: room for the slabs of every channel (up to 2 GiB of address space, touched only
+  // where strips share cells), so that all channels go through ONE scatter + merge launch pair
+  // instead of one pair per group of channels that fits the LDS-window path's 256 MiB.
+  size_t more_slabs = 0;
+  if (p.vc > 1) {
+    const size_t per_channel = (size_t)p.B * strip::kMaxStrips / 2 * (kMaxLdsBytes / 4) * 4;
+    more_slabs = per_channel * (size_t)p.vc;
+    if (more_slabs > ((size_t)2 << 30)) more_slabs = (size_t)2 << 30;
+  }
+  return prepared_bytes(p.B) + tables_bytes(p.B, p.mh, strip::kMaxStrips) + more_slabs;
 }
 
 namespace {
 
-const Plan* cached_plan(const dm_params& p) {
-  thread_local dm_params plan_key = {};
-  thread_local Plan plan;
-  thread_local bool plan_ok = false, plan_valid = false;
-  thread_local int plan_forced = 0;
-  if (!plan_valid || plan_forced != g_force_strips || memcmp(&plan_key, &p, sizeof(dm_params)) != 0) {
-    plan_key = p;
-    plan_forced = g_force_strips;
-    plan_ok = make_plan(p, plan);
-    plan_valid = true;
+// The plan for `p` with the cost model's split (strips = 0) or with a given number of strips.
+const Plan* cached_plan(const dm_params& p, int strips = 0) {
+  struct Slot { dm_params key; Plan plan; bool ok, valid; int strips, forced; };
+  thread_local Slot slots[4] = {};
+  thread_local int next = 0;
+  for (Slot& s : slots)
+    if (s.valid && s.strips == strips && s.forced == g_force_strips && memcmp(&s.key, &p, sizeof(dm_params)) == 0)
+      return s.ok ? &s.plan : nullptr;
+  Slot& s = slots[next];
+  next = (next + 1) % 4;
+  s.key = p; s.strips = strips; s.forced = g_force_strips; s.valid = true;
+  s.ok = make_plan(p, s.plan, strips);
+  return s.ok ? &s.plan : nullptr;
+}
+
+// The plan and rig the call takes: the cost model's split, or -- when a strip's window would not
+// fit in LDS -- the same image cut into 2, 4, 8 strips.  NULL: the strip path does not apply.
+const Plan* plan_and_rig(const dm_params& p, const dm_frame* frames_host, const Rig** rig_out) {
+  const int magnitude = validate_frames(p, frames_host, p.B);
+  if (magnitude < 0) return nullptr;
+  const Plan* plan = cached_plan(p);
+  if (!plan) return nullptr;
+  const Rig* rg = rig_of(p, *plan, frames_host[0], magnitude);
+  for (int strips = 2; !rg->fits && rg->cfg.cone_ok && strips <= strip::kMaxStrips && !g_force_strips; strips *= 2) {
+    if (strips <= plan->P) continue;
+    const Plan* narrower = cached_plan(p, strips);
+    if (!narrower) break;
+    plan = narrower;
+    rg = rig_of(p, *plan, frames_host[0], magnitude);
   }
-  return plan_ok ? &plan : nullptr;
+  *rig_out = rg;
+  return rg->fits ? plan : nullptr;
 }
 
 bool aligned_for_strips(const float* depth, const float* value, float* out, uint8_t* mask, float* height,
@@ -469,12 +499,9 @@ hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const floa
                      hipEvent_t before_projection, hipEvent_t after_projection, hipStream_t s) {
   if (g_force_legacy || p.B > 65535) return hipErrorNotSupported;
   if (!aligned_for_strips(depth, value, out, mask, height, fused, fused_mask)) return hipErrorNotSupported;
-  const Plan* plan = cached_plan(p);
+  const Rig* rg = nullptr;
+  const Plan* plan = plan_and_rig(p, frames_host, &rg);
   if (!plan) return hipErrorNotSupported;
-  const int magnitude = validate_frames(p, frames_host, p.B);
-  if (magnitude < 0) return hipErrorNotSupported;
-  const Rig* rg = rig_of(p, *plan, frames_host[0], magnitude);
-  if (!rg->fits) return hipErrorNotSupported;
   const size_t head = prepared_bytes(p.B);
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0 || ws_bytes < head) return hipErrorNotSupported;
   const dm_frames_plan fp = plan_of(*plan, *rg);
@@ -503,12 +530,9 @@ size_t strip_prepared_bytes(const dm_params& p) { return cached_plan(p) ? prepar
 hipError_t strip_prepare(const dm_params& p, const dm_frame* frames_host, void* prepared_dev,
                          size_t prepared_size, dm_frames_plan* plan_out, hipStream_t s) {
   if (g_force_legacy || p.B > 65535 || p.B < 1) return hipErrorNotSupported;
-  const Plan* plan = cached_plan(p);
+  const Rig* rg = nullptr;
+  const Plan* plan = plan_and_rig(p, frames_host, &rg);
   if (!plan) return hipErrorNotSupported;
-  const int magnitude = validate_frames(p, frames_host, p.B);
-  if (magnitude < 0) return hipErrorNotSupported;
-  const Rig* rg = rig_of(p, *plan, frames_host[0], magnitude);
-  if (!rg->fits) return hipErrorNotSupported;
   if (reinterpret_cast<uintptr_t>(prepared_dev) % 256 != 0 || prepared_size < prepared_bytes(p.B))
     return hipErrorInvalidValue;
   *plan_out = plan_of(*plan, *rg);
@@ -524,6 +548,7 @@ hipError_t run_strip_prepared(const dm_params& p, const dm_frames_plan& fp, void
                               hipStream_t s) {
   if (!aligned_for_strips(depth, value, out, mask, height, fused, fused_mask)) return hipErrorNotSupported;
   const Plan* plan = cached_plan(p);
+  if (plan && plan->P != fp.strips) plan = cached_plan(p, fp.strips);
   if (!plan || plan->P != fp.strips || plan->wp != fp.strip_width) return hipErrorNotSupported;
   if (before_projection) {
     const hipError_t e = hipEventRecord(before_projection, s);

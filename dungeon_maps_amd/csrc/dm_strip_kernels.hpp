@@ -16,7 +16,6 @@
 namespace dm {
 namespace {
 
-constexpr unsigned kSinks = 256;
 constexpr int kGeomBytes = 512;           // LDS reserved for the FrameGeom in front of the cover table
 static_assert(sizeof(strip::FrameGeom) == 336 && sizeof(strip::FrameGeom) <= kGeomBytes, "FrameGeom layout (tests/test_hip_strip.py reads it) and its LDS slot");
 
@@ -47,7 +46,6 @@ struct StripArgs {
   Win16* g_unions;            // (B)                 ... and the batch fuse
   strip::RowEntry* g_rows;    // (B, max_rows, P)   per row and strip: cover, owned
   int* status;                // set non-zero when a frame's geometry does not fit the launch
-  float* sink;                // kSinks x 64 bytes: where fill stores with nothing to write go
 #ifdef DM_STAMPS
   long long* stamps;
 #endif
@@ -94,6 +92,9 @@ template <int RED, bool HAS_VALID, bool HAS_VALUE, bool LEAN>
 __global__ void __launch_bounds__(kScatterThreads)
 k_strip_scatter(StripArgs a) {
   constexpr int VEC = 4;
+  // rows of a thread in flight per pipeline stage: value maps carry a second float4 per row and
+  // spill at four (the kernel is capped at 128 VGPRs by its 1024 threads)
+  constexpr int kRowsInFlight = HAS_VALUE ? 2 : dm::kRowsInFlight;
   extern __shared__ float lds[];
   const int part = blockIdx.x;                 // column strip
   const int chl = blockIdx.y;                  // channel within this launch's group
@@ -213,18 +214,27 @@ k_strip_scatter(StripArgs a) {
   };
   DM_STAMP(3);
   // Fill duty (as in k_window_scatter): map rows part, part + P, ... outside the union window
-  // (a store that has nothing to write -- inside U, or past the end -- goes to this workgroup's
-  // sink in the workspace: unlike k_window_scatter's merge, nothing rewrites all of U later, and
-  // other workgroups write owned groups of U while this one fills)
   const int g4 = a.mw >> 2;
   const int fill_rows = (a.mh - part + nparts - 1) / nparts;
   const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
-  float* const sink = a.sink + (((unsigned)part + (unsigned)nparts * ((unsigned)chl + (unsigned)bl)) % kSinks) * 16u;
   const bool do_fill = a.out != nullptr && fill_rows > 0;
   const int fill_total = do_fill ? fill_rows * g4 : 0;
   const int fill_steps = (fill_total + kScatterThreads - 1) / kScatterThreads;
   const float g4_inv = 1.0f / (float)g4;
   int fs = 0;
+  // Buffer stores: the map of this (frame, channel) as a raw buffer resource.  A store that has
+  // nothing to write gets an offset past the end of the buffer and is dropped by the hardware's
+  // range check: no branch, no dummy destination, scalar base + 32-bit offsets instead of 64-bit
+  // address arithmetic (-1 us).  (Write-through stores, sc0 sc1, measured the same as plain
+  // ones here, for this kernel and for the kernel boundary behind it.)
+  constexpr int kFillCachePolicy = 0;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned map_cells = (unsigned)a.mh * (unsigned)a.mw;
+  const __amdgpu_buffer_rsrc_t rs_out =
+      __builtin_amdgcn_make_buffer_rsrc(a.out + map_base, 0, do_fill ? map_cells * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_mask =
+      __builtin_amdgcn_make_buffer_rsrc(a.mask + map_base, 0, do_fill ? map_cells : 0u, 0x00020000);
+  const unsigned fill_bits = __float_as_uint(a.fill);
   auto fill_step = [&]() {
     const int i = fs * kScatterThreads + (int)threadIdx.x;
     ++fs;
@@ -235,13 +245,11 @@ k_strip_scatter(StripArgs a) {
     const int r = part + k * nparts, x = g << 2;
     const bool skip = (i >= fill_total) | (((unsigned)(r - U.z0) < (unsigned)U.h) &
                                            ((unsigned)(x - U.x0) < (unsigned)U.w));   // (no branch)
-    const size_t cell = map_base + (size_t)(r * a.mw + x);
-    float* po = a.out + cell;
-    uint8_t* pm = a.mask + cell;
-    po = skip ? sink : po;
-    pm = skip ? reinterpret_cast<uint8_t*>(sink + 8) : pm;
-    *reinterpret_cast<float4*>(po) = make_float4(a.fill, a.fill, a.fill, a.fill);
-    *reinterpret_cast<uint32_t*>(pm) = 0u;
+    const int cell = r * a.mw + x;
+    const int ob = skip ? 0x7ffffff0 : cell * 4, mb = skip ? 0x7ffffff0 : cell;
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, ob, 0,
+                                           kFillCachePolicy);
+    __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, mb, 0, kFillCachePolicy);
   };
   // the reductions' identities as float4s in front of the slabs (k_strip_merge reads them where
   // a strip has nothing for a group)

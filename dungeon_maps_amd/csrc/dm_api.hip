@@ -120,11 +120,15 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
   g_mid_event = nullptr;
   g_pre_event = nullptr;
   if (dm::window_path_supported(*p) && !g_force_generic) {
-    e = dm::run_strip(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
+    // the reference's default is no depth truncation at all (maps.py:1267-1268): the fast paths
+    // then run with bounds beyond which no ray can still be inside the map (same cells)
+    dm_params q = *p;
+    const dm_params& pp = dm::bounded_depth_params(q, frames) ? q : *p;
+    e = dm::run_strip(pp, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
                       p->vc ? height_dev : nullptr, fused_dev, fused_mask_dev, workspace_dev,
                       workspace_bytes, pre, mid, s);
     if (e == hipErrorNotSupported)
-      e = dm::run_window(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
+      e = dm::run_window(pp, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
                          p->vc ? height_dev : nullptr, fused_dev, fused_mask_dev, workspace_dev,
                          workspace_bytes, pre, mid, s);
   } else if (padded_route(*p) && !g_force_generic &&

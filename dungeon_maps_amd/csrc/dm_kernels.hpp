@@ -23,6 +23,9 @@ hipError_t run_mask_from_map(const float* map, float fill, uint8_t* mask, size_t
 
 // dm_window.hip -- LDS-windowed scatter + slab merge (max/min; heights or value maps)
 bool window_path_supported(const dm_params& p);
+// Finite depth bounds for a call that lacks them (no pixel beyond them can land in the map);
+// false: no such bounds.
+bool bounded_depth_params(dm_params& p, const dm_frame* frames_host);
 size_t window_workspace_bytes(const dm_params& p);
 hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const float* depth,
                       const float* value, const uint8_t* valid, float* out, uint8_t* mask,

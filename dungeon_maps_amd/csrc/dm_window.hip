@@ -47,6 +47,8 @@ namespace dm {
 // ---------------------------------------------------------------------------
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+bool bounded_depth_params(dm_params& p, const dm_frame* frames_host) { return bound_depth_range(p, frames_host); }
+
 bool window_path_supported(const dm_params& p) {
   if (p.reduction == DM_REDUCE_PROD) return false;      // generic path
   if (p.mw % 4 != 0) return false;
@@ -328,7 +330,7 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
   // get there (a long thin wedge: fine resolution, long range) the depth range is split too
   int max_area = 0;
   const int planes = p.reduction == DM_REDUCE_MEAN ? 2 : 1;     // mean: sum window + count window
-  const bool can_band = p.has_dmin && p.has_dmax && p.dmin >= 0.0f && p.dmax > p.dmin &&
+  const bool can_band = p.has_dmin && p.has_dmax && isfinite(p.dmin) && p.dmax > p.dmin &&
                         isfinite(p.dmax);
   thread_local std::vector<PartSlopes> slopes;
   const bool bounded = frustum_bounded(p);
@@ -355,7 +357,7 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
       Win16* row = wins.data() + (size_t)b * st.nparts;
       for (int k = 0; k < pd; ++k) {
         float dlo = p.dmin, dhi = p.dmax;
-        if (pd > 1) band_bounds(p.dmin, p.dmax, pd, k, dlo, dhi);
+        if (pd > 1) band_bounds(p.dmin, p.dmax, pd, k, dlo, dhi, parts.geo);
         for (int ip = 0; ip < image_parts; ++ip) {
           const Window w = part_window(p, fa, slopes[ip], bounded, dlo, dhi);
           row[k * image_parts + ip] = narrow(w);
@@ -421,14 +423,22 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
       if ((x.pd == 1) != (y.pd == 1)) return x.pd == 1;
       return x.pc * x.pr * x.pd < y.pc * y.pr * y.pd;
     });
-    for (const Parts& c : cands) {
-      if (same_shape && c.pc == last.parts.pc && c.pr == last.parts.pr && c.pd == last.parts.pd) continue;
-      if (evaluate(c)) {
-        const size_t geom = geometry_bytes(p.B, st.nparts);
-        fits = c.pd == 1 || g_force_bands ||
-               banded_split_pays(p, c, st.nparts, max_area * planes, ws_bytes > geom ? ws_bytes - geom : 0);
-        break;            // splits of more parts cost more still
+    for (const Parts& c0 : cands) {
+      if (same_shape && c0.pc == last.parts.pc && c0.pr == last.parts.pr && c0.pd == last.parts.pd) continue;
+      // (banded splits of a range that reaches beyond the map: geometric band edges first, then
+      // equal steps)
+      bool done = false;
+      for (int geo = c0.geo; geo >= 0 && !done; --geo) {
+        Parts c = c0;
+        c.geo = geo;
+        if (evaluate(c)) {
+          const size_t geom = geometry_bytes(p.B, st.nparts);
+          fits = c.pd == 1 || g_force_bands ||
+                 banded_split_pays(p, c, st.nparts, max_area * planes, ws_bytes > geom ? ws_bytes - geom : 0);
+          done = true;    // splits of more parts cost more still
+        }
       }
+      if (done) break;
     }
   }
   last.valid = fits;
@@ -677,7 +687,7 @@ extern "C" __attribute__((visibility("default"))) int dm_debug_windows(
     const FrameAffine fa = frame_affine(*p, frames[b]);
     for (int k = 0; k < pd; ++k) {
       float dlo = p->dmin, dhi = p->dmax;
-      if (pd > 1) band_bounds(p->dmin, p->dmax, pd, k, dlo, dhi);
+      if (pd > 1) band_bounds(p->dmin, p->dmax, pd, k, dlo, dhi, parts.geo);
       for (int ip = 0; ip < image_parts; ++ip) {
         const Window w = part_window(*p, fa, slopes[ip], bounded, dlo, dhi);
         int32_t* o = out_windows + ((size_t)b * nparts + k * image_parts + ip) * 4;

@@ -23,6 +23,7 @@ struct Parts {
   int wp, hp;          // part width (multiple of 4) / height in pixels
   int pd;              // depth bands: band k keeps the pixels with depth in [lo_k, hi_k] (every
                        // band reads the whole rectangle; its window is pd times shorter)
+  int geo;             // band edges: 0 equal steps, 1 geometric towards 0 (band_edge)
 };
 
 // Window of one part in map cells; w == 0: the part cannot hit the map.
@@ -69,11 +70,43 @@ __host__ inline Win16 narrow(Window w) {
 // Depth band k of pd over [dmin, dmax]: the same float expressions on the host (window
 // bounds) and in the kernel (depth test); neighbouring bands share their boundary value,
 // which is harmless for max / min.
+//   geo = 0: equal steps (a truncated range of a few metres).
+//   geo = 1: a range that runs to where rays leave the map (bound_depth_range: tens of metres,
+//            possibly from -D to +D): band edges in geometric progression towards 0 -- the map
+//            is dense near the camera, and the far bands are mostly outside it.  Negative depths
+//            get 3 of 8 (1 of 4, 1 of 2) bands.
+__host__ __device__ inline float band_edge(float dmin, float dmax, int pd, int j, int geo) {
+  if (j <= 0) return dmin;
+  if (j >= pd) return dmax;
+  if (!geo) {
+    const float step = (dmax - dmin) / (float)pd;
+    return __builtin_fmaf((float)j, step, dmin);
+  }
+  const int nneg = dmin < 0.0f && dmax > 0.0f ? (pd >= 8 ? 3 : 1) : (dmax <= 0.0f ? pd : 0);
+  float e;
+  if (j < nneg) {                              // dmin * 0.3^j
+    e = dmin;
+    for (int i = 0; i < j; ++i) e *= 0.3f;
+  } else if (j == nneg && nneg > 0 && nneg < pd) {
+    e = 0.0f;
+  } else {                                     // dmax * 0.55^(pd - j)
+    e = dmax;
+    for (int i = j; i < pd; ++i) e *= 0.55f;
+  }
+  e = e < dmin ? dmin : e;
+  return e > dmax ? dmax : e;
+}
 __host__ __device__ inline void band_bounds(float dmin, float dmax, int pd, int k, float& lo,
-                                            float& hi) {
-  const float step = (dmax - dmin) / (float)pd;
-  lo = k == 0 ? dmin : __builtin_fmaf((float)k, step, dmin);
-  hi = k == pd - 1 ? dmax : __builtin_fmaf((float)(k + 1), step, dmin);
+                                            float& hi, int geo = 0) {
+  lo = band_edge(dmin, dmax, pd, k, geo);
+  hi = band_edge(dmin, dmax, pd, k + 1, geo);
+}
+
+// Geometric band edges where the depth range reaches beyond the map (or behind the camera).
+__host__ inline int band_mode(const dm_params& p) {
+  if (!p.has_dmin || !p.has_dmax) return 0;
+  const double cells = ((double)p.dmax - (double)p.dmin) / (double)p.res;
+  return (p.dmin < 0.0f || cells > (double)(p.mw > p.mh ? p.mw : p.mh)) ? 1 : 0;
 }
 
 __host__ Parts choose_parts(const dm_params& p, int min_parts = 1, int pd = 1) {
@@ -91,7 +124,7 @@ __host__ Parts choose_parts(const dm_params& p, int min_parts = 1, int pd = 1) {
   const int units = (p.W + unit - 1) / unit;
   const int max_pr = p.H / 16 > 8 ? 8 : (p.H / 16 > 0 ? p.H / 16 : 1);
   Parts best;
-  best.pc = 1; best.pr = 1; best.pd = pd; best.wp = units * unit; best.hp = p.H;
+  best.pc = 1; best.pr = 1; best.pd = pd; best.geo = pd > 1 ? band_mode(p) : 0; best.wp = units * unit; best.hp = p.H;
   double best_cost = INFINITY;
   int best_n = 0;
   for (int pc = 1; pc <= units && pc <= 16; ++pc) {
@@ -214,8 +247,62 @@ __host__ PartSlopes part_slopes(const dm_params& p, int q0, int q1, int r0, int 
 // behind the camera: a double cone): trunc_depth_min >= 0 is required, trunc_depth_max is not --
 // without it the part's rays are followed until they have left the map.
 __host__ bool frustum_bounded(const dm_params& p) {
-  if (!p.has_dmin || !(p.dmin >= 0.0f)) return false;
+  if (!p.has_dmin) return false;
+  // both ends finite: any sign (the corners of a band are affine in the depth, so the bounding
+  // box of its eight corners holds the whole band, through the camera's cell if it spans 0)
+  if (p.has_dmax && isfinite(p.dmin) && isfinite(p.dmax)) return p.dmax >= p.dmin;
+  if (!(p.dmin >= 0.0f)) return false;          // open far end: forward rays only
   return !p.has_dmax || p.dmax >= p.dmin;       // (dmax may be +inf)
+}
+
+// Missing depth truncations (the reference's default is None for both, maps.py:1267-1268): a
+// pixel whose depth is so large -- or so negative -- that its ray has left the map cannot land
+// in it, so the call may be given finite bounds without changing a single cell.  With the
+// axis-aligned rotations a point at depth d lies |d| * sqrt(ax^2 + g^2) metres from the camera in
+// the map plane (g = Rp[5] * ay + Rp[8]); the map reaches at most r_far metres from the camera.
+// Fills in dmin / dmax (rounded up on a 1.25^k grid so that the per-shape caches keep their
+// keys) and returns true; false when no bound exists (a ray that points straight down or up
+// never leaves its cell) or the rotations are not the projector's.
+__host__ inline bool bound_depth_range(dm_params& p, const dm_frame* f) {
+  if (p.has_dmin && p.has_dmax) return false;
+  if (!(p.res > 0.0f) || !(p.fx > 0.0f) || !(p.fy > 0.0f)) return false;
+  // smallest planar speed of a ray: sqrt(min ax^2 + min g^2) over the image
+  const double ax0 = (0.0 - (double)p.cx) / (double)p.fx, ax1 = ((double)(p.W - 1) - (double)p.cx) / (double)p.fx;
+  const double ax_min = (ax0 <= 0.0 && ax1 >= 0.0) ? 0.0 : fmin(fabs(ax0), fabs(ax1));
+  double ay[2];
+  for (int i = 0; i < 2; ++i) {
+    double yr = i ? (double)(p.H - 1) : 0.0;
+    if (p.flip_h) yr = (double)(p.H - 1) - yr;
+    ay[i] = (yr - (double)p.cy) / (double)p.fy;
+  }
+  double worst = 0.0;
+  for (int b = 0; b < p.B; ++b) {
+    const float* rp = f[b].Rp;
+    const float* ry = f[b].Ry;
+    if (!(rp[0] == 1.0f && rp[1] == 0.0f && rp[2] == 0.0f && rp[3] == 0.0f && rp[6] == 0.0f)) return false;
+    if (p.to_global && !(ry[1] == 0.0f && ry[3] == 0.0f && ry[4] == 1.0f && ry[5] == 0.0f && ry[7] == 0.0f))
+      return false;
+    const double g0 = (double)rp[5] * ay[0] + (double)rp[8], g1 = (double)rp[5] * ay[1] + (double)rp[8];
+    const double g_min = (g0 > 0.0) == (g1 > 0.0) ? fmin(fabs(g0), fabs(g1)) : 0.0;
+    const double speed = sqrt(ax_min * ax_min + g_min * g_min);
+    if (!(speed > 1e-3)) return false;
+    // the camera's cell and its distance to the farthest map corner, in cells (+ slack)
+    const double inv = 1.0 / (double)p.res;
+    const double xd = (p.to_global ? (double)f[b].tx * inv : 0.0) + (double)f[b].width_offset;
+    double zd = (p.to_global ? (double)f[b].tz * inv : 0.0) + (double)f[b].height_offset;
+    if (p.flip_h) zd = (double)(p.mh - 1) - zd;
+    const double dx = fmax(fabs(xd), fabs(xd - (double)p.mw)), dz = fmax(fabs(zd), fabs(zd - (double)p.mh));
+    const double r_far = (sqrt(dx * dx + dz * dz) + 4.0) * (double)p.res;
+    const double d = r_far / speed;
+    if (!(d == d) || !isfinite(d)) return false;
+    if (d > worst) worst = d;
+  }
+  double grid = 1.0;                              // next 1.25^k above 1.01 * worst
+  while (grid < 1.01 * worst) grid *= 1.25;
+  if (grid > 1e6) return false;
+  if (!p.has_dmax) { p.has_dmax = 1; p.dmax = (float)grid; }
+  if (!p.has_dmin) { p.has_dmin = 1; p.dmin = -(float)grid; }
+  return p.dmax >= p.dmin;
 }
 
 __host__ Window part_window(const dm_params& p, const FrameAffine& fa, const PartSlopes& ps,

@@ -282,7 +282,7 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   bool lds_ready = false;
   const unsigned dummy = (unsigned)(RED == kMean ? 2 * area : area) + (threadIdx.x & 63u);   // 64 scratch cells after the window(s)
   float band_lo = a.dmin, band_hi = a.dmax;    // this part's depth band (wave-uniform)
-  if (a.parts.pd > 1) band_bounds(a.dmin, a.dmax, a.parts.pd, pdk, band_lo, band_hi);
+  if (a.parts.pd > 1) band_bounds(a.dmin, a.dmax, a.parts.pd, pdk, band_lo, band_hi, a.parts.geo);
   // neighbouring bands share their boundary value: harmless for max / min, counted twice by
   // a sum, which therefore takes every band but the last half open
   const bool last_band = pdk == a.parts.pd - 1;

@@ -152,3 +152,37 @@ def test_bench_rccl_leg_with_one_rank():
   assert "RCCL" in one["config"]["parallelism"]
   assert one["fused_checksum"] == solo["fused_checksum"]
   assert one["fused_checksum"]["cells"] > 0
+
+
+@pytest.mark.parametrize("dmin,dmax,fast", [(0.15, None, True), (None, 5.05, True), (None, None, False)])
+def test_missing_depth_truncations_at_full_geometry(dmap, oracle, dmin, dmax, fast):
+  """The reference's default is no depth truncation (maps.py:1267-1268).  The call then runs
+  with finite bounds beyond which no ray can still be inside the map (bound_depth_range), so
+  the LDS-windowed kernels take it (depth bands) instead of the global-atomic path: same cells
+  as the oracle on edge depths (negative, zero, huge, NaN, +-inf), 640x480 -> 512x512."""
+  from dungeon_maps_amd import _native
+  lib = _native.lib()
+  B, H, W, mh, mw = 16, 480, 640, 512, 512
+  g = torch.Generator().manual_seed(606)
+  depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g)
+  flat = depth.view(-1)
+  idx = torch.randint(0, flat.numel(), (11000,), generator=g)
+  flat[idx[:4000]] = -flat[idx[:4000]]
+  flat[idx[4000:6000]] = 0.0
+  flat[idx[6000:8000]] = 1e4
+  flat[idx[8000:9000]] = float("nan")
+  flat[idx[9000:10000]] = float("inf")
+  flat[idx[10000:]] = -float("inf")
+  pose = torch.empty(B, 3).uniform_(-1, 1, generator=g)
+  pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)
+  cfg = dict(_cfg(H, W, mh, mw, -np.inf), trunc_depth_min=dmin, trunc_depth_max=dmax)
+  proj = dmap.MapProjector(**cfg)
+  top, mask = proj.orth_project(depth.cuda(), cam_pose=pose)
+  path = lib.dm_debug_last_path()
+  torch.cuda.synchronize()
+  want = oracle.orth_project(depth.numpy(), nthreads=8,
+                             **dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose.numpy()))
+  np.testing.assert_array_equal(mask.cpu().numpy(), want[1])
+  np.testing.assert_array_equal(top.cpu().numpy(), want[0])
+  if fast:
+    assert path in (1, 2), "expected the LDS-windowed kernels, not the global-atomic path"

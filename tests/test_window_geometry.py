@@ -22,12 +22,40 @@ def _params(B, H, W, cfg, intr):
   return F._make_params(key)[0]
 
 
-def _band(dmin, dmax, pd, k):
-  """band_bounds() of dm_window_geometry.hpp in float32 (fma = exact product, one rounding)."""
-  dmin, dmax = np.float32(dmin), np.float32(dmax)
-  step = np.float32((dmax - dmin) / np.float32(pd))
-  fma = lambda a: np.float32(np.float64(a) * np.float64(step) + np.float64(dmin))
-  return (dmin if k == 0 else fma(k)), (dmax if k == pd - 1 else fma(k + 1))
+def _band_edge(dmin, dmax, pd, j, geo):
+  """band_edge() of dm_window_geometry.hpp in float32 (fma = exact product, one rounding)."""
+  f = np.float32
+  dmin, dmax = f(dmin), f(dmax)
+  if j <= 0:
+    return dmin
+  if j >= pd:
+    return dmax
+  if not geo:
+    step = f((dmax - dmin) / f(pd))
+    return f(np.float64(j) * np.float64(step) + np.float64(dmin))
+  nneg = (3 if pd >= 8 else 1) if (dmin < 0 and dmax > 0) else (pd if dmax <= 0 else 0)
+  if j < nneg:
+    e = dmin
+    for _ in range(j):
+      e = f(e * f(0.3))
+  elif j == nneg and 0 < nneg < pd:
+    e = f(0.0)
+  else:
+    e = dmax
+    for _ in range(j, pd):
+      e = f(e * f(0.55))
+  return min(max(e, dmin), dmax)
+
+
+def _band(dmin, dmax, pd, k, geo=0):
+  return _band_edge(dmin, dmax, pd, k, geo), _band_edge(dmin, dmax, pd, k + 1, geo)
+
+
+def _band_mode(cfg):
+  """band_mode(): geometric band edges where the depth range reaches beyond the map."""
+  dmin, dmax = np.float32(cfg["trunc_depth_min"]), np.float32(cfg["trunc_depth_max"])
+  cells = (float(dmax) - float(dmin)) / float(np.float32(cfg["map_res"]))
+  return int(dmin < 0 or cells > max(cfg["map_width"], cfg["map_height"]))
 
 
 def _random_case(rng, fine, open_far=False):
@@ -93,7 +121,7 @@ def test_every_valid_pixel_lands_inside_its_parts_window(oracle, fine, open_far)
         if open_far:
           in_band = depth[:, 0] >= np.float32(cfg["trunc_depth_min"])
         else:
-          lo, hi = _band(cfg["trunc_depth_min"], cfg["trunc_depth_max"], pd, k)
+          lo, hi = _band(cfg["trunc_depth_min"], cfg["trunc_depth_max"], pd, k, _band_mode(cfg) if pd > 1 else 0)
           in_band = (depth[:, 0] >= lo) & (depth[:, 0] <= hi)
         for iy in range(pr):
           for ix in range(pc):

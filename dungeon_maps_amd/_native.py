@@ -78,6 +78,10 @@ _SIGNATURES = {
     "dm_debug_force_generic_path": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_force_bands": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_slab_budget": (ctypes.c_size_t, [ctypes.c_size_t]),
+    "dm_debug_count_escapes": (ctypes.c_int, [
+        ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dm_debug_last_path": (ctypes.c_int, []),
     "dm_debug_force_legacy_window": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_force_strips": (ctypes.c_int, [ctypes.c_int]),

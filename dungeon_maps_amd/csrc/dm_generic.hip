@@ -365,3 +365,61 @@ hipError_t run_mask_from_map(const float* map, float fill, uint8_t* mask, size_t
 }
 
 }  // namespace dm
+
+// ---------------------------------------------------------------------------
+// dm_debug_count_escapes: the silent-drop bound of the LDS-windowed paths, checked ON THE DEVICE.
+// Every pixel is projected with the device's own float32 arithmetic (project_pixel); a pixel
+// that lands in the map but outside the window -- or the per-row cover -- of the image part that
+// owns it would be lost by those paths without a trace.  counts[0] = pixels landing in the map,
+// counts[1] = those outside their part's window, counts[2] = those outside their strip's cover.
+namespace dm {
+namespace {
+
+__global__ void __launch_bounds__(256)
+k_count_escapes(View v, int dc, int valid_c, const dm_frame* __restrict__ frames,
+                const float* __restrict__ depth, const uint8_t* __restrict__ valid,
+                const int* __restrict__ windows, int pc, int pr, int wp, int hp,
+                const uint32_t* __restrict__ covers, unsigned long long* __restrict__ counts) {
+  const int b = blockIdx.z, ch = blockIdx.y;
+  const int N = v.H * v.W;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const Cam cam = load_cam(frames + b);
+  const int r = i / v.W, q = i - r * v.W;
+  bool ok = border_ok(v, r, q);
+  if (valid) ok = ok && valid[((size_t)b * valid_c + (valid_c == 1 ? 0 : ch)) * N + i] != 0;
+  const float z = depth[((size_t)b * dc + ch) * N + i];
+  const Hit h = project_pixel(v, cam, z, ray_x(v, q), ray_y(v, r), ok);
+  if (h.cell < 0) return;
+  const int zb = h.cell / v.mw, xb = h.cell - zb * v.mw;
+  const int part = (r / hp) * pc + q / wp;
+  const int* w = windows + ((size_t)b * pc * pr + part) * 4;
+  atomicAdd(counts + 0, 1ull);
+  if (!(xb >= w[0] && xb < w[0] + w[2] && zb >= w[1] && zb < w[1] + w[3])) atomicAdd(counts + 1, 1ull);
+  if (covers) {
+    const uint32_t cv = covers[(((size_t)b * v.mh + zb) * pc + part) * 2];
+    if (!(xb >= (int)(cv & 0xffffu) && xb < (int)(cv >> 16))) atomicAdd(counts + 2, 1ull);
+  }
+}
+
+}  // namespace
+}  // namespace dm
+
+extern "C" __attribute__((visibility("default"))) int dm_debug_count_escapes(
+    const dm_params* p, const dm_frame* frames_host, const float* depth_dev, const uint8_t* valid_dev,
+    const int32_t* windows_dev, int32_t pc, int32_t pr, int32_t wp, int32_t hp,
+    const uint32_t* covers_dev, unsigned long long* counts_dev, void* workspace_dev, void* stream) {
+  using namespace dm;
+  if (!p || !frames_host || !depth_dev || !windows_dev || !counts_dev || !workspace_dev || p->B < 1 ||
+      pc < 1 || pr < 1 || wp < 1 || hp < 1 || (covers_dev && pr != 1))
+    return -1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (upload_frames(*p, frames_host, workspace_dev, s) != hipSuccess) return -2;
+  if (hipMemsetAsync(counts_dev, 0, 3 * sizeof(unsigned long long), s) != hipSuccess) return -2;
+  const View v = make_view(*p);
+  const int N = p->H * p->W;
+  hipLaunchKernelGGL(k_count_escapes, dim3((N + 255) / 256, p->dc, p->B), dim3(256), 0, s, v, p->dc,
+                     p->valid_c, static_cast<const dm_frame*>(workspace_dev), depth_dev, valid_dev,
+                     windows_dev, pc, pr, wp, hp, covers_dev, counts_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

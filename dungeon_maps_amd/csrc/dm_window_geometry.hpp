@@ -181,6 +181,7 @@ __host__ bool axis_aligned(const FrameRec* f, int B) {
 // (ax, ay = ray slopes of the pixel).  One coefficient set per frame, in double.
 struct FrameAffine {
   double xa, xb, xc, xd, za, zb, zc, zd;
+  double mag;          // largest float32 intermediate of the device's pixel arithmetic, in cells
   bool finite;
 };
 
@@ -208,6 +209,7 @@ __host__ FrameAffine frame_affine(const dm_params& p, const dm_frame& f) {
   a.xd = t2[0] * inv + f.width_offset;
   double za = G[2][0] * inv, zb = G[2][1] * inv, zc = G[2][2] * inv;
   double zd = t2[2] * inv + f.height_offset;
+  a.mag = fmax(fmax(fabs(t2[0] * inv), fabs(t2[2] * inv)), fmax(fabs((double)f.width_offset), fabs((double)f.height_offset)));
   if (p.flip_h) { za = -za; zb = -zb; zc = -zc; zd = (double)(p.mh - 1) - zd; }
   a.za = za; a.zb = zb; a.zc = zc; a.zd = zd;
   a.finite = isfinite(a.xa) && isfinite(a.xb) && isfinite(a.xc) && isfinite(a.xd) &&
@@ -308,7 +310,12 @@ __host__ inline bool bound_depth_range(dm_params& p, const dm_frame* f) {
 __host__ Window part_window(const dm_params& p, const FrameAffine& fa, const PartSlopes& ps,
                             bool bounded, float dlo, float dhi) {
   if (ps.empty) return Window{0, 0, 0, 0};
-  if (!bounded || !fa.finite) return Window{0, 0, p.mw, p.mh};
+  // The 2 cells of slack below cover the float32 rounding of the device's cell coordinates
+  // (a few ulp of the largest intermediate, x / res before the offset is added) while that
+  // intermediate stays below 2^20 cells (ulp 1/8 cell).  Farther from the origin -- a pose
+  // millions of cells out, cancelled by the offsets -- no window is claimed: the whole map,
+  // which does not fit in LDS, so the call takes the global-atomic path.
+  if (!bounded || !fa.finite || !(fa.mag < 1048576.0)) return Window{0, 0, p.mw, p.mh};
   double lo_x = INFINITY, hi_x = -INFINITY, lo_z = INFINITY, hi_z = -INFINITY;
   double poison = 0.0;                         // NaN as soon as one corner is not finite
   const bool open_far = !p.has_dmax || !isfinite(dhi);

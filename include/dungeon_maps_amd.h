@@ -363,6 +363,19 @@ int dm_debug_strip_geometry_dev(const dm_params* p, const dm_frame* frames_host,
                                 void* stream);
 
 /*
+ * Test hook (GPU): the silent-drop bound of the LDS-windowed paths checked on the device.  Every
+ * pixel is projected with the device's float32 arithmetic; counts_dev[3] (uint64) receives
+ * {pixels landing in the map, those outside the window of the image part that owns them, those
+ * outside their strip's per-row cover}.  windows_dev (B, pc*pr, 4) int32 {x0, z0, w, h} as
+ * dm_debug_windows (pd = 1) or dm_debug_strip_geometry return them, covers_dev (B, mh, pc, 2)
+ * uint32 as dm_debug_strip_geometry returns them, or NULL.  workspace_dev: B * 128 bytes.
+ */
+int dm_debug_count_escapes(const dm_params* p, const dm_frame* frames, const float* depth_dev,
+                           const uint8_t* valid_dev, const int32_t* windows_dev, int32_t pc,
+                           int32_t pr, int32_t wp, int32_t hp, const uint32_t* covers_dev,
+                           unsigned long long* counts_dev, void* workspace_dev, void* stream);
+
+/*
  * Test hook: caps the bytes of LDS-window slabs one channel group of the calling thread's
  * projections may use (0 = no cap; returns the previous cap), so that value maps of few
  * frames go through several channel groups -- the route a 40-class object map of a full

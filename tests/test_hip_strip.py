@@ -256,3 +256,57 @@ def test_prepared_projection_replays_from_a_hip_graph(dmap):
     assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
     assert torch.equal(fout[0], want[2]) and torch.equal(fout[1], want[3])
   assert prep.status() == 0
+
+
+def test_no_pixel_escapes_its_window_on_the_device(dmap, oracle):
+  """dm_debug_count_escapes projects every pixel with the DEVICE's float32 arithmetic and
+  counts those that land in the map but outside the window (or per-row cover) of the image
+  part that owns them -- what the LDS-windowed paths would drop silently.  Zero, over a sweep
+  that includes poses 3e3 ... 3e4 cells from the origin (offsets cancelling the translation)
+  and map_res down to 0.004, for the strip path's geometry and the host-geometry windows."""
+  from dungeon_maps_amd import frames
+  lib = _lib()
+  rng = np.random.default_rng(31337)
+  landed = strip_cases = window_cases = 0
+  for it in range(40):
+    B, H, W, depth, pose, cfg = _case(rng, big_offsets=it % 2 == 0)
+    mh, mw = cfg["map_height"], cfg["map_width"]
+    intr = oracle.camera_intrinsics(W, H, cfg["hfov"], cfg["vfov"])
+    p = _params(B, H, W, cfg, intr)
+    table = frames.build_frame_table(B, pose if cfg["to_global"] else None, cfg["cam_pitch"],
+                                     cfg["cam_height"], cfg["width_offset"], cfg["height_offset"])
+    d = torch.from_numpy(depth).cuda()
+    counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+    ws = torch.zeros(B * 128 + 256, dtype=torch.uint8, device="cuda")
+    # (a) the strip path's device-side geometry
+    lib.dm_debug_force_strips(int(rng.integers(1, 9)))
+    try:
+      P, geom, covers, bound = _geometry(lib, p, table, B, mh)
+    finally:
+      lib.dm_debug_force_strips(0)
+    if P > 0 and bound[0] >= 0 and geom[:, 0].all():
+      wins = torch.from_numpy(np.ascontiguousarray(geom[:, 8:8 + 4 * P].reshape(B, P, 4))).cuda()
+      both = torch.from_numpy(np.stack(covers, axis=-1).astype(np.uint32).view(np.int32)).cuda()
+      rc = lib.dm_debug_count_escapes(ctypes.byref(p), table.data_ptr(), d.data_ptr(), None, wins.data_ptr(),
+                                      P, 1, int(geom[0, 2]), H, both.data_ptr(), counts.data_ptr(),
+                                      ws.data_ptr(), None)
+      assert rc == 0
+      n, out_w, out_c = counts.cpu().tolist()
+      assert out_w == 0 and out_c == 0, (cfg, n, out_w, out_c)
+      landed += n; strip_cases += 1
+    # (b) the host-geometry windows of the LDS-windowed path (no depth bands)
+    for min_parts in (1, 4):
+      parts = (ctypes.c_int32 * 5)()
+      n_parts = lib.dm_debug_windows(ctypes.byref(p), table.data_ptr(), min_parts, 1, parts, None, 0)
+      wins = np.zeros((B, n_parts, 4), dtype=np.int32)
+      lib.dm_debug_windows(ctypes.byref(p), table.data_ptr(), min_parts, 1, parts,
+                           wins.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), B * n_parts)
+      wd = torch.from_numpy(wins).cuda()
+      rc = lib.dm_debug_count_escapes(ctypes.byref(p), table.data_ptr(), d.data_ptr(), None, wd.data_ptr(),
+                                      parts[0], parts[1], parts[3], parts[4], None, counts.data_ptr(),
+                                      ws.data_ptr(), None)
+      assert rc == 0
+      n, out_w, _ = counts.cpu().tolist()
+      assert out_w == 0, (cfg, list(parts), n, out_w)
+      window_cases += 1
+  assert landed > 50_000 and strip_cases >= 15 and window_cases >= 60

@@ -5,9 +5,9 @@
 // rotations have the axis-aligned pattern the fast arithmetic needs, one camera pitch for the
 // whole batch, magnitudes within the float32 slack), copies them to the device (or takes
 // them from the device as they are: dm_frames_prepare_f32 / dm_orth_project_prepared_f32)
-// and launches k_strip_scatter + k_strip_merge with sizes taken from a bound that holds for
-// EVERY yaw and position of the camera (cached per camera rig).  The windows themselves are
-// derived on the device.
+// and launches k_strip_prepare (the frames' geometry and row tables, on the device: once per
+// set of poses for prepared frames) and k_strip_scatter + k_strip_merge with sizes taken from
+// a bound that holds for EVERY yaw and position of the camera (cached per camera rig).
 #include <math.h>
 #include <string.h>
 
@@ -180,8 +180,7 @@ void compute_rig(const dm_params& p, const Plan& plan, const dm_frame& f0, int m
   rg.slab_stride = ((int)ceil(area) + 3) & ~3;
   rg.max_rows = (int)ceil(uh);
   rg.max_union = (((int)ceil(uw) + 2 * strip::kSpanAlign + 3) & ~3) * rg.max_rows;
-  const size_t lds = ((size_t)rg.slab_stride + 64) * 4 + kGeomBytes + (size_t)rg.max_rows * plan.P * sizeof(strip::RowEntry);
-  rg.fits = lds <= (size_t)kMaxLdsBytes;
+  rg.fits = strip_lds_bytes(rg.slab_stride, rg.max_rows, p.H) <= (size_t)kMaxLdsBytes;
 }
 
 const Rig* rig_of(const dm_params& p, const Plan& plan, const dm_frame& f0, int magnitude) {
@@ -230,49 +229,52 @@ MergeKernel pick_merge_kernel(bool is_max, int P) {
 }
 
 // Device copy of a batch's camera state as the kernels read it ("prepared frames"):
-// [Cfg (kCfgBytes) | status word (256 B) | frame records].  Lives at the head of the workspace
-// for dm_orth_project_f32 (staged by one copy per call) or in a buffer of the caller's that
-// dm_frames_prepare_f32 filled once (dm_orth_project_prepared_f32: no copy, no host geometry).
+// [Cfg (kCfgBytes) | status word (256 B) | frame records | frame tables].  Lives at the head of
+// the workspace for dm_orth_project_f32 (staged by one copy per call, the tables by
+// k_strip_prepare right behind it) or in a buffer of the caller's that dm_frames_prepare_f32
+// filled once (dm_orth_project_prepared_f32: no copy and no geometry, host or device).
 struct PreparedView {
   const strip::Cfg* cfg;
   int* status;
   const float* frames;        // (B, 32)
+  FrameTables t;              // sized for mh rows of kMaxStrips strips; indexed with the plan's max_rows and P
 };
 constexpr size_t kStatusBytes = 256;
-inline size_t prepared_bytes(int B) { return kCfgBytes + kStatusBytes + up256((size_t)B * sizeof(dm_frame)); }
-inline PreparedView view_prepared(void* dev) {
+inline size_t tables_bytes(const dm_params& p) {
+  return up256((size_t)p.B * strip::kMaxStrips * sizeof(Win16)) + up256((size_t)p.B * sizeof(Win16)) +
+         up256((size_t)p.B * sizeof(int)) +
+         up256((size_t)p.B * p.mh * strip::kMaxStrips * sizeof(strip::RowEntry));
+}
+inline size_t staged_bytes(int B) {       // what the host copies: Cfg, status, frame records
+  return kCfgBytes + kStatusBytes + up256((size_t)B * sizeof(dm_frame));
+}
+inline size_t prepared_bytes(const dm_params& p) { return staged_bytes(p.B) + tables_bytes(p); }
+inline PreparedView view_prepared(const dm_params& p, void* dev) {
   unsigned char* base = static_cast<unsigned char*>(dev);
-  return PreparedView{reinterpret_cast<const strip::Cfg*>(base), reinterpret_cast<int*>(base + kCfgBytes),
-                      reinterpret_cast<const float*>(base + kCfgBytes + kStatusBytes)};
+  PreparedView v;
+  v.cfg = reinterpret_cast<const strip::Cfg*>(base);
+  v.status = reinterpret_cast<int*>(base + kCfgBytes);
+  v.frames = reinterpret_cast<const float*>(base + kCfgBytes + kStatusBytes);
+  base += staged_bytes(p.B);
+  v.t.wins = reinterpret_cast<Win16*>(base); base += up256((size_t)p.B * strip::kMaxStrips * sizeof(Win16));
+  v.t.unions = reinterpret_cast<Win16*>(base); base += up256((size_t)p.B * sizeof(Win16));
+  v.t.flags = reinterpret_cast<int*>(base); base += up256((size_t)p.B * sizeof(int));
+  v.t.rows = reinterpret_cast<strip::RowEntry*>(base);
+  return v;
 }
 
 struct Layout {               // workspace of the strip path
   float* slabs;               // (the 8 floats in front of them: the reductions' identities)
   size_t slab_bytes;
-  Win16* g_wins;              // (B, kMaxStrips)
-  Win16* g_unions;            // (B)
-  strip::RowEntry* g_rows;    // (B, max_rows, P)
 };
 
-size_t tables_bytes(int B, int rows, int P) {
-  return 256 + up256((size_t)B * strip::kMaxStrips * sizeof(Win16)) + up256((size_t)B * sizeof(Win16)) +
-         up256((size_t)B * rows * P * sizeof(strip::RowEntry));
-}
-
-// [identities (256 B) | slabs ...] and, at the end of the region, the tables the kernels write
-// (windows, unions, row tables).
-bool carve(void* ws, size_t ws_bytes, int B, int rows, int P, Layout& l) {
+// [identities (256 B) | slabs ...]
+bool carve(void* ws, size_t ws_bytes, Layout& l) {
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return false;
-  const size_t tail = tables_bytes(B, rows, P) - 256;
   ws_bytes = ws_bytes / 256 * 256;
-  if (ws_bytes < 256 + tail) return false;
-  unsigned char* base = static_cast<unsigned char*>(ws);
-  l.slabs = reinterpret_cast<float*>(base + 256);
-  l.slab_bytes = ws_bytes - 256 - tail;
-  base += ws_bytes - tail;
-  l.g_wins = reinterpret_cast<Win16*>(base); base += up256((size_t)B * strip::kMaxStrips * sizeof(Win16));
-  l.g_unions = reinterpret_cast<Win16*>(base); base += up256((size_t)B * sizeof(Win16));
-  l.g_rows = reinterpret_cast<strip::RowEntry*>(base);
+  if (ws_bytes < 512) return false;
+  l.slabs = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + 256);
+  l.slab_bytes = ws_bytes - 256;
   return true;
 }
 
@@ -317,7 +319,6 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
   sa.dc = p.dc; sa.valid_c = p.valid_c;
   sa.oc_total = oc_total;
   sa.slab_stride = rb.slab_cells;
-  sa.table_off = rb.slab_cells + 64;
   sa.max_rows = rb.max_rows;
   sa.fill = fill;
   sa.b0 = 0;
@@ -325,8 +326,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
   sa.depth = depth; sa.value = value; sa.valid = valid;
   sa.slabs = l.slabs;
   sa.out = out; sa.mask = mask; sa.mh = p.mh; sa.mw = p.mw;
-  sa.g_wins = l.g_wins; sa.g_unions = l.g_unions; sa.g_rows = l.g_rows; sa.status = pv.status;
-  sa.cfg = pv.cfg;
+  sa.g_wins = pv.t.wins; sa.g_unions = pv.t.unions; sa.g_flags = pv.t.flags; sa.g_rows = pv.t.rows;
 #ifdef DM_STAMPS
   sa.stamps = g_stamp_buffer;
 #endif
@@ -334,7 +334,8 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
   const StripKernel kfn = pick_strip_kernel(is_max, has_valid, has_value, plan.lean);
   hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn));
   if (e != hipSuccess) return e;
-  const size_t lds_bytes = ((size_t)rb.slab_cells + 64) * 4 + kGeomBytes + (size_t)rb.max_rows * plan.P * sizeof(strip::RowEntry);
+  const size_t lds_bytes = strip_lds_bytes(rb.slab_cells, rb.max_rows, p.H);
+  if (lds_bytes > (size_t)kMaxLdsBytes) return hipErrorNotSupported;
   // channel groups: the slabs of one group fit the slab region
   const size_t per_channel = (size_t)p.B * plan.P * rb.slab_cells * 4;
   int group = (int)(slab_bytes / (per_channel ? per_channel : 1));
@@ -350,7 +351,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
     StripMergeArgs ma;
     ma.b0 = 0; ma.oc = oc; ma.ch0 = ch0; ma.oc_total = oc_total; ma.mh = p.mh; ma.mw = p.mw;
     ma.P = plan.P; ma.slab_stride = rb.slab_cells; ma.max_rows = rb.max_rows; ma.fill = fill;
-    ma.g_wins = l.g_wins; ma.g_unions = l.g_unions; ma.g_rows = l.g_rows;
+    ma.g_wins = pv.t.wins; ma.g_unions = pv.t.unions; ma.g_rows = pv.t.rows;
     ma.slabs = l.slabs; ma.out = out; ma.mask = mask;
     // grid.y = frames * channels <= 65535 per launch
     const int per_launch = 65535 / oc > 0 ? 65535 / oc : 1;
@@ -381,7 +382,7 @@ size_t strip_workspace_extra(const dm_params& p) {
     more_slabs = per_channel * (size_t)p.vc;
     if (more_slabs > ((size_t)2 << 30)) more_slabs = (size_t)2 << 30;
   }
-  return prepared_bytes(p.B) + tables_bytes(p.B, p.mh, strip::kMaxStrips) + more_slabs;
+  return prepared_bytes(p) + 512 + more_slabs;
 }
 
 namespace {
@@ -431,7 +432,7 @@ bool aligned_for_strips(const float* depth, const float* value, float* out, uint
 // [Cfg | status | frame records] of a batch as one block of host memory (thread-local staging).
 const std::vector<unsigned char>& stage_prepared(const dm_params& p, const Rig& rg, const dm_frame* frames_host) {
   thread_local std::vector<unsigned char> stage;
-  stage.resize(prepared_bytes(p.B));
+  stage.resize(staged_bytes(p.B));
   memset(stage.data(), 0, kCfgBytes + kStatusBytes);
   memcpy(stage.data(), &rg.cfg, sizeof(strip::Cfg));
   dm_frame* f = reinterpret_cast<dm_frame*>(stage.data() + kCfgBytes + kStatusBytes);
@@ -450,7 +451,7 @@ hipError_t launch_strips(const dm_params& p, const Plan& plan, const dm_frames_p
                          size_t ws_bytes, hipEvent_t after_projection, hipStream_t s) {
   const int oc_total = p.vc ? p.vc : p.dc;
   Layout l;
-  if (!carve(ws, ws_bytes, p.B, fp.max_rows, plan.P, l)) return hipErrorNotSupported;
+  if (!carve(ws, ws_bytes, l)) return hipErrorNotSupported;
   const size_t hm = (height && value) ? up256((size_t)p.B * p.dc * p.mh * p.mw) : 0;
   if (l.slab_bytes < hm + (size_t)p.B * plan.P * fp.slab_cells * 4) return hipErrorNotSupported;
   const bool is_max = p.reduction == DM_REDUCE_MAX;
@@ -471,7 +472,7 @@ hipError_t launch_strips(const dm_params& p, const Plan& plan, const dm_frames_p
     FuseArgs fa;
     fa.B = p.B; fa.b0 = 0; fa.accumulate = 0;
     fa.dc = oc_total; fa.mh = p.mh; fa.mw = p.mw; fa.fill = p.fill;
-    fa.unions = l.g_unions; fa.maps = out; fa.fused = fused; fa.fused_mask = fused_mask;
+    fa.unions = pv.t.unions; fa.maps = out; fa.fused = fused; fa.fused_mask = fused_mask;
     const dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kFuseGroups - 1) / kFuseGroups), oc_total);
     const dim3 blk(kFuseGroups * kFuseLanes);
     e = is_max ? launch(k_fuse_unions<true>, g, blk, 0, s, fa)
@@ -480,6 +481,15 @@ hipError_t launch_strips(const dm_params& p, const Plan& plan, const dm_frames_p
   }
   note_split(plan.P, 1, 1, 2);
   return hipSuccess;
+}
+
+// k_strip_prepare behind the copy of a batch's camera state: geometry and row tables of every frame.
+hipError_t launch_prepare(const dm_params& p, const dm_frames_plan& fp, const PreparedView& pv, hipStream_t s) {
+  StripPrepArgs pa;
+  pa.cfg = pv.cfg; pa.frames = pv.frames;
+  pa.slab_stride = fp.slab_cells; pa.max_rows = fp.max_rows; pa.mw = p.mw;
+  pa.t = pv.t; pa.status = pv.status;
+  return launch(k_strip_prepare, dim3(p.B), dim3(kPrepThreads), 0, s, pa);
 }
 
 dm_frames_plan plan_of(const Plan& plan, const Rig& rg) {
@@ -502,12 +512,12 @@ hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const floa
   const Rig* rg = nullptr;
   const Plan* plan = plan_and_rig(p, frames_host, &rg);
   if (!plan) return hipErrorNotSupported;
-  const size_t head = prepared_bytes(p.B);
+  const size_t head = prepared_bytes(p);
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0 || ws_bytes < head) return hipErrorNotSupported;
   const dm_frames_plan fp = plan_of(*plan, *rg);
   {   // would the rest fit?  (nothing may be enqueued before the answer is yes)
     Layout l;
-    if (!carve(static_cast<unsigned char*>(ws) + head, ws_bytes - head, p.B, fp.max_rows, plan->P, l)) return hipErrorNotSupported;
+    if (!carve(static_cast<unsigned char*>(ws) + head, ws_bytes - head, l)) return hipErrorNotSupported;
     const size_t hm = (height && value) ? up256((size_t)p.B * p.dc * p.mh * p.mw) : 0;
     if (l.slab_bytes < hm + (size_t)p.B * plan->P * fp.slab_cells * 4) return hipErrorNotSupported;
   }
@@ -520,24 +530,29 @@ hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const floa
   const std::vector<unsigned char>& stage = stage_prepared(p, *rg, frames_host);
   e = hipMemcpyAsync(ws, stage.data(), stage.size(), hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return e;
-  return launch_strips(p, *plan, fp, view_prepared(ws), depth, value, valid, out, mask, height, fused,
+  e = launch_prepare(p, fp, view_prepared(p, ws), s);
+  if (e != hipSuccess) return e;
+  return launch_strips(p, *plan, fp, view_prepared(p, ws), depth, value, valid, out, mask, height, fused,
                        fused_mask, static_cast<unsigned char*>(ws) + head, ws_bytes - head, after_projection, s);
 }
 
-size_t strip_prepared_bytes(const dm_params& p) { return cached_plan(p) ? prepared_bytes(p.B) : 0; }
+size_t strip_prepared_bytes(const dm_params& p) { return cached_plan(p) ? prepared_bytes(p) : 0; }
 
-// dm_frames_prepare_f32: validate the batch's camera state, size the launches, upload.
+// dm_frames_prepare_f32: validate the batch's camera state, size the launches, upload, and derive
+// the frames' geometry and row tables on the device (k_strip_prepare).
 hipError_t strip_prepare(const dm_params& p, const dm_frame* frames_host, void* prepared_dev,
                          size_t prepared_size, dm_frames_plan* plan_out, hipStream_t s) {
   if (g_force_legacy || p.B > 65535 || p.B < 1) return hipErrorNotSupported;
   const Rig* rg = nullptr;
   const Plan* plan = plan_and_rig(p, frames_host, &rg);
   if (!plan) return hipErrorNotSupported;
-  if (reinterpret_cast<uintptr_t>(prepared_dev) % 256 != 0 || prepared_size < prepared_bytes(p.B))
+  if (reinterpret_cast<uintptr_t>(prepared_dev) % 256 != 0 || prepared_size < prepared_bytes(p))
     return hipErrorInvalidValue;
   *plan_out = plan_of(*plan, *rg);
   const std::vector<unsigned char>& stage = stage_prepared(p, *rg, frames_host);
-  return hipMemcpyAsync(prepared_dev, stage.data(), stage.size(), hipMemcpyHostToDevice, s);
+  const hipError_t e = hipMemcpyAsync(prepared_dev, stage.data(), stage.size(), hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  return launch_prepare(p, *plan_out, view_prepared(p, prepared_dev), s);
 }
 
 // dm_orth_project_prepared_f32
@@ -554,7 +569,7 @@ hipError_t run_strip_prepared(const dm_params& p, const dm_frames_plan& fp, void
     const hipError_t e = hipEventRecord(before_projection, s);
     if (e != hipSuccess) return e;
   }
-  return launch_strips(p, *plan, fp, view_prepared(prepared_dev), depth, value, valid, out, mask, height,
+  return launch_strips(p, *plan, fp, view_prepared(p, prepared_dev), depth, value, valid, out, mask, height,
                        fused, fused_mask, ws, ws_bytes, after_projection, s);
 }
 
@@ -606,7 +621,7 @@ extern "C" __attribute__((visibility("default"))) int dm_debug_strip_geometry(
     strip::FrameGeom g;
     strip::frame_geometry(rg.cfg, f.Rp, g);
     int32_t* o = out_geom + (size_t)b * stride;
-    o[0] = g.ok; o[1] = plan.P; o[2] = plan.wp; o[3] = rg.slack;
+    o[0] = g.ok | (g.inside << 8); o[1] = plan.P; o[2] = plan.wp; o[3] = rg.slack;
     o[4] = g.U.x0; o[5] = g.U.z0; o[6] = g.U.w; o[7] = g.U.h;
     for (int s = 0; s < strip::kMaxStrips; ++s) {
       o[8 + 4 * s] = g.win[s].x0; o[9 + 4 * s] = g.win[s].z0;

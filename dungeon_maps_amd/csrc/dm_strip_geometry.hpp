@@ -66,7 +66,8 @@ struct FrameGeom {
   Win16 U;                      // bounding box of the windows, x aligned to 4
   Line L[kMaxStrips], R[kMaxStrips];
   int ok;                       // 0: the cone model does not apply to this frame
-  int pad;
+  int inside;                   // bit s: strip s's window was not clipped by the map's borders, i.e.
+                                // EVERY pixel of the strip with a depth in range lands inside it
 };
 
 // Per (map row of the union window, strip): what the strip can reach on that row and the part
@@ -138,9 +139,10 @@ __host__ __device__ inline Pose pose_of(const Cfg& c, float y0, float y2, float 
 
 // Window from the bounding box [lx, hx] x [lz, hz] of the eight corners.
 __host__ __device__ inline Win16 window_of(const Cfg& c, float lx, float hx, float lz, float hz,
-                                           float slack) {
+                                           float slack, bool& inside) {
   float x0 = floorf(floorf(lx + 0.5f) - slack), x1 = ceilf(floorf(hx + 0.5f) + slack + 1.0f);
   float z0 = floorf(floorf(lz + 0.5f) - slack), z1 = ceilf(floorf(hz + 0.5f) + slack + 1.0f);
+  inside = (x0 >= 0.0f) & (z0 >= 0.0f) & (x1 <= (float)c.mw) & (z1 <= (float)c.mh);   // (false for NaN)
   x0 = x0 < 0.0f ? 0.0f : x0;
   z0 = z0 < 0.0f ? 0.0f : z0;
   x1 = x1 > (float)c.mw ? (float)c.mw : x1;
@@ -171,7 +173,7 @@ __host__ __device__ inline Line cone_edge(const Cfg& c, const Pose& p, float t, 
 // One strip's window and cone edges for a pose: the strip's local corners rotated by the yaw.
 __host__ __device__ inline void strip_geometry(const Cfg& c, const Pose& p, const float* cxl,
                                                const float* czl, float tmin, float tmax, bool live,
-                                               Win16& w, Line& L, Line& R) {
+                                               Win16& w, Line& L, Line& R, bool& inside) {
   float lx = INFINITY, hx = -INFINITY, lz = INFINITY, hz = -INFINITY;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -180,8 +182,10 @@ __host__ __device__ inline void strip_geometry(const Cfg& c, const Pose& p, cons
     lx = fmin2(lx, xf); hx = fmax2(hx, xf); lz = fmin2(lz, zf); hz = fmax2(hz, zf);
   }
   const bool on = live & (p.ok != 0);
-  const Win16 ww = window_of(c, lx, hx, lz, hz, p.slack);
+  bool in = false;
+  const Win16 ww = window_of(c, lx, hx, lz, hz, p.slack, in);
   const Line l = cone_edge(c, p, tmin, true), r = cone_edge(c, p, tmax, false);
+  inside = on & in & (ww.w > 0);
   w = on ? ww : Win16{0, 0, 0, 0};
   L = on ? l : Line{0.0f, 0.0f, 0.0f, 0.0f};
   R = on ? r : Line{0.0f, 0.0f, 0.0f, 0.0f};
@@ -191,10 +195,12 @@ __host__ __device__ inline void strip_geometry(const Cfg& c, const Pose& p, cons
 // rec: dm_frame's floats (Ry at [10..18], tx [19], tz [20], offsets [21], [22]).
 __host__ inline void frame_geometry(const Cfg& c, const float* rec, FrameGeom& g) {
   const Pose p = pose_of(c, rec[10], rec[12], rec[16], rec[18], rec[19], rec[20], rec[21], rec[22]);
-  g.ok = p.ok; g.pad = 0;
+  g.ok = p.ok; g.inside = 0;
   int ux0 = 32767, ux1 = 0, uz0 = 32767, uz1 = 0;
   for (int s = 0; s < kMaxStrips; ++s) {
-    strip_geometry(c, p, c.cxl[s], c.czl[s], c.tmin[s], c.tmax[s], s < c.P && c.live[s], g.win[s], g.L[s], g.R[s]);
+    bool in = false;
+    strip_geometry(c, p, c.cxl[s], c.czl[s], c.tmin[s], c.tmax[s], s < c.P && c.live[s], g.win[s], g.L[s], g.R[s], in);
+    g.inside |= in ? 1 << s : 0;
     const Win16 w = g.win[s];
     if (w.w > 0) {
       if (w.x0 < ux0) ux0 = w.x0;

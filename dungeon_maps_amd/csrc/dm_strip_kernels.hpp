@@ -16,41 +16,13 @@
 namespace dm {
 namespace {
 
-constexpr int kGeomBytes = 512;           // LDS reserved for the FrameGeom in front of the cover table
-static_assert(sizeof(strip::FrameGeom) == 336 && sizeof(strip::FrameGeom) <= kGeomBytes, "FrameGeom layout (tests/test_hip_strip.py reads it) and its LDS slot");
+static_assert(sizeof(strip::FrameGeom) == 336, "FrameGeom layout (tests/test_hip_strip.py reads it)");
 
-struct StripArgs {
-  int W, H;
-  int clip, flip_h;
-  float cx, cy, fx, fy, res;
-  float fx_inv, fy_inv, res_inv;
-  float dmin, dmax, hmax;
-  float Hm1, mhm1;
-  int wp, P;
-  int dc, valid_c;
-  int oc, ch0, oc_total;      // channels of this launch's group / first channel / channels of out
-  int slab_stride;            // cells per slab = cells of the LDS window region
-  int table_off;              // float index in LDS of the FrameGeom (the cover table follows)
-  int max_rows;               // rows of a frame's cover table (>= the union window's height)
-  float fill;
-  int b0;
-  const float* frames;        // (B, 32) dm_frame records in device memory
-  const float* depth;
-  const float* value;         // (B, oc_total, H, W) or NULL: project the heights
-  const uint8_t* valid;
-  float* slabs;
-  float* out;
-  uint8_t* mask;
-  int mh, mw;
-  Win16* g_wins;              // (B, kMaxStrips)     published for k_strip_merge
-  Win16* g_unions;            // (B)                 ... and the batch fuse
-  strip::RowEntry* g_rows;    // (B, max_rows, P)   per row and strip: cover, owned
-  int* status;                // set non-zero when a frame's geometry does not fit the launch
-#ifdef DM_STAMPS
-  long long* stamps;
-#endif
-  const strip::Cfg* cfg;      // device copy (in front of the frame records): read by wave 0 only
-};
+// LDS of k_strip_scatter, in floats: [window region: slab_stride | 64 scratch cells |
+// this strip's row entries: 2 * max_rows | ray slopes of the image rows: H].
+__host__ __device__ inline size_t strip_lds_bytes(int slab_cells, int max_rows, int H) {
+  return ((size_t)slab_cells + 64 + 2 * (size_t)max_rows + (size_t)H + 4) * 4;
+}
 
 // L1 geometry of one frame by ONE wave: lane s < kMaxStrips derives strip s (the same calls as
 // strip::frame_geometry, the host's serial version), the union window is reduced over the lanes.
@@ -68,8 +40,10 @@ __device__ inline void strip_geometry_wave(const strip::Cfg& c, float y0, float 
   const Pose p = pose_of(c, y0, y2, y6, y8, tx, tz, wo, ho);
   Win16 w;
   Line L, R;
-  strip_geometry(c, p, cx, cz, tmin, tmax, live, w, L, R);
+  bool in = false;
+  strip_geometry(c, p, cx, cz, tmin, tmax, live, w, L, R, in);
   if (lane < kMaxStrips) { g->win[lane] = w; g->L[lane] = L; g->R[lane] = R; }
+  const unsigned long long in_mask = __builtin_amdgcn_ballot_w64(in & (lane < kMaxStrips));
   const bool some = (lane < kMaxStrips) & (w.w > 0);
   int ux0 = some ? w.x0 : 32767, ux1 = some ? w.x0 + w.w : 0;
   int uz0 = some ? w.z0 : 32767, uz1 = some ? w.z0 + w.h : 0;
@@ -82,12 +56,114 @@ __device__ inline void strip_geometry_wave(const strip::Cfg& c, float y0, float 
     g->U = ux1 > ux0 ? Win16{(short)ux0, (short)uz0, (short)(ux1 - ux0), (short)(uz1 - uz0)}
                      : Win16{0, 0, 0, 0};
     g->ok = p.ok;
-    g->pad = 0;
+    g->inside = (int)(in_mask & 0xffu);
   }
 }
 
+// What k_strip_prepare leaves in device memory for a batch ("frame tables"): read-only for
+// k_strip_scatter, k_strip_merge and the batch fuse.
+struct FrameTables {
+  Win16* wins;                // (B, kMaxStrips)
+  Win16* unions;              // (B)   union windows, x in whole kSpanAlign groups
+  int* flags;                 // (B)   FrameGeom::inside
+  strip::RowEntry* rows;      // (B, max_rows, P)   per row and strip: cover, owned
+};
+
+struct StripPrepArgs {
+  const strip::Cfg* cfg;      // device copy (in front of the frame records)
+  const float* frames;        // (B, 32) dm_frame records in device memory
+  int slab_stride, max_rows, mw;
+  FrameTables t;
+  int* status;                // set non-zero when a frame's geometry does not fit the launch plan
+};
+
+constexpr int kPrepThreads = 256;
+
+// One workgroup per frame: the frame's geometry (wave 0) and its row table -- cover and owned
+// span of every strip on every row of the union window (thread = (row, strip), the strips of a
+// row in neighbouring lanes, which exchange their covers by shuffles).  Runs once per set of
+// poses (dm_frames_prepare_f32) or in front of the projection kernels (dm_orth_project_f32).
+__global__ void __launch_bounds__(kPrepThreads)
+k_strip_prepare(StripPrepArgs a) {
+  __shared__ strip::FrameGeom geom;
+  const int b = blockIdx.x;
+  const float* f = a.frames + (size_t)b * 32;
+  if (threadIdx.x < 64)
+    strip_geometry_wave(*a.cfg, f[10], f[12], f[16], f[18], f[19], f[20], f[21], f[22], (int)threadIdx.x, &geom);
+  __syncthreads();
+  const int nparts = a.cfg->P;
+  Window U = widen(geom.U);
+  {   // the union window in whole span groups (covers reach that far)
+    const int ux1 = min((U.x0 + U.w + strip::kSpanAlign - 1) & ~(strip::kSpanAlign - 1), a.mw);
+    U.x0 &= ~(strip::kSpanAlign - 1);
+    U.w = U.w > 0 ? ux1 - U.x0 : 0;
+  }
+  // a frame that does not fit what the host sized the launches for: flag it and project nothing
+  // (cannot happen when the host derived the sizes from these very frames)
+  bool fits = geom.ok != 0 && U.h <= a.max_rows;
+  for (int s = 0; s < strip::kMaxStrips; ++s) fits = fits && (int)geom.win[s].w * geom.win[s].h <= a.slab_stride;
+  if (!fits) {
+    if (threadIdx.x == 0 && (U.w > 0 || !geom.ok)) atomicOr(a.status, 1);
+    U = Window{0, 0, 0, 0};
+  }
+  if (threadIdx.x < strip::kMaxStrips)
+    a.t.wins[(size_t)b * strip::kMaxStrips + threadIdx.x] = fits ? geom.win[threadIdx.x] : Win16{0, 0, 0, 0};
+  if (threadIdx.x == 0) { a.t.unions[b] = narrow16(U); a.t.flags[b] = fits ? geom.inside : 0; }
+  const int P2 = nparts <= 4 ? 4 : 8;
+  const int sub = (int)threadIdx.x & (P2 - 1);
+  const int per_pass = kPrepThreads / P2;
+  for (int r = (int)threadIdx.x / P2; r < U.h; r += per_pass) {
+    const int ps = sub < nparts ? sub : 0;
+    uint32_t cover = strip::row_cover(geom.win[ps], geom.L[ps], geom.R[ps], U.z0 + r, a.mw);
+    cover = sub < nparts ? cover : 0u;
+    int lo = (int)(cover & 0xffffu), hi = (int)(cover >> 16);
+    for (int m = 1; m < P2; ++m) strip::cut_span(lo, hi, (uint32_t)__shfl_xor((int)cover, m, 64));
+    if (sub < nparts)
+      a.t.rows[((size_t)b * a.max_rows + r) * nparts + sub] =
+          strip::RowEntry{cover, hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u};
+  }
+}
+
+struct StripArgs {
+  int W, H;
+  int clip, flip_h;
+  float cx, cy, fx, fy, res;
+  float fx_inv, fy_inv, res_inv;
+  float dmin, dmax, hmax;
+  float Hm1, mhm1;
+  int wp, P;
+  int dc, valid_c;
+  int oc, ch0, oc_total;      // channels of this launch's group / first channel / channels of out
+  int slab_stride;            // cells per slab = cells of the LDS window region
+  int max_rows;               // rows of a frame's row table (>= the union window's height)
+  float fill;
+  int b0;
+  const float* frames;        // (B, 32) dm_frame records in device memory
+  const float* depth;
+  const float* value;         // (B, oc_total, H, W) or NULL: project the heights
+  const uint8_t* valid;
+  float* slabs;
+  float* out;
+  uint8_t* mask;
+  int mh, mw;
+  const Win16* g_wins;        // frame tables (k_strip_prepare)
+  const Win16* g_unions;
+  const int* g_flags;
+  const strip::RowEntry* g_rows;
+#ifdef DM_STAMPS
+  long long* stamps;
+#endif
+};
+
 // RED: kMin / kMax.  Always the fast geometry (axis-aligned rotations, exact FMA division),
 // 16-byte depth loads.  HAS_VALUE / HAS_VALID / LEAN as in k_window_scatter.
+//
+// The pixel loop is bound by VALU issue (tools/strip_stamps.py with the DM_X_* switches: 21 us
+// of arithmetic against 15 us of memory traffic at cfg2), so everything a pixel does not need
+// is kept out of it: the geometry comes from k_strip_prepare, the ray slope of an image row from
+// a table in LDS, the fill duty is wave-level stores with scalar addressing, and a strip whose
+// window the map's borders did not clip (FrameGeom::inside) skips the window test -- every
+// pixel with a depth in range then lands inside the window by construction.
 template <int RED, bool HAS_VALID, bool HAS_VALUE, bool LEAN>
 __global__ void __launch_bounds__(kScatterThreads)
 k_strip_scatter(StripArgs a) {
@@ -143,128 +219,100 @@ k_strip_scatter(StripArgs a) {
     first_rows_loaded = true;
   }
 
-  // what the pixel loop needs of the frame record: one batch of scalar loads, pinned (the rest
-  // of the record is read by wave 0 only, for the geometry)
+  // the frame's record and tables: one batch of scalar loads, pinned
   const float* tf = a.frames + (size_t)b * 32;
   float p4 = tf[4], p5 = tf[5], p7 = tf[7], p8 = tf[8], cam_h = tf[9];
   float fy0 = tf[10], fy2 = tf[12], fy6 = tf[16], fy8 = tf[18], ftx = tf[19], ftz = tf[20];
   float wo = tf[21], ho = tf[22];
+  const int2 w_raw = *reinterpret_cast<const int2*>(a.g_wins + (size_t)b * strip::kMaxStrips + part);
+  const int2 u_raw = *reinterpret_cast<const int2*>(a.g_unions + b);
+  int flags = a.g_flags[b];
   asm volatile("" : "+s"(p4), "+s"(p5), "+s"(p7), "+s"(p8), "+s"(cam_h), "+s"(fy0), "+s"(fy2),
                     "+s"(fy6), "+s"(fy8), "+s"(ftx), "+s"(ftz), "+s"(wo), "+s"(ho));
 #ifdef DM_STAMPS
   long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   DM_STAMP(0);
-  strip::FrameGeom* geom = reinterpret_cast<strip::FrameGeom*>(lds + a.table_off);
-  strip::RowEntry* rows = reinterpret_cast<strip::RowEntry*>(lds + a.table_off + kGeomBytes / 4);
+  const int table_off = a.slab_stride + 64;
+  strip::RowEntry* rows = reinterpret_cast<strip::RowEntry*>(lds + table_off);   // this strip's entry of every row of U
+  float* aytab = lds + table_off + 2 * a.max_rows;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const float lds_init = a.fill;
-  // Wave 0 derives the frame's geometry while the others initialise the whole window region
-  // of LDS (the window's size is not known before the geometry is).
-  if (wave == 0)
-    strip_geometry_wave(*a.cfg, fy0, fy2, fy6, fy8, ftx, ftz, wo, ho, (int)threadIdx.x & 63, geom);
-  DM_STAMP(1);
+  const int lane = (int)threadIdx.x & 63;
+  // The whole window region of LDS gets the fill value, the ray-slope table its H entries
+  // (maps.py:670-678; border rows poisoned), under the first depth rows in flight.
   for (int i = threadIdx.x * 4; i < a.slab_stride + 64; i += kScatterThreads * 4)
-    *reinterpret_cast<float4*>(lds + i) = make_float4(lds_init, lds_init, lds_init, lds_init);
-  lds_barrier();
-  DM_STAMP(2);
-  Window w = widen(geom->win[part]);
-  Window U = widen(geom->U);
-  {   // the union window in whole 128-byte lines (covers reach that far)
-    const int ux1 = min((U.x0 + U.w + strip::kSpanAlign - 1) & ~(strip::kSpanAlign - 1), a.mw);
-    U.x0 &= ~(strip::kSpanAlign - 1);
-    U.w = U.w > 0 ? ux1 - U.x0 : 0;
+    *reinterpret_cast<float4*>(lds + i) = make_float4(a.fill, a.fill, a.fill, a.fill);
+  for (int r = threadIdx.x; r < a.H; r += kScatterThreads) {
+    float yr = (float)r;
+    yr = a.flip_h ? a.Hm1 - yr : yr;
+    float ay = div_markstein(yr - a.cy, a.fy, a.fy_inv);
+    if (!LEAN) ay = (r < a.clip || r >= a.H - a.clip) ? qnan : ay;
+    aytab[r] = ay;
   }
+  DM_STAMP(1);
+  Window w = {(short)(w_raw.x & 0xffff), (short)(w_raw.x >> 16), (short)(w_raw.y & 0xffff), (short)(w_raw.y >> 16)};
+  Window U = {(short)(u_raw.x & 0xffff), (short)(u_raw.x >> 16), (short)(u_raw.y & 0xffff), (short)(u_raw.y >> 16)};
   {
     // wave-uniform values: keep them in SGPRs
     w.x0 = __builtin_amdgcn_readfirstlane(w.x0); w.z0 = __builtin_amdgcn_readfirstlane(w.z0);
     w.w = __builtin_amdgcn_readfirstlane(w.w); w.h = __builtin_amdgcn_readfirstlane(w.h);
     U.x0 = __builtin_amdgcn_readfirstlane(U.x0); U.z0 = __builtin_amdgcn_readfirstlane(U.z0);
     U.w = __builtin_amdgcn_readfirstlane(U.w); U.h = __builtin_amdgcn_readfirstlane(U.h);
-  }
-  // a frame that does not fit what the host sized the launch for: flag it and project nothing
-  // (cannot happen when the host derived the sizes from these very frames)
-  if (w.w * w.h > a.slab_stride || U.h > a.max_rows || !__builtin_amdgcn_readfirstlane(geom->ok)) {
-    if (threadIdx.x == 0 && (U.w > 0 || !geom->ok)) atomicOr(a.status, 1);
-    w = Window{0, 0, 0, 0};
-    U = Window{0, 0, 0, 0};
+    flags = __builtin_amdgcn_readfirstlane(flags);
   }
   const int area = w.w * w.h;
-  // Row table of the frame (cover and owned span of every strip on every row of the union
-  // window): built right before the pixel loop, under the first depth loads in flight, by all
-  // threads -- thread = (row, strip), the strips of a row in neighbouring lanes, which
-  // exchange their covers by shuffles.  Read back only behind the barrier that ends the loop.
-  const bool publisher = part == 0 && chl == 0;
-  auto build_rows = [&]() {
-    const int P2 = nparts <= 4 ? 4 : 8;
-    const int sub = (int)threadIdx.x & (P2 - 1);
-    const int per_pass = kScatterThreads / P2;
-    for (int r = (int)threadIdx.x / P2; r < U.h; r += per_pass) {
-      const int ps = sub < nparts ? sub : 0;
-      uint32_t cover = strip::row_cover(geom->win[ps], geom->L[ps], geom->R[ps], U.z0 + r, a.mw);
-      cover = sub < nparts ? cover : 0u;
-      int lo = (int)(cover & 0xffffu), hi = (int)(cover >> 16);
-      for (int m = 1; m < P2; ++m) strip::cut_span(lo, hi, (uint32_t)__shfl_xor((int)cover, m, 64));
-      const strip::RowEntry e = {cover, hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u};
-      if (sub < nparts) {
-        rows[r * nparts + sub] = e;
-        if (publisher) a.g_rows[((size_t)b * a.max_rows + r) * nparts + sub] = e;
-      }
-    }
-  };
+  // this strip's row entries (cover, owned span) of the union window's rows -> LDS, for the flush
+  for (int r = threadIdx.x; r < U.h; r += kScatterThreads)
+    rows[r] = a.g_rows[((size_t)b * a.max_rows + r) * nparts + part];
+  lds_barrier();
+  DM_STAMP(2);
   DM_STAMP(3);
-  // Fill duty (as in k_window_scatter): map rows part, part + P, ... outside the union window
-  const int g4 = a.mw >> 2;
-  const int fill_rows = (a.mh - part + nparts - 1) / nparts;
+  // Fill duty: map rows part, part + P, ... of (b, ch) outside the union window U, which the
+  // flush below and k_strip_merge write.  Wave-level: wave v takes the rows part + (v + 16 j) P,
+  // one step stores 256 cells of a row (float4 per lane) and their mask bytes with SCALAR
+  // addressing -- the map of this (frame, channel) as a raw buffer resource, the row and chunk
+  // in the scalar offset, the lane's fixed 16 / 4 bytes in the vector offset.  A lane that has
+  // nothing to write (inside U, past the row's end, past the wave's rows) gets a vector offset
+  // past the end of the buffer and is dropped by the hardware's range check: no branch in the
+  // loop, a handful of VALU instructions per KB.
   const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
-  const bool do_fill = a.out != nullptr && fill_rows > 0;
-  const int fill_total = do_fill ? fill_rows * g4 : 0;
-  const int fill_steps = (fill_total + kScatterThreads - 1) / kScatterThreads;
-  const float g4_inv = 1.0f / (float)g4;
-  int fs = 0;
-  // Buffer stores: the map of this (frame, channel) as a raw buffer resource.  A store that has
-  // nothing to write gets an offset past the end of the buffer and is dropped by the hardware's
-  // range check: no branch, no dummy destination, scalar base + 32-bit offsets instead of 64-bit
-  // address arithmetic (-1 us).  (Write-through stores, sc0 sc1, measured the same as plain
-  // ones here, for this kernel and for the kernel boundary behind it.)
-  constexpr int kFillCachePolicy = 0;
+  const int fill_rows = (a.mh - part + nparts - 1) / nparts;
+  const int chunks = (a.mw + 255) >> 8;
+  const int fill_steps = a.out != nullptr && wave < fill_rows ? ((fill_rows - wave + 15) >> 4) * chunks : 0;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const unsigned map_cells = (unsigned)a.mh * (unsigned)a.mw;
   const __amdgpu_buffer_rsrc_t rs_out =
-      __builtin_amdgcn_make_buffer_rsrc(a.out + map_base, 0, do_fill ? map_cells * 4u : 0u, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(a.out + map_base, 0, a.out ? map_cells * 4u : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_mask =
-      __builtin_amdgcn_make_buffer_rsrc(a.mask + map_base, 0, do_fill ? map_cells : 0u, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(a.mask + map_base, 0, a.out ? map_cells : 0u, 0x00020000);
   const unsigned fill_bits = __float_as_uint(a.fill);
+  const int lane4 = lane << 2;
+  int fs = 0, f_row = part + wave * nparts, f_chunk = 0;       // (wave-uniform)
   auto fill_step = [&]() {
-    const int i = fs * kScatterThreads + (int)threadIdx.x;
+    const int x = (f_chunk << 8) + lane4;
+    const bool in_rows = (unsigned)(f_row - U.z0) < (unsigned)U.h;                  // (scalar)
+    const bool skip = (fs >= fill_steps) | (x >= a.mw) | (in_rows & ((unsigned)(x - U.x0) < (unsigned)U.w));
+    const int cell0 = f_row * a.mw + (f_chunk << 8);                                // (scalar)
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out,
+                                           skip ? 0x7ffffff0 : lane4 << 2, skip ? 0 : cell0 << 2, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, skip ? 0x7ffffff0 : lane4, skip ? 0 : cell0, 0);
     ++fs;
-    int k = (int)((float)i * g4_inv);
-    k -= (k * g4 > i);
-    k += ((k + 1) * g4 <= i);
-    const int g = i - k * g4;
-    const int r = part + k * nparts, x = g << 2;
-    const bool skip = (i >= fill_total) | (((unsigned)(r - U.z0) < (unsigned)U.h) &
-                                           ((unsigned)(x - U.x0) < (unsigned)U.w));   // (no branch)
-    const int cell = r * a.mw + x;
-    const int ob = skip ? 0x7ffffff0 : cell * 4, mb = skip ? 0x7ffffff0 : cell;
-    __builtin_amdgcn_raw_buffer_store_b128((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, ob, 0,
-                                           kFillCachePolicy);
-    __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, mb, 0, kFillCachePolicy);
+    const bool next_row = f_chunk + 1 == chunks;
+    f_chunk = next_row ? 0 : f_chunk + 1;
+    f_row += next_row ? 16 * nparts : 0;
   };
   // the reductions' identities as float4s in front of the slabs (k_strip_merge reads them where
   // a strip has nothing for a group)
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8)
     a.slabs[(int)threadIdx.x - 8] = threadIdx.x < 4 ? -INFINITY : INFINITY;
-  auto publish_geometry = [&]() {
-    if (publisher && threadIdx.x < strip::kMaxStrips)
-      a.g_wins[(size_t)b * strip::kMaxStrips + threadIdx.x] = geom->win[threadIdx.x];
-    if (publisher && threadIdx.x == 0) a.g_unions[b] = narrow16(U);
-  };
 
   // (a local map's records carry a neutral yaw and no translation: dm_strip.hip stage_frames)
   const float y0 = fy0, y2r = fy2, y6 = fy6, y8 = fy8, tx = ftx, tz = ftz;
   const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
-  const unsigned dummy = (unsigned)a.slab_stride + (threadIdx.x & 63u);   // 64 scratch cells
+  const unsigned dummy = ((unsigned)a.slab_stride + (unsigned)lane) << 2;   // 64 scratch cells (byte address)
+  char* const lds_bytes = reinterpret_cast<char*>(lds);
+  // the window's origin folded into the address arithmetic: byte address = (z * w + x) * 4 + origin
+  const int origin = -4 * (w.z0 * w.w + w.x0);
 
   if (area > 0) {
     for (int g = gx; g < nx; g += ntx) {       // one trip unless the strip is wider than the block
@@ -281,17 +329,20 @@ k_strip_scatter(StripArgs a) {
                            float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
         load_rows_at(z, sv, q, r);
       };
-      auto project_rows = [&](const float (&z)[kRowsInFlight][VEC],
+      auto project_rows = [&](auto tested, const float (&z)[kRowsInFlight][VEC],
                               const float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
+        constexpr bool kTest = decltype(tested)::value;
+#ifdef DM_X_NOMATH
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u)
+          lds_reduce<RED>(reinterpret_cast<float*>(lds_bytes + dummy), fmaxf(fmaxf(z[u][0], z[u][1]), fmaxf(z[u][2], z[u][3])));
+        return;
+#endif
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u) {
           int rr = r + u * rows_per_iter;
           rr = rr < r1 ? rr : r1 - 1;
-          float yr = (float)rr;
-          yr = a.flip_h ? a.Hm1 - yr : yr;                       // maps.py:670-671
-          const float dy = yr - a.cy;
-          float ay = div_markstein(dy, a.fy, a.fy_inv);
-          if (!LEAN) ay = (rr < a.clip || rr >= a.H - a.clip) ? qnan : ay;
+          const float ay = aytab[rr];                                      // maps.py:670-678
           unsigned li[VEC];
           float hv[VEC];
           float xfv[VEC], zfv[VEC], h1v[VEC];
@@ -321,17 +372,18 @@ k_strip_scatter(StripArgs a) {
           for (int k = 0; k < VEC; ++k) {
             const float zz = z[u][k], xf = xfv[k], zf = zfv[k], h1 = h1v[k];
             // maps.py:537-544, 286-288, 1150-1158
-            const unsigned ux = (unsigned)(floor_to_int(xf) - w.x0);
-            const unsigned uz = (unsigned)(floor_to_int(zf) - w.z0);
+            const int ix = floor_to_int(xf), iz = floor_to_int(zf);
             // (bitwise &: the short-circuit form compiles to a branch per pixel, and a branch in
             // this loop costs its counted waits)
-            bool ok = (ux < (unsigned)w.w) & (uz < (unsigned)w.h) & (zz >= a.dmin) & (zz <= a.dmax);
+            bool ok = (zz >= a.dmin) & (zz <= a.dmax);
+            if (kTest) ok = ok & ((unsigned)(ix - w.x0) < (unsigned)w.w) & ((unsigned)(iz - w.z0) < (unsigned)w.h);
             if (!LEAN) ok = ok & !__builtin_isunordered(xf, zf) & (h1 <= a.hmax);
             const float sval = HAS_VALUE ? sv[u][k] : h1;
             if (HAS_VALUE) ok = ok & (sval == sval);             // NaN never replaces a number
-            unsigned cell = __umul24(uz, (unsigned)w.w) + ux;
-            asm("" : "+v"(cell));
-            li[k] = ok ? cell : dummy;
+            // (window coordinates fit 24 bits: |cell coordinates| < 2^23, dm_strip.hip validate_frames)
+            unsigned addr = (unsigned)(((__mul24(iz, w.w) + ix) << 2) + origin);
+            asm("" : "+v"(addr));
+            li[k] = ok ? addr : dummy;
             hv[k] = sval;
           }
           if (__builtin_amdgcn_ballot_w64(li[0] == li[VEC - 1] && li[0] != dummy) != 0) {
@@ -344,87 +396,80 @@ k_strip_scatter(StripArgs a) {
             }
           }
 #pragma unroll
-          for (int k = 0; k < VEC; ++k) lds_reduce<RED>(lds + li[k], hv[k]);
+          for (int k = 0; k < VEC; ++k) lds_reduce<RED>(reinterpret_cast<float*>(lds_bytes + li[k]), hv[k]);
         }
       };
       const int niter = (r1 - r0 + step - 1) / step;
-      auto pipeline = [&](auto with_fill) {
-        constexpr bool kFill = decltype(with_fill)::value;
+      // Two copies of the pipelined loop -- with and without the window test -- chosen by ONE
+      // wave-uniform branch: inside, exactly kFillPerHalf unconditional fill steps follow each
+      // group of loads, so the waits count them and never wait on a store or on the prefetch.
+      auto pipeline = [&](auto tested) {
         int r = r0 + gy;
         if (!first_rows_loaded) load_rows(za, va, r);
         first_rows_loaded = false;
-        // (the row table is built here, under the first depth rows in flight, and NOT inside the
-        // loop: a branch in the loop body makes the compiler drain its counted waits)
-        // two groups of rows in flight while the row table is built (VALU + LDS only)
         load_rows(zb_, vb_, r + step);
-        DM_STAMP(7);
-        if (g == gx) build_rows();
-        DM_STAMP(8);
+        DM_STAMP(11);
         // younger waves of a SIMD get the higher issue priority in the loop (age arbitration
         // favours the oldest wave otherwise, and the last wave left on a SIMD runs latency
         // bound).  Only now: under static priorities the four waves of a SIMD run the code
         // above one after the other instead of hiding each other's latencies.
+#ifndef DM_X_NOPRIO
         if (wave >= 12) __builtin_amdgcn_s_setprio(3);
         else if (wave >= 8) __builtin_amdgcn_s_setprio(2);
         else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
         for (int it = 0; it < niter; it += 2) {
-          if (kFill) {
 #pragma unroll
-            for (int t = 0; t < kFillPerHalf; ++t) fill_step();
-          }
-          project_rows(za, va, r);
+          for (int t = 0; t < kFillPerHalf; ++t) fill_step();
+          project_rows(tested, za, va, r);
           if (it + 1 < niter) {
             load_rows(za, va, r + 2 * step);
-            if (kFill) {
 #pragma unroll
-              for (int t = 0; t < kFillPerHalf; ++t) fill_step();
-            }
-            project_rows(zb_, vb_, r + step);
+            for (int t = 0; t < kFillPerHalf; ++t) fill_step();
+            project_rows(tested, zb_, vb_, r + step);
             load_rows(zb_, vb_, r + 3 * step);        // (past the end: the last row again, unused)
           }
           r += 2 * step;
         }
       };
-      if (do_fill) pipeline(std::true_type{}); else pipeline(std::false_type{});
+      if ((flags >> part) & 1) pipeline(std::false_type{}); else pipeline(std::true_type{});
     }
   }
-  if (area == 0 || nx == 0) build_rows();     // (no pixel loop ran: the table is still owed to k_strip_merge)
   DM_STAMP(4);
+#ifdef DM_STAMPS
+  if (a.stamps && (threadIdx.x & 63) == 0)     // every wave: when it left the pixel loop
+    a.stamps[4096 * 12 + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + wave] = stamp[4];
+#endif
   while (fs < fill_steps) fill_step();
   __builtin_amdgcn_s_setprio(0);
   lds_barrier();
   DM_STAMP(5);
+  // Flush, 16 lanes per window row: the groups of this strip's cover go straight to the map where
+  // the strip owns them (no other strip's cover reaches them), else to the slab, which
+  // k_strip_merge combines with the other strips'.
   if (area > 0) {
-    // Flush: 16 lanes per window row.  The groups of this strip's cover go straight to the map
-    // where the strip owns them (no other strip's cover reaches them), else to the slab, which
-    // k_strip_merge combines with the other strips'.
-    const int pid = (b * a.oc + chl) * nparts + part;
-    float* slab = a.slabs + (size_t)pid * a.slab_stride;
     const int l16 = (int)threadIdx.x & 15;
+    const int unit = b * a.oc + chl;             // (frame, channel): the P workgroups that share a map
+    float* slab = a.slabs + ((size_t)unit * nparts + part) * a.slab_stride;
     for (int row = (int)threadIdx.x >> 4; row < w.h; row += kScatterThreads / 16) {
       const int z = w.z0 + row;
-      const strip::RowEntry e = rows[(z - U.z0) * nparts + part];
+      const strip::RowEntry e = rows[z - U.z0];
       const int lo = (int)(e.cover & 0xffffu), hi = (int)(e.cover >> 16);
       const int cell0 = row * w.w - w.x0;
       for (int x = lo + (l16 << 2); x < hi; x += 64) {
-        // (a span is whole 128-byte lines: outside the window nothing landed)
-        const bool inside = (unsigned)(x - w.x0) < (unsigned)w.w;
-        float4 v = make_float4(a.fill, a.fill, a.fill, a.fill);
-        if (inside) v = *reinterpret_cast<const float4*>(lds + cell0 + x);
+        const float4 v = *reinterpret_cast<const float4*>(lds + cell0 + x);
         if (strip::in_span(e.owned, x) && a.out != nullptr) {
           const size_t cell = map_base + (size_t)z * a.mw + x;
           *reinterpret_cast<float4*>(a.out + cell) = v;
-          const uint32_t mk = (uint32_t)mask_of(v.x, a.fill) | ((uint32_t)mask_of(v.y, a.fill) << 8) |
-                              ((uint32_t)mask_of(v.z, a.fill) << 16) |
-                              ((uint32_t)mask_of(v.w, a.fill) << 24);
-          *reinterpret_cast<uint32_t*>(a.mask + cell) = mk;
-        } else if (inside) {
+          *reinterpret_cast<uint32_t*>(a.mask + cell) =
+              (uint32_t)mask_of(v.x, a.fill) | ((uint32_t)mask_of(v.y, a.fill) << 8) |
+              ((uint32_t)mask_of(v.z, a.fill) << 16) | ((uint32_t)mask_of(v.w, a.fill) << 24);
+        } else {
           *reinterpret_cast<float4*>(slab + cell0 + x) = v;
         }
       }
     }
   }
-  publish_geometry();
   DM_STAMP(6);
   DM_STAMPS_OUT();
 }

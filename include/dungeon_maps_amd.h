@@ -339,7 +339,8 @@ int dm_debug_force_bands(int on);
  *                                strip path on small images.
  *   dm_debug_strip_geometry      host only (no GPU needed): the strip path's geometry for `p` and
  *                                the given frames exactly as the kernels derive it.
- *                                out_geom (B, 8 + 4*8) int32 per frame: {ok, strips P, strip
+ *                                out_geom (B, 8 + 4*8) int32 per frame: {ok | inside << 8 (bit s of
+ *                                inside: strip s's window was not clipped by the map), strips P, strip
  *                                width, slack cells, union window x0, z0, w, h, then 8 strip
  *                                windows {x0, z0, w, h}}; out_covers (B, mh, P, 2) uint32 or NULL:
  *                                per map row and strip the cells [lo, hi) the strip can reach

@@ -61,12 +61,14 @@ def test_device_geometry_equals_host_geometry(dmap, oracle):
     finally:
       lib.dm_debug_force_strips(0)
     torch.cuda.synchronize()
-    # FrameGeom (336 B): Win16 win[8] (64 B), Win16 U (8 B), Line L[8], R[8] (4 floats each), int ok, pad
+    # FrameGeom (336 B): Win16 win[8] (64 B), Win16 U (8 B), Line L[8], R[8] (4 floats each), int ok, inside
     raw = dev.cpu().numpy()[:B * 336].reshape(B, 336)
     wins = raw[:, :64].copy().view(np.int16).reshape(B, 8, 4)
     U = raw[:, 64:72].copy().view(np.int16).reshape(B, 4)
     ok = raw[:, 72 + 2 * 8 * 16:72 + 2 * 8 * 16 + 4].copy().view(np.int32).reshape(B)
-    np.testing.assert_array_equal(ok != 0, geom[:, 0] != 0)
+    inside = raw[:, 72 + 2 * 8 * 16 + 4:72 + 2 * 8 * 16 + 8].copy().view(np.int32).reshape(B)
+    np.testing.assert_array_equal(ok != 0, (geom[:, 0] & 0xff) != 0)
+    np.testing.assert_array_equal(inside, geom[:, 0] >> 8)   # (strips whose windows the map did not clip)
     np.testing.assert_array_equal(U.astype(np.int32), geom[:, 4:8])
     np.testing.assert_array_equal(wins.astype(np.int32).reshape(B, 32), geom[:, 8:40])
     compared += B

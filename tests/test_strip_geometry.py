@@ -71,7 +71,7 @@ def _case(rng, big_offsets=False):
 def test_every_valid_pixel_lands_inside_its_strips_window_and_cover(oracle, big_offsets):
   lib = _native.lib()
   rng = np.random.default_rng(777 + big_offsets)
-  checked = applied = shared_groups = owned_groups = 0
+  checked = applied = shared_groups = owned_groups = inside_strips = clipped_strips = 0
   for _ in range(120):
     B, H, W, depth, pose, cfg = _case(rng, big_offsets)
     mh, mw = cfg["map_height"], cfg["map_width"]
@@ -91,8 +91,8 @@ def test_every_valid_pixel_lands_inside_its_strips_window_and_cover(oracle, big_
     wp = int(geom[0, 2])
     assert P * wp >= W and wp % 4 == 0 and 1 <= P <= 8
     xb = dbg["x_bin"].reshape(B, H, W); zb = dbg["z_bin"].reshape(B, H, W)
-    ok = dbg["valid"].reshape(B, H, W)
-    ok = ok & (xb >= 0) & (xb < mw) & (zb >= 0) & (zb < mh)
+    pre_ok = dbg["valid"].reshape(B, H, W)          # every test but the map's bounds
+    ok = pre_ok & (xb >= 0) & (xb < mw) & (zb >= 0) & (zb < mh)
     for b in range(B):
       if not geom[b, 0]:
         continue                     # cone model not applicable to this frame: flagged, not used
@@ -130,6 +130,15 @@ def test_every_valid_pixel_lands_inside_its_strips_window_and_cover(oracle, big_
         in_cover = (xs >= lo[zs, s]) & (xs < hi[zs, s])
         assert in_cover.all(), (cfg, s, "cover", int((~in_cover).sum()))
         checked += int(sel.sum())
+        # a strip flagged "inside" (its window was not clipped by the map's borders) runs without
+        # the window test: EVERY pixel that passes the other tests must land inside the window
+        if (int(geom[b, 0]) >> (8 + s)) & 1:
+          pre = pre_ok[b, :, cols]
+          xa, za = xb[b, :, cols][pre], zb[b, :, cols][pre]
+          assert ((xa >= x0) & (xa < x0 + w) & (za >= z0) & (za < z0 + h)).all(), (cfg, s, "inside")
+          inside_strips += 1
+        elif w:
+          clipped_strips += 1
       # the launch bound holds for these frames
       assert bound[1] == 0 or ((wins[:, 2] * wins[:, 3]).max() <= bound[2] and U[3] <= bound[3]
                                and U[2] * U[3] <= bound[4])
@@ -140,6 +149,7 @@ def test_every_valid_pixel_lands_inside_its_strips_window_and_cover(oracle, big_
       assert (no <= 1).all() and (n[no == 1] == 1).all()     # owned => in exactly one cover
       owned_groups += int((no == 1).sum()); shared_groups += int(((n >= 1) & (no == 0)).sum())
   assert checked > 200_000 and applied > 60
+  assert inside_strips > 20 and clipped_strips > 20
   # most reachable groups have one owner (that is the point of the path)
   assert owned_groups > shared_groups > 0
 

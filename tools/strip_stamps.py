@@ -16,14 +16,16 @@ proj = dmap.MapProjector(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.r
                          trunc_depth_min=0.15, trunc_depth_max=5.05, to_global=True, fill_value=-np.inf)
 lib = ctypes.CDLL(_native.LIB_PATH)
 _native.lib()
-buf = torch.zeros(4096 * 12, dtype=torch.int64, device="cuda")
+buf = torch.zeros(4096 * 12 + 4096 * 16, dtype=torch.int64, device="cuda")
 lib.dm_debug_strip_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
 if os.environ.get("DM_STAMPS_LEGACY"):
   _native.lib().dm_debug_force_legacy_window(1)
 for _ in range(5):
   top, mask = proj.orth_project(depth, cam_pose=pose)
 torch.cuda.synchronize()
-raw = buf.cpu().numpy().reshape(-1, 12)
+allb = buf.cpu().numpy()
+raw = allb[:4096 * 12].reshape(-1, 12)
+waves = allb[4096 * 12:].reshape(-1, 16)[:(raw[:, 0] != 0).sum()]
 raw = raw[raw[:, 0] != 0]
 st = raw[:, :7]
 names = ["frame record + geometry (wave 0)", "lds init + barrier", "cover table", "scatter loop",
@@ -41,3 +43,8 @@ print("  total                              %8.2f %8.2f" % (np.median(tot), tot.
 print("kernel span us: %.2f   start skew: %.2f   end skew: %.2f" % (
     (st[:, -1].max() - st[:, 0].min()) * 0.01, (st[:, 0].max() - st[:, 0].min()) * 0.01,
     (st[:, -1].max() - st[:, -1].min()) * 0.01))
+
+if waves.any():
+  rel = (waves - st[:, :1]) * 0.01            # each wave's loop end, relative to its workgroup's start
+  print("loop end by wave index (mean us after WG start):", np.round(rel.mean(axis=0), 1))
+  print("  first / last wave of a WG (median): %.2f / %.2f" % (np.median(rel.min(axis=1)), np.median(rel.max(axis=1))))

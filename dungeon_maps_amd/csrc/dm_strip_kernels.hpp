@@ -291,11 +291,14 @@ k_strip_scatter(StripArgs a) {
   auto fill_step = [&]() {
     const int x = (f_chunk << 8) + lane4;
     const bool in_rows = (unsigned)(f_row - U.z0) < (unsigned)U.h;                  // (scalar)
-    const bool skip = (fs >= fill_steps) | (x >= a.mw) | (in_rows & ((unsigned)(x - U.x0) < (unsigned)U.w));
-    const int cell0 = f_row * a.mw + (f_chunk << 8);                                // (scalar)
+    const bool live = fs < fill_steps;                                              // (scalar)
+    const bool skip = !live | (x >= a.mw) | (in_rows & ((unsigned)(x - U.x0) < (unsigned)U.w));
+    // (the scalar offset must be the same in every lane, skipping or not: a lane-dependent one
+    // costs a waterfall loop per store)
+    const int cell0 = __builtin_amdgcn_readfirstlane(live ? f_row * a.mw + (f_chunk << 8) : 0);
     __builtin_amdgcn_raw_buffer_store_b128((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out,
-                                           skip ? 0x7ffffff0 : lane4 << 2, skip ? 0 : cell0 << 2, 0);
-    __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, skip ? 0x7ffffff0 : lane4, skip ? 0 : cell0, 0);
+                                           skip ? 0x7ffffff0 : lane4 << 2, cell0 << 2, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, skip ? 0x7ffffff0 : lane4, cell0, 0);
     ++fs;
     const bool next_row = f_chunk + 1 == chunks;
     f_chunk = next_row ? 0 : f_chunk + 1;
@@ -309,10 +312,14 @@ k_strip_scatter(StripArgs a) {
   // (a local map's records carry a neutral yaw and no translation: dm_strip.hip stage_frames)
   const float y0 = fy0, y2r = fy2, y6 = fy6, y8 = fy8, tx = ftx, tz = ftz;
   const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
-  const unsigned dummy = ((unsigned)a.slab_stride + (unsigned)lane) << 2;   // 64 scratch cells (byte address)
-  char* const lds_bytes = reinterpret_cast<char*>(lds);
-  // the window's origin folded into the address arithmetic: byte address = (z * w + x) * 4 + origin
-  const int origin = -4 * (w.z0 * w.w + w.x0);
+  // LDS addresses of the pixel loop as plain 32-bit byte addresses (an LDS pointer IS that), so
+  // that the window's origin and the base of `lds` fold into one scalar:
+  // address = (z * w + x) * 4 + origin
+  typedef __attribute__((address_space(3))) float lds_float;
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_float*)lds;
+  const unsigned dummy = lds_base + (((unsigned)a.slab_stride + (unsigned)lane) << 2);   // 64 scratch cells
+  const int origin = (int)lds_base - 4 * (w.z0 * w.w + w.x0);
+  auto lds_at = [](unsigned addr) { return (lds_float*)(uintptr_t)addr; };
 
   if (area > 0) {
     for (int g = gx; g < nx; g += ntx) {       // one trip unless the strip is wider than the block
@@ -335,7 +342,7 @@ k_strip_scatter(StripArgs a) {
 #ifdef DM_X_NOMATH
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u)
-          lds_reduce<RED>(reinterpret_cast<float*>(lds_bytes + dummy), fmaxf(fmaxf(z[u][0], z[u][1]), fmaxf(z[u][2], z[u][3])));
+          lds_reduce<RED>(lds_at(dummy), fmaxf(fmaxf(z[u][0], z[u][1]), fmaxf(z[u][2], z[u][3])));
         return;
 #endif
 #pragma unroll
@@ -396,7 +403,7 @@ k_strip_scatter(StripArgs a) {
             }
           }
 #pragma unroll
-          for (int k = 0; k < VEC; ++k) lds_reduce<RED>(reinterpret_cast<float*>(lds_bytes + li[k]), hv[k]);
+          for (int k = 0; k < VEC; ++k) lds_reduce<RED>(lds_at(li[k]), hv[k]);
         }
       };
       const int niter = (r1 - r0 + step - 1) / step;

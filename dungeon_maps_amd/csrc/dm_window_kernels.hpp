@@ -88,8 +88,8 @@ __host__ __device__ constexpr bool additive(int red) { return red == kSum || red
 
 // ds_max_f32 / ds_min_f32: "store if new > old" -- torch_scatter's rule; a NaN
 // operand never replaces a number.
-template <int RED>
-__device__ inline void lds_reduce(float* cell, float v) {
+template <int RED, class P>
+__device__ inline void lds_reduce(P cell, float v) {
   if (RED == kMax) __hip_atomic_fetch_max(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else if (RED == kMin) __hip_atomic_fetch_min(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else __hip_atomic_fetch_add(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -57,6 +57,7 @@ bool make_plan(const dm_params& p, Plan& plan, int strips = 0) {
   if (p.reduction != DM_REDUCE_MAX && p.reduction != DM_REDUCE_MIN) return false;
   if (p.mw % 4 != 0 || p.W % 4 != 0) return false;
   if (p.mw > 32767 || p.mh > 32767 || (int64_t)p.mh * p.mw >= (1ll << 28)) return false;   // (32-bit byte offsets)
+  if ((int64_t)p.H * p.W >= (1ll << 28)) return false;                                      // (the same for the images)
   if (!(p.fill == p.fill)) return false;
   if (!p.has_dmin || !p.has_dmax || !(p.dmin >= 0.0f) || !(p.dmax >= p.dmin) || !isfinite(p.dmax))
     return false;
@@ -218,49 +219,56 @@ StripKernel pick_strip_kernel(bool is_max, bool has_valid, bool has_value, bool 
   return table[is_max ? 1 : 0][has_valid][has_value][lean && !has_valid];
 }
 
-using MergeKernel = void (*)(StripMergeArgs);
-
-MergeKernel pick_merge_kernel(bool is_max, int P) {
-#define DM_M(M) {k_strip_merge<M, 1>, k_strip_merge<M, 2>, k_strip_merge<M, 3>, k_strip_merge<M, 4>, \
-                 k_strip_merge<M, 5>, k_strip_merge<M, 6>, k_strip_merge<M, 7>, k_strip_merge<M, 8>}
-  static const MergeKernel table[2][strip::kMaxStrips] = {DM_M(kMin), DM_M(kMax)};
-#undef DM_M
-  return table[is_max ? 1 : 0][P - 1];
-}
 
 // Device copy of a batch's camera state as the kernels read it ("prepared frames"):
-// [Cfg (kCfgBytes) | status word (256 B) | frame records | frame tables].  Lives at the head of
-// the workspace for dm_orth_project_f32 (staged by one copy per call, the tables by
-// k_strip_prepare right behind it) or in a buffer of the caller's that dm_frames_prepare_f32
-// filled once (dm_orth_project_prepared_f32: no copy and no geometry, host or device).
+// [Cfg (kCfgBytes) | status word (256 B) | frame records | frame tables].
+// Lives at the head of the workspace for dm_orth_project_f32 (staged by one copy per call, the
+// tables by k_strip_prepare right behind it) or in a buffer of the caller's that
+// dm_frames_prepare_f32 filled once (dm_orth_project_prepared_f32: no copy and no geometry,
+// host or device).
 struct PreparedView {
   const strip::Cfg* cfg;
   int* status;
   const float* frames;        // (B, 32)
-  FrameTables t;              // sized for mh rows of kMaxStrips strips; indexed with the plan's max_rows and P
+  FrameTables t;              // sized from the parameters alone; indexed with the plan's max_rows, P, list_cap
 };
 constexpr size_t kStatusBytes = 256;
+// entries of a frame's shared-group list: every float4 group of the largest union window
+inline size_t list_cap_bound(const dm_params& p) {
+  const size_t rows = p.mh < kListMaxRows ? p.mh : kListMaxRows;
+  const size_t groups = p.mw / 4 < kListMaxGroups ? p.mw / 4 : kListMaxGroups;
+  return rows * groups;
+}
 inline size_t tables_bytes(const dm_params& p) {
   return up256((size_t)p.B * strip::kMaxStrips * sizeof(Win16)) + up256((size_t)p.B * sizeof(Win16)) +
-         up256((size_t)p.B * sizeof(int)) +
-         up256((size_t)p.B * p.mh * strip::kMaxStrips * sizeof(strip::RowEntry));
+         2 * up256((size_t)p.B * sizeof(int)) +
+         up256((size_t)p.B * p.mh * strip::kMaxStrips * sizeof(strip::RowEntry)) +
+         up256((size_t)p.B * p.mh * sizeof(uint2)) + up256((size_t)p.B * list_cap_bound(p) * sizeof(uint32_t));
 }
-inline size_t staged_bytes(int B) {       // what the host copies: Cfg, status, frame records
-  return kCfgBytes + kStatusBytes + up256((size_t)B * sizeof(dm_frame));
+inline size_t staged_bytes(const dm_params& p) {      // what the host copies: Cfg, status, frame records
+  return kCfgBytes + kStatusBytes + up256((size_t)p.B * sizeof(dm_frame));
 }
-inline size_t prepared_bytes(const dm_params& p) { return staged_bytes(p.B) + tables_bytes(p); }
+inline size_t prepared_bytes(const dm_params& p) { return staged_bytes(p) + tables_bytes(p); }
 inline PreparedView view_prepared(const dm_params& p, void* dev) {
   unsigned char* base = static_cast<unsigned char*>(dev);
   PreparedView v;
   v.cfg = reinterpret_cast<const strip::Cfg*>(base);
   v.status = reinterpret_cast<int*>(base + kCfgBytes);
   v.frames = reinterpret_cast<const float*>(base + kCfgBytes + kStatusBytes);
-  base += staged_bytes(p.B);
+  base += staged_bytes(p);
   v.t.wins = reinterpret_cast<Win16*>(base); base += up256((size_t)p.B * strip::kMaxStrips * sizeof(Win16));
   v.t.unions = reinterpret_cast<Win16*>(base); base += up256((size_t)p.B * sizeof(Win16));
   v.t.flags = reinterpret_cast<int*>(base); base += up256((size_t)p.B * sizeof(int));
-  v.t.rows = reinterpret_cast<strip::RowEntry*>(base);
+  v.t.counts = reinterpret_cast<int*>(base); base += up256((size_t)p.B * sizeof(int));
+  v.t.rows = reinterpret_cast<strip::RowEntry*>(base); base += up256((size_t)p.B * p.mh * strip::kMaxStrips * sizeof(strip::RowEntry));
+  v.t.reach = reinterpret_cast<uint2*>(base); base += up256((size_t)p.B * p.mh * sizeof(uint2));
+  v.t.list = reinterpret_cast<uint32_t*>(base);
   return v;
+}
+// entries per frame of the shared-group lists of a plan
+inline int list_cap_of(const dm_params& p, const dm_frames_plan& fp) {
+  const size_t cap = (size_t)fp.max_union_cells / 4 + 1;
+  return (int)(cap < list_cap_bound(p) ? cap : list_cap_bound(p));
 }
 
 struct Layout {               // workspace of the strip path
@@ -327,6 +335,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
   sa.slabs = l.slabs;
   sa.out = out; sa.mask = mask; sa.mh = p.mh; sa.mw = p.mw;
   sa.g_wins = pv.t.wins; sa.g_unions = pv.t.unions; sa.g_flags = pv.t.flags; sa.g_rows = pv.t.rows;
+  sa.g_reach = pv.t.reach;
 #ifdef DM_STAMPS
   sa.stamps = g_stamp_buffer;
 #endif
@@ -342,24 +351,24 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
   if (group < 1) return hipErrorNotSupported;
   if (group > oc_total) group = oc_total;
   if (group > 65535) group = 65535;
-  const int merge_blocks = (rb.max_rows + kMergeRowsPerBlock - 1) / kMergeRowsPerBlock;
   for (int ch0 = 0; ch0 < oc_total; ch0 += group) {
     const int oc = oc_total - ch0 < group ? oc_total - ch0 : group;
     sa.oc = oc; sa.ch0 = ch0;
     e = launch(kfn, dim3(plan.P, oc, p.B), dim3(kScatterThreads), lds_bytes, s, sa);
     if (e != hipSuccess) return e;
-    StripMergeArgs ma;
-    ma.b0 = 0; ma.oc = oc; ma.ch0 = ch0; ma.oc_total = oc_total; ma.mh = p.mh; ma.mw = p.mw;
-    ma.P = plan.P; ma.slab_stride = rb.slab_cells; ma.max_rows = rb.max_rows; ma.fill = fill;
-    ma.g_wins = pv.t.wins; ma.g_unions = pv.t.unions; ma.g_rows = pv.t.rows;
-    ma.slabs = l.slabs; ma.out = out; ma.mask = mask;
+    StripCombineArgs ca;
+    ca.b0 = 0; ca.oc = oc; ca.ch0 = ch0; ca.oc_total = oc_total; ca.mh = p.mh; ca.mw = p.mw;
+    ca.P = plan.P; ca.slab_stride = rb.slab_cells; ca.list_cap = list_cap_of(p, rb); ca.fill = fill;
+    ca.g_wins = pv.t.wins; ca.g_unions = pv.t.unions; ca.g_counts = pv.t.counts; ca.g_list = pv.t.list;
+    ca.slabs = l.slabs; ca.out = out; ca.mask = mask;
     // grid.y = frames * channels <= 65535 per launch
     const int per_launch = 65535 / oc > 0 ? 65535 / oc : 1;
     for (int b0 = 0; b0 < p.B; b0 += per_launch) {
       const int nb = p.B - b0 < per_launch ? p.B - b0 : per_launch;
-      ma.b0 = b0;
-      const dim3 g((unsigned)merge_blocks, (unsigned)(nb * oc));
-      e = launch(pick_merge_kernel(is_max, plan.P), g, dim3(kMergeThreads), 0, s, ma);
+      ca.b0 = b0;
+      const dim3 g(kCombineBlocks, (unsigned)(nb * oc));
+      e = is_max ? launch(k_strip_combine<kMax>, g, dim3(kCombineThreads), 0, s, ca)
+                 : launch(k_strip_combine<kMin>, g, dim3(kCombineThreads), 0, s, ca);
       if (e != hipSuccess) return e;
     }
   }
@@ -421,9 +430,9 @@ const Plan* plan_and_rig(const dm_params& p, const dm_frame* frames_host, const 
   return rg->fits ? plan : nullptr;
 }
 
-bool aligned_for_strips(const float* depth, const float* value, float* out, uint8_t* mask, float* height,
-                        float* fused, uint8_t* fused_mask) {
-  return reinterpret_cast<uintptr_t>(out) % 16 == 0 && reinterpret_cast<uintptr_t>(mask) % 4 == 0 &&
+bool aligned_for_strips(const float* depth, const float* value, const uint8_t* valid, float* out, uint8_t* mask,
+                        float* height, float* fused, uint8_t* fused_mask) {
+  return reinterpret_cast<uintptr_t>(valid) % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && reinterpret_cast<uintptr_t>(mask) % 4 == 0 &&
          reinterpret_cast<uintptr_t>(fused) % 16 == 0 && reinterpret_cast<uintptr_t>(fused_mask) % 4 == 0 &&
          reinterpret_cast<uintptr_t>(height) % 16 == 0 && reinterpret_cast<uintptr_t>(depth) % 16 == 0 &&
          reinterpret_cast<uintptr_t>(value) % 16 == 0;
@@ -432,7 +441,7 @@ bool aligned_for_strips(const float* depth, const float* value, float* out, uint
 // [Cfg | status | frame records] of a batch as one block of host memory (thread-local staging).
 const std::vector<unsigned char>& stage_prepared(const dm_params& p, const Rig& rg, const dm_frame* frames_host) {
   thread_local std::vector<unsigned char> stage;
-  stage.resize(staged_bytes(p.B));
+  stage.resize(staged_bytes(p));
   memset(stage.data(), 0, kCfgBytes + kStatusBytes);
   memcpy(stage.data(), &rg.cfg, sizeof(strip::Cfg));
   dm_frame* f = reinterpret_cast<dm_frame*>(stage.data() + kCfgBytes + kStatusBytes);
@@ -487,7 +496,7 @@ hipError_t launch_strips(const dm_params& p, const Plan& plan, const dm_frames_p
 hipError_t launch_prepare(const dm_params& p, const dm_frames_plan& fp, const PreparedView& pv, hipStream_t s) {
   StripPrepArgs pa;
   pa.cfg = pv.cfg; pa.frames = pv.frames;
-  pa.slab_stride = fp.slab_cells; pa.max_rows = fp.max_rows; pa.mw = p.mw;
+  pa.slab_stride = fp.slab_cells; pa.max_rows = fp.max_rows; pa.mw = p.mw; pa.list_cap = list_cap_of(p, fp);
   pa.t = pv.t; pa.status = pv.status;
   return launch(k_strip_prepare, dim3(p.B), dim3(kPrepThreads), 0, s, pa);
 }
@@ -508,7 +517,7 @@ hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const floa
                      float* height, float* fused, uint8_t* fused_mask, void* ws, size_t ws_bytes,
                      hipEvent_t before_projection, hipEvent_t after_projection, hipStream_t s) {
   if (g_force_legacy || p.B > 65535) return hipErrorNotSupported;
-  if (!aligned_for_strips(depth, value, out, mask, height, fused, fused_mask)) return hipErrorNotSupported;
+  if (!aligned_for_strips(depth, value, valid, out, mask, height, fused, fused_mask)) return hipErrorNotSupported;
   const Rig* rg = nullptr;
   const Plan* plan = plan_and_rig(p, frames_host, &rg);
   if (!plan) return hipErrorNotSupported;
@@ -561,7 +570,7 @@ hipError_t run_strip_prepared(const dm_params& p, const dm_frames_plan& fp, void
                               uint8_t* mask, float* height, float* fused, uint8_t* fused_mask, void* ws,
                               size_t ws_bytes, hipEvent_t before_projection, hipEvent_t after_projection,
                               hipStream_t s) {
-  if (!aligned_for_strips(depth, value, out, mask, height, fused, fused_mask)) return hipErrorNotSupported;
+  if (!aligned_for_strips(depth, value, valid, out, mask, height, fused, fused_mask)) return hipErrorNotSupported;
   const Plan* plan = cached_plan(p);
   if (plan && plan->P != fp.strips) plan = cached_plan(p, fp.strips);
   if (!plan || plan->P != fp.strips || plan->wp != fp.strip_width) return hipErrorNotSupported;

@@ -1,13 +1,15 @@
-// Device side of the strip path: k_strip_scatter and k_strip_merge (dm_strip.hip launches
-// them).  Same pixel arithmetic and LDS-window scatter as k_window_scatter
+// Device side of the strip path (dm_strip.hip launches it): k_strip_prepare, k_strip_scatter,
+// k_strip_combine.  Same pixel arithmetic and LDS-window scatter as k_window_scatter
 // (dm_window_kernels.hpp), but
 //   * the geometry (windows, cone edges, per-row covers: dm_strip_geometry.hpp) is derived ON
-//     THE DEVICE from the frame records -- nothing of a call is computed on the host, so the
-//     launch sequence depends only on pointers and call-wide constants (graph capturable), and
+//     THE DEVICE from the frame records, by k_strip_prepare -- nothing of a call is computed
+//     on the host, so the launch sequence depends only on pointers and call-wide constants
+//     (graph capturable), and with prepared frames it is derived once per set of poses;
 //   * every float4 group of a strip's window that no other strip can reach is written
 //     straight from LDS to the map; only groups two or more strips can reach go through a
-//     slab, and k_strip_merge visits only those and the never-reached groups of the union
-//     window.
+//     slab, and k_strip_combine visits exactly those (a list k_strip_prepare leaves behind);
+//   * the rest of the map -- everything outside the hull of the covers on each row -- gets
+//     the fill value from the scatter kernel's fill duty.
 #pragma once
 
 #include "dm_strip_geometry.hpp"
@@ -19,9 +21,10 @@ namespace {
 static_assert(sizeof(strip::FrameGeom) == 336, "FrameGeom layout (tests/test_hip_strip.py reads it)");
 
 // LDS of k_strip_scatter, in floats: [window region: slab_stride | 64 scratch cells |
-// this strip's row entries: 2 * max_rows | ray slopes of the image rows: H].
+// this strip's row entries: 2 * max_rows | the rows' reach spans: 2 * max_rows | ray slopes of
+// the image rows: H].
 __host__ __device__ inline size_t strip_lds_bytes(int slab_cells, int max_rows, int H) {
-  return ((size_t)slab_cells + 64 + 2 * (size_t)max_rows + (size_t)H + 4) * 4;
+  return ((size_t)slab_cells + 64 + 4 * (size_t)max_rows + (size_t)H + 4) * 4;
 }
 
 // L1 geometry of one frame by ONE wave: lane s < kMaxStrips derives strip s (the same calls as
@@ -61,18 +64,28 @@ __device__ inline void strip_geometry_wave(const strip::Cfg& c, float y0, float 
 }
 
 // What k_strip_prepare leaves in device memory for a batch ("frame tables"): read-only for
-// k_strip_scatter, k_strip_merge and the batch fuse.
+// k_strip_scatter, k_strip_combine and the batch fuse.
 struct FrameTables {
   Win16* wins;                // (B, kMaxStrips)
   Win16* unions;              // (B)   union windows, x in whole kSpanAlign groups
   int* flags;                 // (B)   FrameGeom::inside
+  int* counts;                // (B)   entries of the frame's shared-group list
   strip::RowEntry* rows;      // (B, max_rows, P)   per row and strip: cover, owned
+  uint2* reach;               // (B, max_rows)      per row: {lo, width} of the hull of the covers
+  uint32_t* list;             // (B, list_cap)      the groups of the reach spans nobody owns
 };
+
+// An entry of a frame's shared-group list: row of the union window (12 bits), float4 group of the
+// union window's row (12 bits), bit s of the top byte: strip s's cover holds the group.
+__host__ __device__ inline uint32_t pack_shared(int row, int group, uint32_t hits) {
+  return (uint32_t)row | ((uint32_t)group << 12) | (hits << 24);
+}
+constexpr int kListMaxRows = 4096, kListMaxGroups = 4096;
 
 struct StripPrepArgs {
   const strip::Cfg* cfg;      // device copy (in front of the frame records)
   const float* frames;        // (B, 32) dm_frame records in device memory
-  int slab_stride, max_rows, mw;
+  int slab_stride, max_rows, mw, list_cap;
   FrameTables t;
   int* status;                // set non-zero when a frame's geometry does not fit the launch plan
 };
@@ -81,13 +94,18 @@ constexpr int kPrepThreads = 256;
 
 // One workgroup per frame: the frame's geometry (wave 0) and its row table -- cover and owned
 // span of every strip on every row of the union window (thread = (row, strip), the strips of a
-// row in neighbouring lanes, which exchange their covers by shuffles).  Runs once per set of
-// poses (dm_frames_prepare_f32) or in front of the projection kernels (dm_orth_project_f32).
+// row in neighbouring lanes, which exchange their covers by shuffles), the hull of the covers
+// per row ("reach": outside it the map holds the fill value) and the list of the float4 groups
+// inside the hulls that no strip owns (several strips reach them, or none: what is left to
+// combine after the strips have written their own groups).  Runs once per set of poses
+// (dm_frames_prepare_f32) or in front of the projection kernels (dm_orth_project_f32).
 __global__ void __launch_bounds__(kPrepThreads)
 k_strip_prepare(StripPrepArgs a) {
   __shared__ strip::FrameGeom geom;
+  __shared__ int listed;
   const int b = blockIdx.x;
   const float* f = a.frames + (size_t)b * 32;
+  if (threadIdx.x == 0) listed = 0;
   if (threadIdx.x < 64)
     strip_geometry_wave(*a.cfg, f[10], f[12], f[16], f[18], f[19], f[20], f[21], f[22], (int)threadIdx.x, &geom);
   __syncthreads();
@@ -100,7 +118,7 @@ k_strip_prepare(StripPrepArgs a) {
   }
   // a frame that does not fit what the host sized the launches for: flag it and project nothing
   // (cannot happen when the host derived the sizes from these very frames)
-  bool fits = geom.ok != 0 && U.h <= a.max_rows;
+  bool fits = geom.ok != 0 && U.h <= a.max_rows && U.h <= kListMaxRows && U.w <= 4 * kListMaxGroups;
   for (int s = 0; s < strip::kMaxStrips; ++s) fits = fits && (int)geom.win[s].w * geom.win[s].h <= a.slab_stride;
   if (!fits) {
     if (threadIdx.x == 0 && (U.w > 0 || !geom.ok)) atomicOr(a.status, 1);
@@ -117,10 +135,41 @@ k_strip_prepare(StripPrepArgs a) {
     uint32_t cover = strip::row_cover(geom.win[ps], geom.L[ps], geom.R[ps], U.z0 + r, a.mw);
     cover = sub < nparts ? cover : 0u;
     int lo = (int)(cover & 0xffffu), hi = (int)(cover >> 16);
-    for (int m = 1; m < P2; ++m) strip::cut_span(lo, hi, (uint32_t)__shfl_xor((int)cover, m, 64));
-    if (sub < nparts)
-      a.t.rows[((size_t)b * a.max_rows + r) * nparts + sub] =
-          strip::RowEntry{cover, hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u};
+    int rlo = cover ? (int)(cover & 0xffffu) : 32767, rhi = (int)(cover >> 16);
+    for (int m = 1; m < P2; ++m) {
+      const uint32_t other = (uint32_t)__shfl_xor((int)cover, m, 64);
+      strip::cut_span(lo, hi, other);
+      rlo = min(rlo, other ? (int)(other & 0xffffu) : 32767); rhi = max(rhi, (int)(other >> 16));
+    }
+    const uint32_t owned = hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
+    if (sub < nparts) a.t.rows[((size_t)b * a.max_rows + r) * nparts + sub] = strip::RowEntry{cover, owned};
+    if (sub == 0) a.t.reach[(size_t)b * a.max_rows + r] = rhi > rlo ? make_uint2((unsigned)rlo, (unsigned)(rhi - rlo)) : make_uint2(0u, 0u);
+    // the groups of [rlo, rhi) nobody owns: the P2 lanes of the row take every P2-th group
+    uint32_t cov[8], own[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      cov[q] = (uint32_t)__shfl((int)cover, ((int)threadIdx.x & 63 & ~(P2 - 1)) + (q & (P2 - 1)), 64);
+      own[q] = (uint32_t)__shfl((int)owned, ((int)threadIdx.x & 63 & ~(P2 - 1)) + (q & (P2 - 1)), 64);
+      if (q >= P2) { cov[q] = 0u; own[q] = 0u; }
+    }
+    for (int x = rlo + 4 * sub; x < rhi; x += 4 * P2) {
+      uint32_t hits = 0;
+      bool mine = false;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        hits |= strip::in_span(cov[q], x) ? 1u << q : 0u;
+        mine = mine | strip::in_span(own[q], x);
+      }
+      if (!mine) {
+        const int at = atomicAdd(&listed, 1);
+        if (at < a.list_cap) a.t.list[(size_t)b * a.list_cap + at] = pack_shared(r, (x - U.x0) >> 2, hits);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.t.counts[b] = listed < a.list_cap ? listed : a.list_cap;
+    if (listed > a.list_cap) atomicOr(a.status, 2);       // (cannot happen: the list holds every group of U)
   }
 }
 
@@ -150,6 +199,7 @@ struct StripArgs {
   const Win16* g_unions;
   const int* g_flags;
   const strip::RowEntry* g_rows;
+  const uint2* g_reach;
 #ifdef DM_STAMPS
   long long* stamps;
 #endif
@@ -187,28 +237,38 @@ k_strip_scatter(StripArgs a) {
   const int rows_per_iter = kScatterThreads / ntx;
   const int gx = threadIdx.x % ntx, gy = threadIdx.x / ntx;
   const size_t N = (size_t)a.H * a.W;
-  const float* dimg = a.depth + ((size_t)b * a.dc + dch) * N;
-  const uint8_t* vimg = HAS_VALID
-      ? a.valid + ((size_t)b * a.valid_c + (a.valid_c == 1 ? 0 : dch)) * N : nullptr;
-  const float* simg = HAS_VALUE ? a.value + ((size_t)b * a.oc_total + ch) * N : nullptr;
+  // the images of this (frame, channel) as raw buffer resources: a scalar base and 32-bit offsets
+  // instead of 64-bit address arithmetic per row (H * W < 2^28: dm_strip.hip make_plan)
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rs_depth = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.depth) + ((size_t)b * a.dc + dch) * N, 0, (unsigned)N * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_valid = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(HAS_VALID ? a.valid + ((size_t)b * a.valid_c + (a.valid_c == 1 ? 0 : dch)) * N : a.valid),
+      0, HAS_VALID ? (unsigned)N : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_value = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(HAS_VALUE ? a.value + ((size_t)b * a.oc_total + ch) * N : a.value), 0,
+      HAS_VALUE ? (unsigned)N * 4u : 0u, 0x00020000);
   const float qnan = __builtin_nanf("");
   float za[kRowsInFlight][VEC], zb_[kRowsInFlight][VEC];
   float va[HAS_VALUE ? kRowsInFlight : 1][VEC], vb_[HAS_VALUE ? kRowsInFlight : 1][VEC];
+  float aya[kRowsInFlight], ayb[kRowsInFlight];     // the rows' ray slopes (from the LDS table)
   auto load_rows_at = [&](float (&z)[kRowsInFlight][VEC],
                           float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int q, int r) {
 #pragma unroll
     for (int u = 0; u < kRowsInFlight; ++u) {
       int rr = r + u * rows_per_iter;
       rr = rr < r1 ? rr : r1 - 1;              // tail rows repeat the last row (max / min: idempotent)
-      const float4 t = *reinterpret_cast<const float4*>(dimg + (size_t)rr * a.W + q);
+      const int at = rr * a.W + q;             // (pixel index inside the image)
+      const f32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_depth, at << 2, 0, 0);
       z[u][0] = t.x; z[u][1] = t.y; z[u][2] = t.z; z[u][3] = t.w;
-      if (HAS_VALID) {
+      if (HAS_VALID) {                         // (four bools at once: q is a multiple of 4)
+        const unsigned ok4 = __builtin_amdgcn_raw_buffer_load_b32(rs_valid, at, 0, 0);
 #pragma unroll
         for (int k = 0; k < VEC; ++k)
-          z[u][k] = vimg[(size_t)rr * a.W + q + k] ? z[u][k] : qnan;
+          z[u][k] = ((ok4 >> (8 * k)) & 0xffu) ? z[u][k] : qnan;
       }
       if (HAS_VALUE) {
-        const float4 s = *reinterpret_cast<const float4*>(simg + (size_t)rr * a.W + q);
+        const f32x4 s = __builtin_amdgcn_raw_buffer_load_b128(rs_value, at << 2, 0, 0);
         sv[u][0] = s.x; sv[u][1] = s.y; sv[u][2] = s.z; sv[u][3] = s.w;
       }
     }
@@ -224,6 +284,15 @@ k_strip_scatter(StripArgs a) {
   float p4 = tf[4], p5 = tf[5], p7 = tf[7], p8 = tf[8], cam_h = tf[9];
   float fy0 = tf[10], fy2 = tf[12], fy6 = tf[16], fy8 = tf[18], ftx = tf[19], ftz = tf[20];
   float wo = tf[21], ho = tf[22];
+  // this strip's row entries (cover, owned span) and the rows' reach spans: requested right behind
+  // the first depth rows, for as many rows as the table holds (the union window's height is not
+  // known yet, and waiting for it would put two round trips in a row into the kernel's head)
+  strip::RowEntry row_e = {0u, 0u};
+  uint2 reach_e = make_uint2(0u, 0u);
+  if ((int)threadIdx.x < a.max_rows) {
+    row_e = a.g_rows[((size_t)b * a.max_rows + threadIdx.x) * nparts + part];
+    reach_e = a.g_reach[(size_t)b * a.max_rows + threadIdx.x];
+  }
   const int2 w_raw = *reinterpret_cast<const int2*>(a.g_wins + (size_t)b * strip::kMaxStrips + part);
   const int2 u_raw = *reinterpret_cast<const int2*>(a.g_unions + b);
   int flags = a.g_flags[b];
@@ -235,7 +304,8 @@ k_strip_scatter(StripArgs a) {
   DM_STAMP(0);
   const int table_off = a.slab_stride + 64;
   strip::RowEntry* rows = reinterpret_cast<strip::RowEntry*>(lds + table_off);   // this strip's entry of every row of U
-  float* aytab = lds + table_off + 2 * a.max_rows;
+  uint2* reach = reinterpret_cast<uint2*>(lds + table_off + 2 * a.max_rows);     // {lo, width} of every row of U
+  float* aytab = lds + table_off + 4 * a.max_rows;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = (int)threadIdx.x & 63;
   // The whole window region of LDS gets the fill value, the ray-slope table its H entries
@@ -261,18 +331,21 @@ k_strip_scatter(StripArgs a) {
     flags = __builtin_amdgcn_readfirstlane(flags);
   }
   const int area = w.w * w.h;
-  // this strip's row entries (cover, owned span) of the union window's rows -> LDS, for the flush
-  for (int r = threadIdx.x; r < U.h; r += kScatterThreads)
+  // the row tables -> LDS (rows past the union window's height hold whatever the table does: never used)
+  if ((int)threadIdx.x < a.max_rows) { rows[threadIdx.x] = row_e; reach[threadIdx.x] = reach_e; }
+  for (int r = threadIdx.x + kScatterThreads; r < U.h; r += kScatterThreads) {
     rows[r] = a.g_rows[((size_t)b * a.max_rows + r) * nparts + part];
+    reach[r] = a.g_reach[(size_t)b * a.max_rows + r];
+  }
   lds_barrier();
   DM_STAMP(2);
   DM_STAMP(3);
-  // Fill duty: map rows part, part + P, ... of (b, ch) outside the union window U, which the
-  // flush below and k_strip_merge write.  Wave-level: wave v takes the rows part + (v + 16 j) P,
+  // Fill duty: map rows part, part + P, ... of (b, ch) outside the rows' reach spans (the hull of
+  // the strips' covers: inside it the flush below and the combine step write).  Wave-level: wave v takes the rows part + (v + 16 j) P,
   // one step stores 256 cells of a row (float4 per lane) and their mask bytes with SCALAR
   // addressing -- the map of this (frame, channel) as a raw buffer resource, the row and chunk
   // in the scalar offset, the lane's fixed 16 / 4 bytes in the vector offset.  A lane that has
-  // nothing to write (inside U, past the row's end, past the wave's rows) gets a vector offset
+  // nothing to write (inside the reach, past the row's end, past the wave's rows) gets a vector offset
   // past the end of the buffer and is dropped by the hardware's range check: no branch in the
   // loop, a handful of VALU instructions per KB.
   const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
@@ -288,11 +361,29 @@ k_strip_scatter(StripArgs a) {
   const unsigned fill_bits = __float_as_uint(a.fill);
   const int lane4 = lane << 2;
   int fs = 0, f_row = part + wave * nparts, f_chunk = 0;       // (wave-uniform)
+  // the reach of a map row ({0, 0} outside U's rows), read from LDS TWO steps ahead: the steps
+  // come in pairs, and a value read one step ahead would make the second step of a pair wait
+  // for every LDS operation in flight (one counter), the pixel loop's atomics among them
+  auto reach_of = [&](int row) {
+    const int i = row - U.z0;
+    const bool in_rows = (unsigned)i < (unsigned)U.h;                               // (scalar)
+    const uint2 rr = reach[in_rows ? i : 0];
+    return make_uint2(rr.x, in_rows ? rr.y : 0u);
+  };
+  auto advance = [&](int& row, int& chunk) {
+    const bool next_row = chunk + 1 == chunks;
+    chunk = next_row ? 0 : chunk + 1;
+    row += next_row ? 16 * nparts : 0;
+  };
+  int f_row2 = f_row, f_chunk2 = f_chunk;      // where the fill duty is two steps from now
+  uint2 f_reach = reach_of(f_row2);
+  advance(f_row2, f_chunk2);
+  uint2 f_reach1 = reach_of(f_row2);
+  advance(f_row2, f_chunk2);
   auto fill_step = [&]() {
     const int x = (f_chunk << 8) + lane4;
-    const bool in_rows = (unsigned)(f_row - U.z0) < (unsigned)U.h;                  // (scalar)
     const bool live = fs < fill_steps;                                              // (scalar)
-    const bool skip = !live | (x >= a.mw) | (in_rows & ((unsigned)(x - U.x0) < (unsigned)U.w));
+    const bool skip = !live | (x >= a.mw) | ((unsigned)(x - (int)f_reach.x) < f_reach.y);
     // (the scalar offset must be the same in every lane, skipping or not: a lane-dependent one
     // costs a waterfall loop per store)
     const int cell0 = __builtin_amdgcn_readfirstlane(live ? f_row * a.mw + (f_chunk << 8) : 0);
@@ -300,15 +391,11 @@ k_strip_scatter(StripArgs a) {
                                            skip ? 0x7ffffff0 : lane4 << 2, cell0 << 2, 0);
     __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, skip ? 0x7ffffff0 : lane4, cell0, 0);
     ++fs;
-    const bool next_row = f_chunk + 1 == chunks;
-    f_chunk = next_row ? 0 : f_chunk + 1;
-    f_row += next_row ? 16 * nparts : 0;
+    advance(f_row, f_chunk);
+    f_reach = f_reach1;
+    f_reach1 = reach_of(f_row2);
+    advance(f_row2, f_chunk2);
   };
-  // the reductions' identities as float4s in front of the slabs (k_strip_merge reads them where
-  // a strip has nothing for a group)
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8)
-    a.slabs[(int)threadIdx.x - 8] = threadIdx.x < 4 ? -INFINITY : INFINITY;
-
   // (a local map's records carry a neutral yaw and no translation: dm_strip.hip stage_frames)
   const float y0 = fy0, y2r = fy2, y6 = fy6, y8 = fy8, tx = ftx, tz = ftz;
   const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
@@ -336,8 +423,20 @@ k_strip_scatter(StripArgs a) {
                            float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
         load_rows_at(z, sv, q, r);
       };
+      // (the ray slopes are read from LDS together with the depth loads, a whole pipeline stage
+      // ahead: read where they are used they would make every row wait for the LDS atomics of
+      // the row before -- one counter)
+      auto load_ay = [&](float (&ay)[kRowsInFlight], int r) {
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u) {
+          int rr = r + u * rows_per_iter;
+          rr = rr < r1 ? rr : r1 - 1;
+          ay[u] = aytab[rr];                                                 // maps.py:670-678
+        }
+      };
       auto project_rows = [&](auto tested, const float (&z)[kRowsInFlight][VEC],
-                              const float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
+                              const float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC],
+                              const float (&ayr)[kRowsInFlight]) {
         constexpr bool kTest = decltype(tested)::value;
 #ifdef DM_X_NOMATH
 #pragma unroll
@@ -347,9 +446,7 @@ k_strip_scatter(StripArgs a) {
 #endif
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u) {
-          int rr = r + u * rows_per_iter;
-          rr = rr < r1 ? rr : r1 - 1;
-          const float ay = aytab[rr];                                      // maps.py:670-678
+          const float ay = ayr[u];
           unsigned li[VEC];
           float hv[VEC];
           float xfv[VEC], zfv[VEC], h1v[VEC];
@@ -414,7 +511,9 @@ k_strip_scatter(StripArgs a) {
         int r = r0 + gy;
         if (!first_rows_loaded) load_rows(za, va, r);
         first_rows_loaded = false;
+        load_ay(aya, r);
         load_rows(zb_, vb_, r + step);
+        load_ay(ayb, r + step);
         DM_STAMP(11);
         // younger waves of a SIMD get the higher issue priority in the loop (age arbitration
         // favours the oldest wave otherwise, and the last wave left on a SIMD runs latency
@@ -428,13 +527,15 @@ k_strip_scatter(StripArgs a) {
         for (int it = 0; it < niter; it += 2) {
 #pragma unroll
           for (int t = 0; t < kFillPerHalf; ++t) fill_step();
-          project_rows(tested, za, va, r);
+          project_rows(tested, za, va, aya);
           if (it + 1 < niter) {
             load_rows(za, va, r + 2 * step);
+            load_ay(aya, r + 2 * step);
 #pragma unroll
             for (int t = 0; t < kFillPerHalf; ++t) fill_step();
-            project_rows(tested, zb_, vb_, r + step);
+            project_rows(tested, zb_, vb_, ayb);
             load_rows(zb_, vb_, r + 3 * step);        // (past the end: the last row again, unused)
+            load_ay(ayb, r + 3 * step);
           }
           r += 2 * step;
         }
@@ -452,8 +553,8 @@ k_strip_scatter(StripArgs a) {
   lds_barrier();
   DM_STAMP(5);
   // Flush, 16 lanes per window row: the groups of this strip's cover go straight to the map where
-  // the strip owns them (no other strip's cover reaches them), else to the slab, which
-  // k_strip_merge combines with the other strips'.
+  // the strip owns them (no other strip's cover reaches them), else to the slab: k_strip_combine
+  // combines those with the other strips'.
   if (area > 0) {
     const int l16 = (int)threadIdx.x & 15;
     const int unit = b * a.oc + chl;             // (frame, channel): the P workgroups that share a map
@@ -465,12 +566,12 @@ k_strip_scatter(StripArgs a) {
       const int cell0 = row * w.w - w.x0;
       for (int x = lo + (l16 << 2); x < hi; x += 64) {
         const float4 v = *reinterpret_cast<const float4*>(lds + cell0 + x);
-        if (strip::in_span(e.owned, x) && a.out != nullptr) {
-          const size_t cell = map_base + (size_t)z * a.mw + x;
-          *reinterpret_cast<float4*>(a.out + cell) = v;
-          *reinterpret_cast<uint32_t*>(a.mask + cell) =
+        if (strip::in_span(e.owned, x)) {
+          const int cell = z * a.mw + x;
+          __builtin_amdgcn_raw_buffer_store_b128((f32x4){v.x, v.y, v.z, v.w}, rs_out, cell << 2, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(
               (uint32_t)mask_of(v.x, a.fill) | ((uint32_t)mask_of(v.y, a.fill) << 8) |
-              ((uint32_t)mask_of(v.z, a.fill) << 16) | ((uint32_t)mask_of(v.w, a.fill) << 24);
+              ((uint32_t)mask_of(v.z, a.fill) << 16) | ((uint32_t)mask_of(v.w, a.fill) << 24), rs_mask, cell, 0, 0);
         } else {
           *reinterpret_cast<float4*>(slab + cell0 + x) = v;
         }
@@ -481,122 +582,68 @@ k_strip_scatter(StripArgs a) {
   DM_STAMPS_OUT();
 }
 
-struct StripMergeArgs {
+struct StripCombineArgs {
   int b0, oc, ch0, oc_total, mh, mw;
-  int P, slab_stride, max_rows;
+  int P, slab_stride, list_cap;
   float fill;
   const Win16* g_wins;
   const Win16* g_unions;
-  const strip::RowEntry* g_rows;
-  const float* slabs;         // (the 8 floats in front of it: -inf x 4, +inf x 4)
+  const int* g_counts;
+  const uint32_t* g_list;
+  const float* slabs;
   float* out;
   uint8_t* mask;
 };
 
-constexpr int kMergeRowsPerWave = 4;
-constexpr int kMergeRowsPerBlock = kMergeThreads / 64 * kMergeRowsPerWave;
-static_assert(strip::kSpanAlign == 4, "k_strip_merge reads a slab wherever a cover is: covers must lie inside the windows");
+constexpr int kCombineThreads = 256;
+constexpr int kCombineBlocks = 16;             // per (frame, channel); the threads stride over the list
 
-// One wave per kMergeRowsPerWave map rows of a frame's union window, lanes along the row: a
-// group inside some strip's owned span was written by k_strip_scatter; every other group gets
-// the max / min of the slabs of the strips whose covers hold it (the fill value where none
-// does).  The kernel is bound by instruction issue (16 K rows of a few groups each), so what a
-// row needs is kept wave-uniform -- lane p fetches strip p's row entry and window in one batch
-// of loads, the values are broadcast from the lanes, the span arithmetic runs on the scalar
-// unit -- and P is a template parameter: P slab loads in flight per row, no loop.  Strips with
-// nothing for a group load `ident` (a float4 of the reduction's identity) instead.
-template <int RED, int P>
-__global__ void __launch_bounds__(kMergeThreads)
-k_strip_merge(StripMergeArgs a) {
+// The groups of a frame's reach spans that no strip owns (the frame's shared-group list,
+// k_strip_prepare): max / min over the slabs of the strips whose covers hold the group -- the fill
+// value where none does -- written to the map with its mask bytes.  One list entry per thread;
+// what a block needs of the frame (count, union window, the strips' windows) is wave-uniform.
+template <int RED>
+__global__ void __launch_bounds__(kCombineThreads)
+k_strip_combine(StripCombineArgs a) {
   const int fcl = blockIdx.y;                  // (frame of the launch) * oc + channel of the group
   const int bl = fcl / a.oc, b = a.b0 + bl;
   const int chl = fcl - bl * a.oc;
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int lane = (int)threadIdx.x & 63;
-  const int row0 = (blockIdx.x * (kMergeThreads / 64) + wave) * kMergeRowsPerWave;
-  if (row0 >= a.max_rows) return;
-  const int pi = lane < P ? lane : P - 1;
-  const Win16 wv = a.g_wins[(size_t)b * strip::kMaxStrips + pi];
-  const Window U = widen(a.g_unions[b]);
-  const strip::RowEntry* re = a.g_rows + ((size_t)b * a.max_rows + row0) * P + pi;
-  strip::RowEntry ev[kMergeRowsPerWave];
+  const int listed = a.g_counts[b];
+  const int first = blockIdx.x * kCombineThreads + (int)threadIdx.x;
+  if (blockIdx.x * kCombineThreads >= listed) return;
+  const int2 u_raw = *reinterpret_cast<const int2*>(a.g_unions + b);
+  const int ux0 = (short)(u_raw.x & 0xffff), uz0 = (short)(u_raw.x >> 16);
+  int2 wq[strip::kMaxStrips];
 #pragma unroll
-  for (int k = 0; k < kMergeRowsPerWave; ++k)   // (rows past max_rows: clamped, unused)
-    ev[k] = re[(size_t)(row0 + k < a.max_rows ? k : 0) * P];
-  int wxz = (int)(uint16_t)wv.x0 | ((int)(uint16_t)wv.z0 << 16), www = (int)(uint16_t)wv.w;
-  // The lanes' values are read across lanes inside divergent code below: they must exist in
-  // EVERY lane, i.e. be loaded here, where all lanes are active (left to itself the compiler
-  // sinks the loads to their uses, where only the lanes of the row's groups execute them).
-  asm volatile("" : "+v"(wxz), "+v"(www));
-#pragma unroll
-  for (int k = 0; k < kMergeRowsPerWave; ++k) asm volatile("" : "+v"(ev[k].cover), "+v"(ev[k].owned));
-  // Lane p prepares strip p's numbers for every row (vector ALU, all strips at once: the scalar
-  // unit is shared by the CU's waves and would be the bottleneck of this kernel); they are
-  // broadcast from the lanes where they are used.
-  //   base: where cell (0, 0) of the map would lie in the strip's slab, as a 32-bit float index
-  //         relative to `slabs` (the slabs of one channel group hold fewer than 2^31 floats)
-  const int ww_l = www;
-  const int base_l = pi * a.slab_stride - (wxz >> 16) * ww_l - (int)(int16_t)(wxz & 0xffff);
-  int clo_l[kMergeRowsPerWave], olo_l[kMergeRowsPerWave], ohi_l[kMergeRowsPerWave],
-      chi_l[kMergeRowsPerWave], off_l[kMergeRowsPerWave];
-#pragma unroll
-  for (int k = 0; k < kMergeRowsPerWave; ++k) {
-    const uint32_t cover = ev[k].cover, owned = ev[k].owned;
-    clo_l[k] = (int)(cover & 0xffffu); chi_l[k] = (int)(cover >> 16);
-    olo_l[k] = owned ? (int)(owned & 0xffffu) : clo_l[k];      // (no owned span: an empty one at clo)
-    ohi_l[k] = owned ? (int)(owned >> 16) : clo_l[k];
-    off_l[k] = base_l + (U.z0 + row0 + k) * ww_l;
-    // (read across lanes inside divergent code below: must be computed here, in every lane)
-    asm volatile("" : "+v"(clo_l[k]), "+v"(olo_l[k]), "+v"(ohi_l[k]), "+v"(chi_l[k]), "+v"(off_l[k]));
-  }
-  const size_t fo = (size_t)b * a.oc_total + a.ch0 + chl;
-  const float* slabs = a.slabs + ((size_t)(b * a.oc + chl) * P) * a.slab_stride;
-  // the reduction's identity as a float4 in memory, 8 (max) / 4 (min) floats in front of the slabs
-  const int ident_at = (int)(a.slabs - slabs) - (RED == kMax ? 8 : 4);
+  for (int q = 0; q < strip::kMaxStrips; ++q)
+    wq[q] = *reinterpret_cast<const int2*>(a.g_wins + (size_t)b * strip::kMaxStrips + (q < a.P ? q : 0));
+  const uint32_t* const list = a.g_list + (size_t)b * a.list_cap;
+  const float* const slabs = a.slabs + ((size_t)(b * a.oc + chl) * a.P) * a.slab_stride;
+  const size_t fo = ((size_t)b * a.oc_total + a.ch0 + chl) * (size_t)a.mh * a.mw;
   const float ident = RED == kMax ? -INFINITY : INFINITY;
+  for (int i = first; i < listed; i += kCombineBlocks * kCombineThreads) {
+    const uint32_t entry = list[i];
+    const int z = uz0 + (int)(entry & 0xfffu), x = ux0 + (int)(((entry >> 12) & 0xfffu) << 2);
+    float4 t[strip::kMaxStrips];
 #pragma unroll
-  for (int k = 0; k < kMergeRowsPerWave; ++k) {
-    const int row = row0 + k;
-    if (row >= U.h) break;                     // wave-uniform
-    const int zb = U.z0 + row;
-    float* const out_row = a.out + fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw;
-    uint8_t* const mask_row = a.mask + fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw;
-    // per strip: the two pieces of its cover around its owned span, its slab row's offset
-    int clo[P], olo[P], ohi[P], chi[P], off[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      clo[p] = __builtin_amdgcn_readlane(clo_l[k], p); olo[p] = __builtin_amdgcn_readlane(olo_l[k], p);
-      ohi[p] = __builtin_amdgcn_readlane(ohi_l[k], p); chi[p] = __builtin_amdgcn_readlane(chi_l[k], p);
-      off[p] = __builtin_amdgcn_readlane(off_l[k], p);
+    for (int q = 0; q < strip::kMaxStrips; ++q) {
+      const bool hit = ((entry >> (24 + q)) & 1u) != 0u;      // (never set for q >= P)
+      const int wx0 = (short)(wq[q].x & 0xffff), wz0 = (short)(wq[q].x >> 16), ww = (short)(wq[q].y & 0xffff);
+      t[q] = make_float4(ident, ident, ident, ident);
+      if (hit) t[q] = *reinterpret_cast<const float4*>(slabs + (size_t)q * a.slab_stride + (z - wz0) * ww + (x - wx0));
     }
-    for (int x = U.x0 + (lane << 2); x < U.x0 + U.w; x += 256) {
-      bool is_owned = false;
-      float4 sv[P];
+    // (the fill value takes part: utils.py:470-477 reduces INTO the filled canvas)
+    float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
 #pragma unroll
-      for (int p = 0; p < P; ++p) {
-        is_owned = is_owned | ((x >= olo[p]) & (x < ohi[p]));
-        const bool hit = ((x >= clo[p]) & (x < olo[p])) | ((x >= ohi[p]) & (x < chi[p]));
-        const int at = hit ? off[p] + x : ident_at;
-        sv[p] = *reinterpret_cast<const float4*>(slabs + at);
-      }
-      float4 acc = make_float4(ident, ident, ident, ident);
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        acc.x = combine<RED>(acc.x, sv[p].x);
-        acc.y = combine<RED>(acc.y, sv[p].y);
-        acc.z = combine<RED>(acc.z, sv[p].z);
-        acc.w = combine<RED>(acc.w, sv[p].w);
-      }
-      // (the fill value takes part: utils.py:470-477 reduces INTO the filled canvas)
-      acc.x = combine<RED>(acc.x, a.fill); acc.y = combine<RED>(acc.y, a.fill);
-      acc.z = combine<RED>(acc.z, a.fill); acc.w = combine<RED>(acc.w, a.fill);
-      if (is_owned) continue;
-      *reinterpret_cast<float4*>(out_row + x) = acc;
-      const uint32_t mk = (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
-                          ((uint32_t)mask_of(acc.z, a.fill) << 16) |
-                          ((uint32_t)mask_of(acc.w, a.fill) << 24);
-      *reinterpret_cast<uint32_t*>(mask_row + x) = mk;
+    for (int q = 0; q < strip::kMaxStrips; ++q) {
+      acc.x = combine<RED>(acc.x, t[q].x); acc.y = combine<RED>(acc.y, t[q].y);
+      acc.z = combine<RED>(acc.z, t[q].z); acc.w = combine<RED>(acc.w, t[q].w);
     }
+    const size_t cell = fo + (size_t)z * a.mw + x;
+    *reinterpret_cast<float4*>(a.out + cell) = acc;
+    *reinterpret_cast<uint32_t*>(a.mask + cell) =
+        (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+        ((uint32_t)mask_of(acc.z, a.fill) << 16) | ((uint32_t)mask_of(acc.w, a.fill) << 24);
   }
 }
 

@@ -20,6 +20,8 @@ buf = torch.zeros(4096 * 12 + 4096 * 16, dtype=torch.int64, device="cuda")
 lib.dm_debug_strip_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
 if os.environ.get("DM_STAMPS_LEGACY"):
   _native.lib().dm_debug_force_legacy_window(1)
+if os.environ.get("DM_STAMPS_TWO_KERNELS"):
+  _native.lib().dm_debug_strip_two_kernels(1)
 for _ in range(5):
   top, mask = proj.orth_project(depth, cam_pose=pose)
 torch.cuda.synchronize()
@@ -28,16 +30,23 @@ raw = allb[:4096 * 12].reshape(-1, 12)
 waves = allb[4096 * 12:].reshape(-1, 16)[:(raw[:, 0] != 0).sum()]
 raw = raw[raw[:, 0] != 0]
 st = raw[:, :7]
-names = ["frame record + geometry (wave 0)", "lds init + barrier", "cover table", "scatter loop",
-         "fill rest + barrier", "flush + publish"]
-d = np.diff(st, axis=1).astype(np.float64) * 0.01     # us
+def seg(name, i, j):
+  dd = (raw[:, j] - raw[:, i]) * 0.01
+  print(f"  {name:44s} {np.median(dd):8.2f} {dd.max():8.2f}")
 print("workgroups: %d   per-WG phase time in us (median / max):" % len(st))
-for i, n in enumerate(names):
-  print(f"  {n:34s} {np.median(d[:, i]):8.2f} {d[:, i].max():8.2f}")
+seg("scalar loads, lds init, ray-slope table", 0, 1)
+seg("row entries -> lds, barrier", 1, 2)
+seg("second loads (head of the pipeline)", 2, 11)
+seg("pixel loop", 11, 4)
+seg("rest of the fill duty + barrier", 4, 5)
 if raw[:, 7].any():
-  print("  (inside 'scatter loop': row table %.2f / %.2f, loop proper %.2f / %.2f)" % (
-      np.median(raw[:, 8] - raw[:, 7]) * 0.01, (raw[:, 8] - raw[:, 7]).max() * 0.01,
-      np.median(raw[:, 4] - raw[:, 8]) * 0.01, (raw[:, 4] - raw[:, 8]).max() * 0.01))
+  seg("tail: shared groups -> slab", 5, 7)
+  seg("tail: drain + barrier", 7, 8)
+  seg("tail: owned groups -> map (counter in flight)", 8, 9)
+  seg("tail: counter back + barrier", 9, 10)
+  seg("tail: combine (the last workgroup of a frame)", 10, 6)
+else:
+  seg("flush", 5, 6)
 tot = (st[:, -1] - st[:, 0]) * 0.01
 print("  total                              %8.2f %8.2f" % (np.median(tot), tot.max()))
 print("kernel span us: %.2f   start skew: %.2f   end skew: %.2f" % (

@@ -221,7 +221,7 @@ StripKernel pick_strip_kernel(bool is_max, bool has_valid, bool has_value, bool 
 
 
 // Device copy of a batch's camera state as the kernels read it ("prepared frames"):
-// [Cfg (kCfgBytes) | status word (256 B) | frame records | frame tables].
+// [Cfg (kCfgBytes) | status word (256 B) | list counters | frame records | frame tables].
 // Lives at the head of the workspace for dm_orth_project_f32 (staged by one copy per call, the
 // tables by k_strip_prepare right behind it) or in a buffer of the caller's that
 // dm_frames_prepare_f32 filled once (dm_orth_project_prepared_f32: no copy and no geometry,
@@ -241,12 +241,13 @@ inline size_t list_cap_bound(const dm_params& p) {
 }
 inline size_t tables_bytes(const dm_params& p) {
   return up256((size_t)p.B * strip::kMaxStrips * sizeof(Win16)) + up256((size_t)p.B * sizeof(Win16)) +
-         2 * up256((size_t)p.B * sizeof(int)) +
+         up256((size_t)p.B * sizeof(int)) +
          up256((size_t)p.B * p.mh * strip::kMaxStrips * sizeof(strip::RowEntry)) +
          up256((size_t)p.B * p.mh * sizeof(uint2)) + up256((size_t)p.B * list_cap_bound(p) * sizeof(uint32_t));
 }
-inline size_t staged_bytes(const dm_params& p) {      // what the host copies: Cfg, status, frame records
-  return kCfgBytes + kStatusBytes + up256((size_t)p.B * sizeof(dm_frame));
+inline size_t counts_bytes(const dm_params& p) { return up256((size_t)p.B * sizeof(int)); }
+inline size_t staged_bytes(const dm_params& p) {      // what the host copies: Cfg, status, list counters (zero), frame records
+  return kCfgBytes + kStatusBytes + counts_bytes(p) + up256((size_t)p.B * sizeof(dm_frame));
 }
 inline size_t prepared_bytes(const dm_params& p) { return staged_bytes(p) + tables_bytes(p); }
 inline PreparedView view_prepared(const dm_params& p, void* dev) {
@@ -254,12 +255,12 @@ inline PreparedView view_prepared(const dm_params& p, void* dev) {
   PreparedView v;
   v.cfg = reinterpret_cast<const strip::Cfg*>(base);
   v.status = reinterpret_cast<int*>(base + kCfgBytes);
-  v.frames = reinterpret_cast<const float*>(base + kCfgBytes + kStatusBytes);
+  v.t.counts = reinterpret_cast<int*>(base + kCfgBytes + kStatusBytes);
+  v.frames = reinterpret_cast<const float*>(base + kCfgBytes + kStatusBytes + counts_bytes(p));
   base += staged_bytes(p);
   v.t.wins = reinterpret_cast<Win16*>(base); base += up256((size_t)p.B * strip::kMaxStrips * sizeof(Win16));
   v.t.unions = reinterpret_cast<Win16*>(base); base += up256((size_t)p.B * sizeof(Win16));
   v.t.flags = reinterpret_cast<int*>(base); base += up256((size_t)p.B * sizeof(int));
-  v.t.counts = reinterpret_cast<int*>(base); base += up256((size_t)p.B * sizeof(int));
   v.t.rows = reinterpret_cast<strip::RowEntry*>(base); base += up256((size_t)p.B * p.mh * strip::kMaxStrips * sizeof(strip::RowEntry));
   v.t.reach = reinterpret_cast<uint2*>(base); base += up256((size_t)p.B * p.mh * sizeof(uint2));
   v.t.list = reinterpret_cast<uint32_t*>(base);
@@ -442,9 +443,9 @@ bool aligned_for_strips(const float* depth, const float* value, const uint8_t* v
 const std::vector<unsigned char>& stage_prepared(const dm_params& p, const Rig& rg, const dm_frame* frames_host) {
   thread_local std::vector<unsigned char> stage;
   stage.resize(staged_bytes(p));
-  memset(stage.data(), 0, kCfgBytes + kStatusBytes);
+  memset(stage.data(), 0, kCfgBytes + kStatusBytes + counts_bytes(p));
   memcpy(stage.data(), &rg.cfg, sizeof(strip::Cfg));
-  dm_frame* f = reinterpret_cast<dm_frame*>(stage.data() + kCfgBytes + kStatusBytes);
+  dm_frame* f = reinterpret_cast<dm_frame*>(stage.data() + kCfgBytes + kStatusBytes + counts_bytes(p));
   memcpy(f, frames_host, (size_t)p.B * sizeof(dm_frame));
   if (!p.to_global) {       // local map: neutral yaw, no translation (exact: x * 1 + z * 0 + 0)
     static const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -498,7 +499,7 @@ hipError_t launch_prepare(const dm_params& p, const dm_frames_plan& fp, const Pr
   pa.cfg = pv.cfg; pa.frames = pv.frames;
   pa.slab_stride = fp.slab_cells; pa.max_rows = fp.max_rows; pa.mw = p.mw; pa.list_cap = list_cap_of(p, fp);
   pa.t = pv.t; pa.status = pv.status;
-  return launch(k_strip_prepare, dim3(p.B), dim3(kPrepThreads), 0, s, pa);
+  return launch(k_strip_prepare, dim3(p.B, kPrepSlices), dim3(kPrepThreads), 0, s, pa);
 }
 
 dm_frames_plan plan_of(const Plan& plan, const Rig& rg) {

@@ -69,7 +69,7 @@ struct FrameTables {
   Win16* wins;                // (B, kMaxStrips)
   Win16* unions;              // (B)   union windows, x in whole kSpanAlign groups
   int* flags;                 // (B)   FrameGeom::inside
-  int* counts;                // (B)   entries of the frame's shared-group list
+  int* counts;                // (B)   entries of the frame's shared-group list (may exceed list_cap: clamp)
   strip::RowEntry* rows;      // (B, max_rows, P)   per row and strip: cover, owned
   uint2* reach;               // (B, max_rows)      per row: {lo, width} of the hull of the covers
   uint32_t* list;             // (B, list_cap)      the groups of the reach spans nobody owns
@@ -91,19 +91,24 @@ struct StripPrepArgs {
 };
 
 constexpr int kPrepThreads = 256;
+constexpr int kPrepSlices = 4;                 // workgroups per frame, each a band of the union window's rows
+constexpr int kPrepListLds = 2048;             // list entries a workgroup collects in LDS before it appends them
 
-// One workgroup per frame: the frame's geometry (wave 0) and its row table -- cover and owned
-// span of every strip on every row of the union window (thread = (row, strip), the strips of a
-// row in neighbouring lanes, which exchange their covers by shuffles), the hull of the covers
-// per row ("reach": outside it the map holds the fill value) and the list of the float4 groups
-// inside the hulls that no strip owns (several strips reach them, or none: what is left to
-// combine after the strips have written their own groups).  Runs once per set of poses
+// kPrepSlices workgroups per frame: the frame's geometry (wave 0 of each) and, for the
+// workgroup's band of rows of the union window, the row table -- cover and owned span of every
+// strip (thread = (row, strip), the strips of a row in neighbouring lanes, which exchange their
+// covers by shuffles), the hull of the covers per row ("reach": outside it the map holds the
+// fill value) and the list of the float4 groups inside the hulls that no strip owns (several
+// strips reach them, or none: what is left to combine after the strips have written their own
+// groups; collected in LDS, appended with one atomic per workgroup to the frame's list, whose
+// counter the host zeroed with the staged copy).  Runs once per set of poses
 // (dm_frames_prepare_f32) or in front of the projection kernels (dm_orth_project_f32).
 __global__ void __launch_bounds__(kPrepThreads)
 k_strip_prepare(StripPrepArgs a) {
   __shared__ strip::FrameGeom geom;
-  __shared__ int listed;
-  const int b = blockIdx.x;
+  __shared__ int listed, list_base;
+  __shared__ uint32_t found[kPrepListLds];
+  const int b = blockIdx.x, slice = blockIdx.y;
   const float* f = a.frames + (size_t)b * 32;
   if (threadIdx.x == 0) listed = 0;
   if (threadIdx.x < 64)
@@ -121,55 +126,72 @@ k_strip_prepare(StripPrepArgs a) {
   bool fits = geom.ok != 0 && U.h <= a.max_rows && U.h <= kListMaxRows && U.w <= 4 * kListMaxGroups;
   for (int s = 0; s < strip::kMaxStrips; ++s) fits = fits && (int)geom.win[s].w * geom.win[s].h <= a.slab_stride;
   if (!fits) {
-    if (threadIdx.x == 0 && (U.w > 0 || !geom.ok)) atomicOr(a.status, 1);
+    if (threadIdx.x == 0 && slice == 0 && (U.w > 0 || !geom.ok)) atomicOr(a.status, 1);
     U = Window{0, 0, 0, 0};
   }
-  if (threadIdx.x < strip::kMaxStrips)
-    a.t.wins[(size_t)b * strip::kMaxStrips + threadIdx.x] = fits ? geom.win[threadIdx.x] : Win16{0, 0, 0, 0};
-  if (threadIdx.x == 0) { a.t.unions[b] = narrow16(U); a.t.flags[b] = fits ? geom.inside : 0; }
+  if (slice == 0) {
+    if (threadIdx.x < strip::kMaxStrips)
+      a.t.wins[(size_t)b * strip::kMaxStrips + threadIdx.x] = fits ? geom.win[threadIdx.x] : Win16{0, 0, 0, 0};
+    if (threadIdx.x == 0) { a.t.unions[b] = narrow16(U); a.t.flags[b] = fits ? geom.inside : 0; }
+  }
+  // appends the entries collected in LDS to the frame's list (all threads call it)
+  auto append = [&]() {
+    __syncthreads();
+    const int n = listed < kPrepListLds ? listed : kPrepListLds;
+    if (threadIdx.x == 0) list_base = n > 0 ? atomicAdd(a.t.counts + b, n) : 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kPrepThreads)
+      if (list_base + i < a.list_cap) a.t.list[(size_t)b * a.list_cap + list_base + i] = found[i];
+    if (threadIdx.x == 0 && list_base + n > a.list_cap) atomicOr(a.status, 2);   // (cannot happen: the list holds every group of U)
+    __syncthreads();
+    if (threadIdx.x == 0) listed = 0;
+    __syncthreads();
+  };
   const int P2 = nparts <= 4 ? 4 : 8;
   const int sub = (int)threadIdx.x & (P2 - 1);
   const int per_pass = kPrepThreads / P2;
-  for (int r = (int)threadIdx.x / P2; r < U.h; r += per_pass) {
-    const int ps = sub < nparts ? sub : 0;
-    uint32_t cover = strip::row_cover(geom.win[ps], geom.L[ps], geom.R[ps], U.z0 + r, a.mw);
-    cover = sub < nparts ? cover : 0u;
-    int lo = (int)(cover & 0xffffu), hi = (int)(cover >> 16);
-    int rlo = cover ? (int)(cover & 0xffffu) : 32767, rhi = (int)(cover >> 16);
-    for (int m = 1; m < P2; ++m) {
-      const uint32_t other = (uint32_t)__shfl_xor((int)cover, m, 64);
-      strip::cut_span(lo, hi, other);
-      rlo = min(rlo, other ? (int)(other & 0xffffu) : 32767); rhi = max(rhi, (int)(other >> 16));
-    }
-    const uint32_t owned = hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
-    if (sub < nparts) a.t.rows[((size_t)b * a.max_rows + r) * nparts + sub] = strip::RowEntry{cover, owned};
-    if (sub == 0) a.t.reach[(size_t)b * a.max_rows + r] = rhi > rlo ? make_uint2((unsigned)rlo, (unsigned)(rhi - rlo)) : make_uint2(0u, 0u);
-    // the groups of [rlo, rhi) nobody owns: the P2 lanes of the row take every P2-th group
-    uint32_t cov[8], own[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      cov[q] = (uint32_t)__shfl((int)cover, ((int)threadIdx.x & 63 & ~(P2 - 1)) + (q & (P2 - 1)), 64);
-      own[q] = (uint32_t)__shfl((int)owned, ((int)threadIdx.x & 63 & ~(P2 - 1)) + (q & (P2 - 1)), 64);
-      if (q >= P2) { cov[q] = 0u; own[q] = 0u; }
-    }
-    for (int x = rlo + 4 * sub; x < rhi; x += 4 * P2) {
-      uint32_t hits = 0;
-      bool mine = false;
+  const int band = (U.h + kPrepSlices - 1) / kPrepSlices;
+  const int r_end = min(U.h, (slice + 1) * band);
+  for (int r0 = slice * band; r0 < r_end; r0 += per_pass) {      // (uniform trip count: append() has barriers)
+    const int r = r0 + (int)threadIdx.x / P2;
+    if (r < r_end) {
+      const int ps = sub < nparts ? sub : 0;
+      uint32_t cover = strip::row_cover(geom.win[ps], geom.L[ps], geom.R[ps], U.z0 + r, a.mw);
+      cover = sub < nparts ? cover : 0u;
+      int lo = (int)(cover & 0xffffu), hi = (int)(cover >> 16);
+      int rlo = cover ? (int)(cover & 0xffffu) : 32767, rhi = (int)(cover >> 16);
+      for (int m = 1; m < P2; ++m) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)cover, m, 64);
+        strip::cut_span(lo, hi, other);
+        rlo = min(rlo, other ? (int)(other & 0xffffu) : 32767); rhi = max(rhi, (int)(other >> 16));
+      }
+      const uint32_t owned = hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
+      if (sub < nparts) a.t.rows[((size_t)b * a.max_rows + r) * nparts + sub] = strip::RowEntry{cover, owned};
+      if (sub == 0) a.t.reach[(size_t)b * a.max_rows + r] = rhi > rlo ? make_uint2((unsigned)rlo, (unsigned)(rhi - rlo)) : make_uint2(0u, 0u);
+      // the groups of [rlo, rhi) nobody owns: the P2 lanes of the row take every P2-th group
+      uint32_t cov[8], own[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        hits |= strip::in_span(cov[q], x) ? 1u << q : 0u;
-        mine = mine | strip::in_span(own[q], x);
+        cov[q] = (uint32_t)__shfl((int)cover, ((int)threadIdx.x & 63 & ~(P2 - 1)) + (q & (P2 - 1)), 64);
+        own[q] = (uint32_t)__shfl((int)owned, ((int)threadIdx.x & 63 & ~(P2 - 1)) + (q & (P2 - 1)), 64);
+        if (q >= P2) { cov[q] = 0u; own[q] = 0u; }
       }
-      if (!mine) {
-        const int at = atomicAdd(&listed, 1);
-        if (at < a.list_cap) a.t.list[(size_t)b * a.list_cap + at] = pack_shared(r, (x - U.x0) >> 2, hits);
+      for (int x = rlo + 4 * sub; x < rhi; x += 4 * P2) {
+        uint32_t hits = 0;
+        bool mine = false;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          hits |= strip::in_span(cov[q], x) ? 1u << q : 0u;
+          mine = mine | strip::in_span(own[q], x);
+        }
+        if (!mine) {
+          const int at = atomicAdd(&listed, 1);
+          if (at < kPrepListLds) found[at] = pack_shared(r, (x - U.x0) >> 2, hits);
+          else atomicOr(a.status, 2);         // (a pass of 64 rows with more than 2048 shared groups)
+        }
       }
     }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    a.t.counts[b] = listed < a.list_cap ? listed : a.list_cap;
-    if (listed > a.list_cap) atomicOr(a.status, 2);       // (cannot happen: the list holds every group of U)
+    append();
   }
 }
 
@@ -273,6 +295,7 @@ k_strip_scatter(StripArgs a) {
       }
     }
   };
+  // the first rows: requested from kernel arguments alone, before anything else
   bool first_rows_loaded = false;
   if (gx < nx && q1 > q0) {
     load_rows_at(za, va, q0 + gx * VEC, r0 + gy);
@@ -296,8 +319,6 @@ k_strip_scatter(StripArgs a) {
   const int2 w_raw = *reinterpret_cast<const int2*>(a.g_wins + (size_t)b * strip::kMaxStrips + part);
   const int2 u_raw = *reinterpret_cast<const int2*>(a.g_unions + b);
   int flags = a.g_flags[b];
-  asm volatile("" : "+s"(p4), "+s"(p5), "+s"(p7), "+s"(p8), "+s"(cam_h), "+s"(fy0), "+s"(fy2),
-                    "+s"(fy6), "+s"(fy8), "+s"(ftx), "+s"(ftz), "+s"(wo), "+s"(ho));
 #ifdef DM_STAMPS
   long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -320,6 +341,9 @@ k_strip_scatter(StripArgs a) {
     aytab[r] = ay;
   }
   DM_STAMP(1);
+  // (the scalar loads are waited for only here, under the LDS work above; pinned: one batch)
+  asm volatile("" : "+s"(p4), "+s"(p5), "+s"(p7), "+s"(p8), "+s"(cam_h), "+s"(fy0), "+s"(fy2),
+                    "+s"(fy6), "+s"(fy8), "+s"(ftx), "+s"(ftz), "+s"(wo), "+s"(ho));
   Window w = {(short)(w_raw.x & 0xffff), (short)(w_raw.x >> 16), (short)(w_raw.y & 0xffff), (short)(w_raw.y >> 16)};
   Window U = {(short)(u_raw.x & 0xffff), (short)(u_raw.x >> 16), (short)(u_raw.y & 0xffff), (short)(u_raw.y >> 16)};
   {
@@ -490,7 +514,7 @@ k_strip_scatter(StripArgs a) {
             li[k] = ok ? addr : dummy;
             hv[k] = sval;
           }
-          if (__builtin_amdgcn_ballot_w64(li[0] == li[VEC - 1] && li[0] != dummy) != 0) {
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(li[0] == li[VEC - 1] && li[0] != dummy) != 0, 0)) {
 #pragma unroll
             for (int k = 0; k + 1 < VEC; ++k) {
               const bool same = li[k] == li[k + 1];
@@ -519,18 +543,38 @@ k_strip_scatter(StripArgs a) {
         // favours the oldest wave otherwise, and the last wave left on a SIMD runs latency
         // bound).  Only now: under static priorities the four waves of a SIMD run the code
         // above one after the other instead of hiding each other's latencies.
-#ifndef DM_X_NOPRIO
+#ifdef DM_X_ROTPRIO
+        const int cls = wave >> 2;
+        // s_setprio takes an immediate: one opaque block of scalar code picks it (a branch the
+        // compiler sees would make it drain the loop's counted waits)
+        auto set_prio = [](int p) {
+          asm volatile("s_cmp_eq_u32 %0, 3\n\ts_cbranch_scc1 .Lp3_%=\n\t"
+                       "s_cmp_eq_u32 %0, 2\n\ts_cbranch_scc1 .Lp2_%=\n\t"
+                       "s_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 .Lp1_%=\n\t"
+                       "s_setprio 0\n\ts_branch .Lpe_%=\n"
+                       ".Lp3_%=:\n\ts_setprio 3\n\ts_branch .Lpe_%=\n"
+                       ".Lp2_%=:\n\ts_setprio 2\n\ts_branch .Lpe_%=\n"
+                       ".Lp1_%=:\n\ts_setprio 1\n"
+                       ".Lpe_%=:\n" :: "s"(p) : "scc");
+        };
+#elif !defined(DM_X_NOPRIO)
         if (wave >= 12) __builtin_amdgcn_s_setprio(3);
         else if (wave >= 8) __builtin_amdgcn_s_setprio(2);
         else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
         for (int it = 0; it < niter; it += 2) {
+#ifdef DM_X_ROTPRIO
+          set_prio((cls + it) & 3);
+#endif
 #pragma unroll
           for (int t = 0; t < kFillPerHalf; ++t) fill_step();
           project_rows(tested, za, va, aya);
           if (it + 1 < niter) {
             load_rows(za, va, r + 2 * step);
             load_ay(aya, r + 2 * step);
+#ifdef DM_X_ROTPRIO
+            set_prio((cls + it + 1) & 3);
+#endif
 #pragma unroll
             for (int t = 0; t < kFillPerHalf; ++t) fill_step();
             project_rows(tested, zb_, vb_, ayb);
@@ -608,7 +652,7 @@ k_strip_combine(StripCombineArgs a) {
   const int fcl = blockIdx.y;                  // (frame of the launch) * oc + channel of the group
   const int bl = fcl / a.oc, b = a.b0 + bl;
   const int chl = fcl - bl * a.oc;
-  const int listed = a.g_counts[b];
+  const int listed = min(a.g_counts[b], a.list_cap);
   const int first = blockIdx.x * kCombineThreads + (int)threadIdx.x;
   if (blockIdx.x * kCombineThreads >= listed) return;
   const int2 u_raw = *reinterpret_cast<const int2*>(a.g_unions + b);

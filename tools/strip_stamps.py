@@ -20,11 +20,17 @@ buf = torch.zeros(4096 * 12 + 4096 * 16, dtype=torch.int64, device="cuda")
 lib.dm_debug_strip_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
 if os.environ.get("DM_STAMPS_LEGACY"):
   _native.lib().dm_debug_force_legacy_window(1)
-if os.environ.get("DM_STAMPS_TWO_KERNELS"):
-  _native.lib().dm_debug_strip_two_kernels(1)
+if os.environ.get("DM_STAMPS_STRIPS"):
+  _native.lib().dm_debug_force_strips(int(os.environ["DM_STAMPS_STRIPS"]))
 for _ in range(5):
   top, mask = proj.orth_project(depth, cam_pose=pose)
 torch.cuda.synchronize()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+ev[0].record()
+for _ in range(20):
+  top, mask = proj.orth_project(depth, cam_pose=pose)
+ev[1].record(); torch.cuda.synchronize()
+print("orth_project call (pose upload + prepare + scatter + combine): %.1f us" % (ev[0].elapsed_time(ev[1]) * 50))
 allb = buf.cpu().numpy()
 raw = allb[:4096 * 12].reshape(-1, 12)
 waves = allb[4096 * 12:].reshape(-1, 16)[:(raw[:, 0] != 0).sum()]

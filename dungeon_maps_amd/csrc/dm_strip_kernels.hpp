@@ -652,8 +652,12 @@ k_strip_combine(StripCombineArgs a) {
   const int fcl = blockIdx.y;                  // (frame of the launch) * oc + channel of the group
   const int bl = fcl / a.oc, b = a.b0 + bl;
   const int chl = fcl - bl * a.oc;
-  const int listed = min(a.g_counts[b], a.list_cap);
   const int first = blockIdx.x * kCombineThreads + (int)threadIdx.x;
+  const uint32_t* const list = a.g_list + (size_t)b * a.list_cap;
+  // (the thread's first entry is requested before the list's length is known: one round trip
+  // less in a kernel that is nothing but a chain of them)
+  uint32_t entry = first < a.list_cap ? list[first] : 0u;
+  const int listed = min(a.g_counts[b], a.list_cap);
   if (blockIdx.x * kCombineThreads >= listed) return;
   const int2 u_raw = *reinterpret_cast<const int2*>(a.g_unions + b);
   const int ux0 = (short)(u_raw.x & 0xffff), uz0 = (short)(u_raw.x >> 16);
@@ -661,12 +665,11 @@ k_strip_combine(StripCombineArgs a) {
 #pragma unroll
   for (int q = 0; q < strip::kMaxStrips; ++q)
     wq[q] = *reinterpret_cast<const int2*>(a.g_wins + (size_t)b * strip::kMaxStrips + (q < a.P ? q : 0));
-  const uint32_t* const list = a.g_list + (size_t)b * a.list_cap;
   const float* const slabs = a.slabs + ((size_t)(b * a.oc + chl) * a.P) * a.slab_stride;
   const size_t fo = ((size_t)b * a.oc_total + a.ch0 + chl) * (size_t)a.mh * a.mw;
   const float ident = RED == kMax ? -INFINITY : INFINITY;
   for (int i = first; i < listed; i += kCombineBlocks * kCombineThreads) {
-    const uint32_t entry = list[i];
+    if (i != first) entry = list[i];
     const int z = uz0 + (int)(entry & 0xfffu), x = ux0 + (int)(((entry >> 12) & 0xfffu) << 2);
     float4 t[strip::kMaxStrips];
 #pragma unroll

@@ -63,3 +63,18 @@ if waves.any():
   rel = (waves - st[:, :1]) * 0.01            # each wave's loop end, relative to its workgroup's start
   print("loop end by wave index (mean us after WG start):", np.round(rel.mean(axis=0), 1))
   print("  first / last wave of a WG (median): %.2f / %.2f" % (np.median(rel.min(axis=1)), np.median(rel.max(axis=1))))
+
+# where the slow workgroups are: pixel-loop time by strip, by XCD (workgroup id mod 8), by frame
+loop = (raw[:, 4] - raw[:, 11]) * 0.01
+wg = np.arange(len(loop))
+if len(loop) % 4 == 0 and not os.environ.get("DM_STAMPS_STRIPS"):
+  print("pixel loop by strip:", np.round([loop[wg % 4 == s].mean() for s in range(4)], 2))
+  print("pixel loop by XCD:  ", np.round([loop[wg % 8 == x].mean() for x in range(8)], 2))
+  fr = loop.reshape(-1, 4).mean(axis=1)
+  yaw = pose[:, 2].numpy()
+  order = np.argsort(fr)
+  print("slowest frames (loop us, yaw deg):", [(round(float(fr[i]), 1), int(np.degrees(yaw[i]))) for i in order[-6:]])
+  print("fastest frames (loop us, yaw deg):", [(round(float(fr[i]), 1), int(np.degrees(yaw[i]))) for i in order[:6]])
+  print("per-WG loop: p10 %.2f  p50 %.2f  p90 %.2f  max %.2f" % tuple(np.percentile(loop, [10, 50, 90, 100])))
+  start = (raw[:, 0] - raw[:, 0].min()) * 0.01
+  print("corr(loop, start time) = %.2f" % np.corrcoef(loop, start)[0, 1])

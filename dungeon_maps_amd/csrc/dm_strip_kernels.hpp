@@ -243,6 +243,11 @@ k_strip_scatter(StripArgs a) {
   // rows of a thread in flight per pipeline stage: value maps carry a second float4 per row and
   // spill at four (the kernel is capped at 128 VGPRs by its 1024 threads)
   constexpr int kRowsInFlight = HAS_VALUE ? 2 : dm::kRowsInFlight;
+  // Heights without a height test: the camera height is added when the window is flushed, not
+  // per pixel.  x -> RN(x + c) is monotone, so max_i RN(h_i + c) = RN(max_i h_i + c) (min
+  // alike): the window reduces the raw heights from the reduction's identity, and the flush
+  // turns a cell into combine(fill, cell + cam_h) -- which is the fill value where nothing landed.
+  constexpr bool kDeferCamH = !HAS_VALUE && LEAN;
   extern __shared__ float lds[];
   const int part = blockIdx.x;                 // column strip
   const int chl = blockIdx.y;                  // channel within this launch's group
@@ -331,8 +336,9 @@ k_strip_scatter(StripArgs a) {
   const int lane = (int)threadIdx.x & 63;
   // The whole window region of LDS gets the fill value, the ray-slope table its H entries
   // (maps.py:670-678; border rows poisoned), under the first depth rows in flight.
+  const float lds_init = kDeferCamH ? (RED == kMax ? -INFINITY : INFINITY) : a.fill;
   for (int i = threadIdx.x * 4; i < a.slab_stride + 64; i += kScatterThreads * 4)
-    *reinterpret_cast<float4*>(lds + i) = make_float4(a.fill, a.fill, a.fill, a.fill);
+    *reinterpret_cast<float4*>(lds + i) = make_float4(lds_init, lds_init, lds_init, lds_init);
   for (int r = threadIdx.x; r < a.H; r += kScatterThreads) {
     float yr = (float)r;
     yr = a.flip_h ? a.Hm1 - yr : yr;
@@ -481,7 +487,8 @@ k_strip_scatter(StripArgs a) {
             const f2 axp = {ax[k], ax[k + 1]};
             const f2 X = axp * zz;
             const f2 Y = zz * ay;                                            // maps.py:677-678
-            const f2 h1 = __builtin_elementwise_fma(zz, (f2){p7, p7}, Y * p4) + cam_h;   // maps.py:790-797
+            f2 h1 = __builtin_elementwise_fma(zz, (f2){p7, p7}, Y * p4);                  // maps.py:790-797
+            if (!kDeferCamH) h1 = h1 + cam_h;
             const f2 z1 = __builtin_elementwise_fma(zz, (f2){p8, p8}, Y * p5);
             const f2 x2 = __builtin_elementwise_fma(z1, (f2){y6, y6}, X * y0) + tx;      // maps.py:884-892
             const f2 z2 = __builtin_elementwise_fma(z1, (f2){y8, y8}, X * y2r) + tz;
@@ -609,7 +616,11 @@ k_strip_scatter(StripArgs a) {
       const int lo = (int)(e.cover & 0xffffu), hi = (int)(e.cover >> 16);
       const int cell0 = row * w.w - w.x0;
       for (int x = lo + (l16 << 2); x < hi; x += 64) {
-        const float4 v = *reinterpret_cast<const float4*>(lds + cell0 + x);
+        float4 v = *reinterpret_cast<const float4*>(lds + cell0 + x);
+        if (kDeferCamH) {
+          v.x = combine<RED>(v.x + cam_h, a.fill); v.y = combine<RED>(v.y + cam_h, a.fill);
+          v.z = combine<RED>(v.z + cam_h, a.fill); v.w = combine<RED>(v.w + cam_h, a.fill);
+        }
         if (strip::in_span(e.owned, x)) {
           const int cell = z * a.mw + x;
           __builtin_amdgcn_raw_buffer_store_b128((f32x4){v.x, v.y, v.z, v.w}, rs_out, cell << 2, 0, 0);

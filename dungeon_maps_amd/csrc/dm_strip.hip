@@ -220,6 +220,23 @@ StripKernel pick_strip_kernel(bool is_max, bool has_valid, bool has_value, bool 
 }
 
 
+// Value maps of kListMinChannels channels or more (one depth channel for all of them): the cell of
+// every pixel is computed once (index pass) and the channels scatter from that list (value pass).
+constexpr int kListMinChannels = 3;
+StripKernel pick_index_kernel(bool has_valid, bool lean) {
+  if (lean && !has_valid) return k_strip_scatter<kMax, false, false, true, kIndexOut>;
+  return has_valid ? k_strip_scatter<kMax, true, false, false, kIndexOut>
+                   : k_strip_scatter<kMax, false, false, false, kIndexOut>;
+}
+StripKernel pick_value_kernel(bool is_max) {
+  return is_max ? k_strip_scatter<kMax, false, true, true, kFromList>
+                : k_strip_scatter<kMin, false, true, true, kFromList>;
+}
+inline size_t pixel_list_bytes(const dm_params& p) {     // (B, P, H, wp) uint16: P * wp <= W + 32 per strip
+  return up256((size_t)p.B * p.H * ((size_t)p.W + 32 * strip::kMaxStrips) * 2);
+}
+inline bool wants_pixel_list(const dm_params& p) { return p.vc >= kListMinChannels && p.dc == 1; }
+
 // Device copy of a batch's camera state as the kernels read it ("prepared frames"):
 // [Cfg (kCfgBytes) | status word (256 B) | list counters | frame records | frame tables].
 // Lives at the head of the workspace for dm_orth_project_f32 (staged by one copy per call, the
@@ -273,17 +290,20 @@ inline int list_cap_of(const dm_params& p, const dm_frames_plan& fp) {
 }
 
 struct Layout {               // workspace of the strip path
-  float* slabs;               // (the 8 floats in front of them: the reductions' identities)
+  float* slabs;
   size_t slab_bytes;
+  uint16_t* pixel_list;       // value maps of many channels: the pixels' cells (or NULL)
 };
 
-// [identities (256 B) | slabs ...]
-bool carve(void* ws, size_t ws_bytes, Layout& l) {
+// [256 B | slabs ... | pixel list]
+bool carve(const dm_params& p, void* ws, size_t ws_bytes, Layout& l) {
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return false;
   ws_bytes = ws_bytes / 256 * 256;
-  if (ws_bytes < 512) return false;
+  const size_t lb = wants_pixel_list(p) ? pixel_list_bytes(p) : 0;
+  if (ws_bytes < 512 + lb) return false;
   l.slabs = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + 256);
-  l.slab_bytes = ws_bytes - 256;
+  l.slab_bytes = ws_bytes - 256 - lb;
+  l.pixel_list = lb ? reinterpret_cast<uint16_t*>(static_cast<unsigned char*>(ws) + ws_bytes - lb) : nullptr;
   return true;
 }
 
@@ -341,11 +361,23 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
   sa.stamps = g_stamp_buffer;
 #endif
   const bool has_valid = valid != nullptr, has_value = value != nullptr;
-  const StripKernel kfn = pick_strip_kernel(is_max, has_valid, has_value, plan.lean);
+  const bool from_list = has_value && l.pixel_list != nullptr && wants_pixel_list(p);
+  sa.list = from_list ? l.pixel_list : nullptr;
+  const StripKernel kfn = from_list ? pick_value_kernel(is_max)
+                                    : pick_strip_kernel(is_max, has_valid, has_value, plan.lean);
   hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn));
   if (e != hipSuccess) return e;
   const size_t lds_bytes = strip_lds_bytes(rb.slab_cells, rb.max_rows, p.H);
   if (lds_bytes > (size_t)kMaxLdsBytes) return hipErrorNotSupported;
+  if (from_list) {            // the index pass: every pixel's cell inside its strip's window, once for all channels
+    const StripKernel ifn = pick_index_kernel(has_valid, plan.lean);
+    e = raise_lds_limit(reinterpret_cast<const void*>(ifn));
+    if (e != hipSuccess) return e;
+    StripArgs ia = sa;
+    ia.value = nullptr; ia.out = nullptr; ia.mask = nullptr; ia.oc = 1; ia.ch0 = 0; ia.oc_total = 1;
+    e = launch(ifn, dim3(plan.P, 1, p.B), dim3(kScatterThreads), lds_bytes, s, ia);
+    if (e != hipSuccess) return e;
+  }
   // channel groups: the slabs of one group fit the slab region
   const size_t per_channel = (size_t)p.B * plan.P * rb.slab_cells * 4;
   int group = (int)(slab_bytes / (per_channel ? per_channel : 1));
@@ -355,7 +387,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
   for (int ch0 = 0; ch0 < oc_total; ch0 += group) {
     const int oc = oc_total - ch0 < group ? oc_total - ch0 : group;
     sa.oc = oc; sa.ch0 = ch0;
-    e = launch(kfn, dim3(plan.P, oc, p.B), dim3(kScatterThreads), lds_bytes, s, sa);
+    e = launch(kfn, from_list ? dim3(oc, plan.P, p.B) : dim3(plan.P, oc, p.B), dim3(kScatterThreads), lds_bytes, s, sa);
     if (e != hipSuccess) return e;
     StripCombineArgs ca;
     ca.b0 = 0; ca.oc = oc; ca.ch0 = ch0; ca.oc_total = oc_total; ca.mh = p.mh; ca.mw = p.mw;
@@ -392,7 +424,7 @@ size_t strip_workspace_extra(const dm_params& p) {
     more_slabs = per_channel * (size_t)p.vc;
     if (more_slabs > ((size_t)2 << 30)) more_slabs = (size_t)2 << 30;
   }
-  return prepared_bytes(p) + 512 + more_slabs;
+  return prepared_bytes(p) + 512 + more_slabs + (wants_pixel_list(p) ? pixel_list_bytes(p) : 0);
 }
 
 namespace {
@@ -461,7 +493,7 @@ hipError_t launch_strips(const dm_params& p, const Plan& plan, const dm_frames_p
                          size_t ws_bytes, hipEvent_t after_projection, hipStream_t s) {
   const int oc_total = p.vc ? p.vc : p.dc;
   Layout l;
-  if (!carve(ws, ws_bytes, l)) return hipErrorNotSupported;
+  if (!carve(p, ws, ws_bytes, l)) return hipErrorNotSupported;
   const size_t hm = (height && value) ? up256((size_t)p.B * p.dc * p.mh * p.mw) : 0;
   if (l.slab_bytes < hm + (size_t)p.B * plan.P * fp.slab_cells * 4) return hipErrorNotSupported;
   const bool is_max = p.reduction == DM_REDUCE_MAX;
@@ -527,7 +559,7 @@ hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const floa
   const dm_frames_plan fp = plan_of(*plan, *rg);
   {   // would the rest fit?  (nothing may be enqueued before the answer is yes)
     Layout l;
-    if (!carve(static_cast<unsigned char*>(ws) + head, ws_bytes - head, l)) return hipErrorNotSupported;
+    if (!carve(p, static_cast<unsigned char*>(ws) + head, ws_bytes - head, l)) return hipErrorNotSupported;
     const size_t hm = (height && value) ? up256((size_t)p.B * p.dc * p.mh * p.mw) : 0;
     if (l.slab_bytes < hm + (size_t)p.B * plan->P * fp.slab_cells * 4) return hipErrorNotSupported;
   }

@@ -222,6 +222,7 @@ struct StripArgs {
   const int* g_flags;
   const strip::RowEntry* g_rows;
   const uint2* g_reach;
+  uint16_t* list;             // (B, P, H, wp) cells of the pixels inside their strips' windows (index / value pass)
 #ifdef DM_STAMPS
   long long* stamps;
 #endif
@@ -236,21 +237,39 @@ struct StripArgs {
 // a table in LDS, the fill duty is wave-level stores with scalar addressing, and a strip whose
 // window the map's borders did not clip (FrameGeom::inside) skips the window test -- every
 // pixel with a depth in range then lands inside the window by construction.
-template <int RED, bool HAS_VALID, bool HAS_VALUE, bool LEAN>
+//
+// MODE (value maps of many channels: one index computation per pixel, maps.py:314-350):
+//   kProject     the whole projection in one kernel (heights; value maps of few channels).
+//   kIndexOut    the index pass: no window, no fill, no flush -- every pixel's cell inside its
+//                strip's window (16 bits, 0xffff: rejected) goes to a list in the workspace.
+//   kFromList    the value pass, one workgroup per (strip, channel, frame): cells from the list,
+//                values from the channel's image -- 8 + 16 bytes per thread and row, four
+//                instructions per pixel instead of twenty, four rows in flight.
+enum { kProject = 0, kIndexOut = 1, kFromList = 2 };
+template <int RED, bool HAS_VALID, bool HAS_VALUE, bool LEAN, int MODE = kProject>
 __global__ void __launch_bounds__(kScatterThreads)
 k_strip_scatter(StripArgs a) {
   constexpr int VEC = 4;
+  static_assert(MODE != kFromList || HAS_VALUE, "the value pass scatters values");
+  static_assert(MODE != kIndexOut || !HAS_VALUE, "the index pass reads no values");
   // rows of a thread in flight per pipeline stage: value maps carry a second float4 per row and
   // spill at four (the kernel is capped at 128 VGPRs by its 1024 threads)
-  constexpr int kRowsInFlight = HAS_VALUE ? 2 : dm::kRowsInFlight;
+  constexpr int kRowsInFlight = (HAS_VALUE && MODE != kFromList) ? 2 : dm::kRowsInFlight;
   // Heights without a height test: the camera height is added when the window is flushed, not
   // per pixel.  x -> RN(x + c) is monotone, so max_i RN(h_i + c) = RN(max_i h_i + c) (min
   // alike): the window reduces the raw heights from the reduction's identity, and the flush
   // turns a cell into combine(fill, cell + cam_h) -- which is the fill value where nothing landed.
-  constexpr bool kDeferCamH = !HAS_VALUE && LEAN;
+  constexpr bool kDeferCamH = !HAS_VALUE && LEAN && MODE == kProject;
+#ifndef DM_X_FILL_VALUE
+#define DM_X_FILL_VALUE 2
+#endif
+  // fill steps (wave-level, 1 KB each) per pipeline half-iteration
+  constexpr int kStripFillPerHalf = HAS_VALUE ? DM_X_FILL_VALUE : 2;
   extern __shared__ float lds[];
-  const int part = blockIdx.x;                 // column strip
-  const int chl = blockIdx.y;                  // channel within this launch's group
+  // (the value pass runs channel-major: the workgroups of one (frame, strip) -- which read the same
+  // part of the pixel list -- are dispatched together)
+  const int part = MODE == kFromList ? blockIdx.y : blockIdx.x;   // column strip
+  const int chl = MODE == kFromList ? blockIdx.x : blockIdx.y;    // channel within this launch's group
   const int bl = blockIdx.z, b = a.b0 + bl;
   const int ch = a.ch0 + chl;
   const int dch = a.dc == 1 ? 0 : ch;
@@ -275,6 +294,9 @@ k_strip_scatter(StripArgs a) {
   const __amdgpu_buffer_rsrc_t rs_value = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(HAS_VALUE ? a.value + ((size_t)b * a.oc_total + ch) * N : a.value), 0,
       HAS_VALUE ? (unsigned)N * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_list = __builtin_amdgcn_make_buffer_rsrc(
+      a.list + (MODE != kProject ? ((size_t)b * nparts + part) * (size_t)a.H * a.wp : 0), 0,
+      MODE != kProject ? (unsigned)a.H * (unsigned)a.wp * 2u : 0u, 0x00020000);
   const float qnan = __builtin_nanf("");
   float za[kRowsInFlight][VEC], zb_[kRowsInFlight][VEC];
   float va[HAS_VALUE ? kRowsInFlight : 1][VEC], vb_[HAS_VALUE ? kRowsInFlight : 1][VEC];
@@ -286,9 +308,15 @@ k_strip_scatter(StripArgs a) {
       int rr = r + u * rows_per_iter;
       rr = rr < r1 ? rr : r1 - 1;              // tail rows repeat the last row (max / min: idempotent)
       const int at = rr * a.W + q;             // (pixel index inside the image)
-      const f32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_depth, at << 2, 0, 0);
-      z[u][0] = t.x; z[u][1] = t.y; z[u][2] = t.z; z[u][3] = t.w;
-      if (HAS_VALID) {                         // (four bools at once: q is a multiple of 4)
+      if (MODE == kFromList) {                 // four 16-bit cells instead of four depths
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(rs_list, (rr * a.wp + (q - q0)) << 1, 0, 0);
+        z[u][0] = __uint_as_float(c.x); z[u][1] = __uint_as_float(c.y);
+      } else {
+        const f32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_depth, at << 2, 0, 0);
+        z[u][0] = t.x; z[u][1] = t.y; z[u][2] = t.z; z[u][3] = t.w;
+      }
+      if (HAS_VALID && MODE != kFromList) {                         // (four bools at once: q is a multiple of 4)
         const unsigned ok4 = __builtin_amdgcn_raw_buffer_load_b32(rs_valid, at, 0, 0);
 #pragma unroll
         for (int k = 0; k < VEC; ++k)
@@ -337,8 +365,9 @@ k_strip_scatter(StripArgs a) {
   // The whole window region of LDS gets the fill value, the ray-slope table its H entries
   // (maps.py:670-678; border rows poisoned), under the first depth rows in flight.
   const float lds_init = kDeferCamH ? (RED == kMax ? -INFINITY : INFINITY) : a.fill;
-  for (int i = threadIdx.x * 4; i < a.slab_stride + 64; i += kScatterThreads * 4)
-    *reinterpret_cast<float4*>(lds + i) = make_float4(lds_init, lds_init, lds_init, lds_init);
+  if (MODE != kIndexOut)
+    for (int i = threadIdx.x * 4; i < a.slab_stride + 64; i += kScatterThreads * 4)
+      *reinterpret_cast<float4*>(lds + i) = make_float4(lds_init, lds_init, lds_init, lds_init);
   for (int r = threadIdx.x; r < a.H; r += kScatterThreads) {
     float yr = (float)r;
     yr = a.flip_h ? a.Hm1 - yr : yr;
@@ -466,8 +495,36 @@ k_strip_scatter(StripArgs a) {
       };
       auto project_rows = [&](auto tested, const float (&z)[kRowsInFlight][VEC],
                               const float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC],
-                              const float (&ayr)[kRowsInFlight]) {
+                              const float (&ayr)[kRowsInFlight], int r) {
         constexpr bool kTest = decltype(tested)::value;
+        if (MODE == kFromList) {
+#pragma unroll
+          for (int u = 0; u < kRowsInFlight; ++u) {
+            const unsigned c01 = __float_as_uint(z[u][0]), c23 = __float_as_uint(z[u][1]);
+            const unsigned cell[VEC] = {c01 & 0xffffu, c01 >> 16, c23 & 0xffffu, c23 >> 16};
+            unsigned li[VEC];
+            float hv[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+              const float sval = sv[u][k];
+              const bool ok = (cell[k] != 0xffffu) & (sval == sval);        // NaN never replaces a number
+              li[k] = ok ? lds_base + (cell[k] << 2) : dummy;
+              hv[k] = sval;
+            }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(li[0] == li[VEC - 1] && li[0] != dummy) != 0, 0)) {
+#pragma unroll
+              for (int k = 0; k + 1 < VEC; ++k) {
+                const bool same = li[k] == li[k + 1];
+                const float m = combine<RED>(hv[k], hv[k + 1]);
+                hv[k + 1] = same ? m : hv[k + 1];
+                li[k] = same ? dummy : li[k];
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) lds_reduce<RED>(lds_at(li[k]), hv[k]);
+          }
+          return;
+        }
 #ifdef DM_X_NOMATH
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u)
@@ -519,7 +576,16 @@ k_strip_scatter(StripArgs a) {
             unsigned addr = (unsigned)(((__mul24(iz, w.w) + ix) << 2) + origin);
             asm("" : "+v"(addr));
             li[k] = ok ? addr : dummy;
+            if (MODE == kIndexOut) li[k] = ok ? (addr - lds_base) >> 2 : 0xffffu;    // the cell inside the window
             hv[k] = sval;
+          }
+          if (MODE == kIndexOut) {
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            int rr = r + u * rows_per_iter;
+            rr = rr < r1 ? rr : r1 - 1;
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){li[0] | (li[1] << 16), li[2] | (li[3] << 16)}, rs_list,
+                                                  (rr * a.wp + (q - q0)) << 1, 0, 0);
+            continue;
           }
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(li[0] == li[VEC - 1] && li[0] != dummy) != 0, 0)) {
 #pragma unroll
@@ -536,7 +602,7 @@ k_strip_scatter(StripArgs a) {
       };
       const int niter = (r1 - r0 + step - 1) / step;
       // Two copies of the pipelined loop -- with and without the window test -- chosen by ONE
-      // wave-uniform branch: inside, exactly kFillPerHalf unconditional fill steps follow each
+      // wave-uniform branch: inside, exactly kStripFillPerHalf unconditional fill steps follow each
       // group of loads, so the waits count them and never wait on a store or on the prefetch.
       auto pipeline = [&](auto tested) {
         int r = r0 + gy;
@@ -574,8 +640,8 @@ k_strip_scatter(StripArgs a) {
           set_prio((cls + it) & 3);
 #endif
 #pragma unroll
-          for (int t = 0; t < kFillPerHalf; ++t) fill_step();
-          project_rows(tested, za, va, aya);
+          for (int t = 0; t < kStripFillPerHalf; ++t) fill_step();
+          project_rows(tested, za, va, aya, r);
           if (it + 1 < niter) {
             load_rows(za, va, r + 2 * step);
             load_ay(aya, r + 2 * step);
@@ -583,8 +649,8 @@ k_strip_scatter(StripArgs a) {
             set_prio((cls + it + 1) & 3);
 #endif
 #pragma unroll
-            for (int t = 0; t < kFillPerHalf; ++t) fill_step();
-            project_rows(tested, zb_, vb_, ayb);
+            for (int t = 0; t < kStripFillPerHalf; ++t) fill_step();
+            project_rows(tested, zb_, vb_, ayb, r + step);
             load_rows(zb_, vb_, r + 3 * step);        // (past the end: the last row again, unused)
             load_ay(ayb, r + 3 * step);
           }
@@ -606,7 +672,7 @@ k_strip_scatter(StripArgs a) {
   // Flush, 16 lanes per window row: the groups of this strip's cover go straight to the map where
   // the strip owns them (no other strip's cover reaches them), else to the slab: k_strip_combine
   // combines those with the other strips'.
-  if (area > 0) {
+  if (area > 0 && MODE != kIndexOut) {
     const int l16 = (int)threadIdx.x & 15;
     const int unit = b * a.oc + chl;             // (frame, channel): the P workgroups that share a map
     float* slab = a.slabs + ((size_t)unit * nparts + part) * a.slab_stride;

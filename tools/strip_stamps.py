@@ -22,18 +22,30 @@ if os.environ.get("DM_STAMPS_LEGACY"):
   _native.lib().dm_debug_force_legacy_window(1)
 if os.environ.get("DM_STAMPS_STRIPS"):
   _native.lib().dm_debug_force_strips(int(os.environ["DM_STAMPS_STRIPS"]))
+C = int(os.environ.get("DM_STAMPS_CHANNELS", "0"))
+value = None
+if C:      # value maps: the stamps then are those of the value pass (the kernel that runs last)
+  value = torch.nn.functional.one_hot(torch.randint(0, C, (B, H, W), generator=g), C).permute(0, 3, 1, 2).float().contiguous().cuda()
+  proj = dmap.MapProjector(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
+                           width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
+                           trunc_depth_min=0.15, trunc_depth_max=5.05, to_global=True, fill_value=0.0)
+  buf = torch.zeros(4096 * 12 * C + 4096 * 16 * C, dtype=torch.int64, device="cuda")
+  lib.dm_debug_strip_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+def run():
+  return proj.orth_project(depth, value_map=value, cam_pose=pose)
 for _ in range(5):
-  top, mask = proj.orth_project(depth, cam_pose=pose)
+  top, mask = run()
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 ev[0].record()
 for _ in range(20):
-  top, mask = proj.orth_project(depth, cam_pose=pose)
+  top, mask = run()
 ev[1].record(); torch.cuda.synchronize()
 print("orth_project call (pose upload + prepare + scatter + combine): %.1f us" % (ev[0].elapsed_time(ev[1]) * 50))
 allb = buf.cpu().numpy()
-raw = allb[:4096 * 12].reshape(-1, 12)
-waves = allb[4096 * 12:].reshape(-1, 16)[:(raw[:, 0] != 0).sum()]
+nwg = 256 * C if C else 4096       # (value maps: C <= 16, so that the workgroup stamps stay below the wave stamps)
+raw = allb[:nwg * 12].reshape(-1, 12)
+waves = allb[4096 * 12:4096 * 12 + 4096 * 16].reshape(-1, 16)[:(raw[:, 0] != 0).sum()] if not C else np.zeros((0, 16))
 raw = raw[raw[:, 0] != 0]
 st = raw[:, :7]
 def seg(name, i, j):
@@ -59,7 +71,7 @@ print("kernel span us: %.2f   start skew: %.2f   end skew: %.2f" % (
     (st[:, -1].max() - st[:, 0].min()) * 0.01, (st[:, 0].max() - st[:, 0].min()) * 0.01,
     (st[:, -1].max() - st[:, -1].min()) * 0.01))
 
-if waves.any():
+if waves.size and waves.any():
   rel = (waves - st[:, :1]) * 0.01            # each wave's loop end, relative to its workgroup's start
   print("loop end by wave index (mean us after WG start):", np.round(rel.mean(axis=0), 1))
   print("  first / last wave of a WG (median): %.2f / %.2f" % (np.median(rel.min(axis=1)), np.median(rel.max(axis=1))))
@@ -67,7 +79,7 @@ if waves.any():
 # where the slow workgroups are: pixel-loop time by strip, by XCD (workgroup id mod 8), by frame
 loop = (raw[:, 4] - raw[:, 11]) * 0.01
 wg = np.arange(len(loop))
-if len(loop) % 4 == 0 and not os.environ.get("DM_STAMPS_STRIPS"):
+if len(loop) % 4 == 0 and not os.environ.get("DM_STAMPS_STRIPS") and not C:
   print("pixel loop by strip:", np.round([loop[wg % 4 == s].mean() for s in range(4)], 2))
   print("pixel loop by XCD:  ", np.round([loop[wg % 8 == x].mean() for x in range(8)], 2))
   fr = loop.reshape(-1, 4).mean(axis=1)

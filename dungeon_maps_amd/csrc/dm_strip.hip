@@ -399,9 +399,15 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
     for (int b0 = 0; b0 < p.B; b0 += per_launch) {
       const int nb = p.B - b0 < per_launch ? p.B - b0 : per_launch;
       ca.b0 = b0;
-      const dim3 g(kCombineBlocks, (unsigned)(nb * oc));
-      e = is_max ? launch(k_strip_combine<kMax>, g, dim3(kCombineThreads), 0, s, ca)
-                 : launch(k_strip_combine<kMin>, g, dim3(kCombineThreads), 0, s, ca);
+      if (oc_total >= kListMinChannels) {
+        const dim3 g(kCombineSlots / 4, (unsigned)(nb * oc));
+        e = is_max ? launch(k_strip_combine<kMax, 4>, g, dim3(kCombineThreads), 0, s, ca)
+                   : launch(k_strip_combine<kMin, 4>, g, dim3(kCombineThreads), 0, s, ca);
+      } else {
+        const dim3 g(kCombineSlots, (unsigned)(nb * oc));
+        e = is_max ? launch(k_strip_combine_one<kMax>, g, dim3(kCombineThreads), 0, s, ca)
+                   : launch(k_strip_combine_one<kMin>, g, dim3(kCombineThreads), 0, s, ca);
+      }
       if (e != hipSuccess) return e;
     }
   }

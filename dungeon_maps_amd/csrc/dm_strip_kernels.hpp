@@ -717,15 +717,22 @@ struct StripCombineArgs {
 };
 
 constexpr int kCombineThreads = 256;
-constexpr int kCombineBlocks = 16;             // per (frame, channel); the threads stride over the list
+// A (frame, channel) gets kCombineSlots / ENTRIES blocks whose threads take ENTRIES list entries at a
+// time (their slab loads in flight together) and stride over the list.  One entry per thread for
+// height maps (a handful of blocks per frame: the kernel is one chain of round trips, 6 us at
+// cfg2), four for value maps of many channels (the chip holds 2 K blocks at a time: with one
+// entry per thread 40 channels were twenty rounds of that chain, 200 us; with four, 80 us).
+constexpr int kCombineSlots = 16;
 
 // The groups of a frame's reach spans that no strip owns (the frame's shared-group list,
 // k_strip_prepare): max / min over the slabs of the strips whose covers hold the group -- the fill
-// value where none does -- written to the map with its mask bytes.  One list entry per thread;
+// value where none does -- written to the map with its mask bytes.  kCombineEntries list entries per thread at a time;
 // what a block needs of the frame (count, union window, the strips' windows) is wave-uniform.
+// One list entry per thread (height maps).
 template <int RED>
 __global__ void __launch_bounds__(kCombineThreads)
-k_strip_combine(StripCombineArgs a) {
+k_strip_combine_one(StripCombineArgs a) {
+  constexpr int kCombineBlocks = kCombineSlots;
   const int fcl = blockIdx.y;                  // (frame of the launch) * oc + channel of the group
   const int bl = fcl / a.oc, b = a.b0 + bl;
   const int chl = fcl - bl * a.oc;
@@ -768,6 +775,91 @@ k_strip_combine(StripCombineArgs a) {
     *reinterpret_cast<uint32_t*>(a.mask + cell) =
         (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
         ((uint32_t)mask_of(acc.z, a.fill) << 16) | ((uint32_t)mask_of(acc.w, a.fill) << 24);
+  }
+}
+
+// kCombineEntries list entries per thread at a time (value maps of many channels).
+template <int RED, int kCombineEntries>
+__global__ void __launch_bounds__(kCombineThreads)
+k_strip_combine(StripCombineArgs a) {
+  constexpr int kCombineBlocks = kCombineSlots / kCombineEntries;
+  const int fcl = blockIdx.y;                  // (frame of the launch) * oc + channel of the group
+  const int bl = fcl / a.oc, b = a.b0 + bl;
+  const int chl = fcl - bl * a.oc;
+  constexpr int kStride = kCombineBlocks * kCombineThreads;
+  const int first = blockIdx.x * kCombineThreads + (int)threadIdx.x;
+  const uint32_t* const list = a.g_list + (size_t)b * a.list_cap;
+  // (the thread's first entries are requested before the list's length is known: one round trip
+  // less in a kernel that is nothing but a chain of them)
+  uint32_t ent[kCombineEntries];
+#pragma unroll
+  for (int k = 0; k < kCombineEntries; ++k) ent[k] = first + k * kStride < a.list_cap ? list[first + k * kStride] : 0u;
+  const int listed = min(a.g_counts[b], a.list_cap);
+  if (blockIdx.x * kCombineThreads >= listed) return;
+  const int2 u_raw = *reinterpret_cast<const int2*>(a.g_unions + b);
+  const int ux0 = (short)(u_raw.x & 0xffff), uz0 = (short)(u_raw.x >> 16);
+  int2 wq[strip::kMaxStrips];
+#pragma unroll
+  for (int q = 0; q < strip::kMaxStrips; ++q)
+    wq[q] = *reinterpret_cast<const int2*>(a.g_wins + (size_t)b * strip::kMaxStrips + (q < a.P ? q : 0));
+  const float* const slabs = a.slabs + ((size_t)(b * a.oc + chl) * a.P) * a.slab_stride;
+  const size_t fo = ((size_t)b * a.oc_total + a.ch0 + chl) * (size_t)a.mh * a.mw;
+  const float ident = RED == kMax ? -INFINITY : INFINITY;
+  for (int base = first; base < listed; base += kCombineEntries * kStride) {
+    if (base != first) {
+#pragma unroll
+      for (int k = 0; k < kCombineEntries; ++k) ent[k] = base + k * kStride < listed ? list[base + k * kStride] : 0u;
+    }
+    // where each group lies in the slabs of the (usually two) strips whose covers hold it; the
+    // slab loads of all of the thread's entries are in flight together.  Further strips (around
+    // the camera's cell) take the slow lane.
+    int z[kCombineEntries], x[kCombineEntries];
+    uint32_t more[kCombineEntries];
+    float4 ta[kCombineEntries], tb[kCombineEntries];
+    bool has_a[kCombineEntries], has_b[kCombineEntries];
+    auto slab_offset = [&](int k, int q) {
+      const int wx0 = (short)(wq[q].x & 0xffff), wz0 = (short)(wq[q].x >> 16), ww = (short)(wq[q].y & 0xffff);
+      return q * a.slab_stride + (z[k] - wz0) * ww + (x[k] - wx0);
+    };
+#pragma unroll
+    for (int k = 0; k < kCombineEntries; ++k) {
+      const bool live = base + k * kStride < listed;
+      const uint32_t hits = live ? ent[k] >> 24 : 0u;          // (never set for strips >= P)
+      z[k] = uz0 + (int)(ent[k] & 0xfffu); x[k] = ux0 + (int)(((ent[k] >> 12) & 0xfffu) << 2);
+      int off_a = 0, off_b = 0;
+      has_a[k] = false; has_b[k] = false; more[k] = 0;
+#pragma unroll
+      for (int q = 0; q < strip::kMaxStrips; ++q) {
+        const bool hit = ((hits >> q) & 1u) != 0u;
+        const int o = slab_offset(k, q);
+        const bool first_hit = hit & !has_a[k], second_hit = hit & !first_hit & !has_b[k];
+        more[k] |= (hit & !first_hit & !second_hit) ? 1u << q : 0u;
+        off_a = first_hit ? o : off_a; has_a[k] = has_a[k] | first_hit;
+        off_b = second_hit ? o : off_b; has_b[k] = has_b[k] | second_hit;
+      }
+      ta[k] = *reinterpret_cast<const float4*>(slabs + off_a);     // (offset 0 when there is no hit: discarded)
+      tb[k] = *reinterpret_cast<const float4*>(slabs + off_b);
+    }
+#pragma unroll
+    for (int k = 0; k < kCombineEntries; ++k) {
+      if (base + k * kStride >= listed) continue;
+      // (the fill value takes part: utils.py:470-477 reduces INTO the filled canvas)
+      float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+      if (has_a[k]) { acc.x = combine<RED>(acc.x, ta[k].x); acc.y = combine<RED>(acc.y, ta[k].y);
+                      acc.z = combine<RED>(acc.z, ta[k].z); acc.w = combine<RED>(acc.w, ta[k].w); }
+      if (has_b[k]) { acc.x = combine<RED>(acc.x, tb[k].x); acc.y = combine<RED>(acc.y, tb[k].y);
+                      acc.z = combine<RED>(acc.z, tb[k].z); acc.w = combine<RED>(acc.w, tb[k].w); }
+      for (uint32_t m = more[k]; m != 0; m &= m - 1) {
+        const float4 t = *reinterpret_cast<const float4*>(slabs + slab_offset(k, __builtin_ctz(m)));
+        acc.x = combine<RED>(acc.x, t.x); acc.y = combine<RED>(acc.y, t.y);
+        acc.z = combine<RED>(acc.z, t.z); acc.w = combine<RED>(acc.w, t.w);
+      }
+      const size_t cell = fo + (size_t)z[k] * a.mw + x[k];
+      *reinterpret_cast<float4*>(a.out + cell) = acc;
+      *reinterpret_cast<uint32_t*>(a.mask + cell) =
+          (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+          ((uint32_t)mask_of(acc.z, a.fill) << 16) | ((uint32_t)mask_of(acc.w, a.fill) << 24);
+    }
   }
 }
 

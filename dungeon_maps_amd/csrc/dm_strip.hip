@@ -345,6 +345,16 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
   sa.hmax = p.has_hmax ? p.hmax : INFINITY;
   sa.Hm1 = (float)(p.H - 1); sa.mhm1 = (float)(p.mh - 1);
   sa.wp = plan.wp; sa.P = plan.P;
+  // small batches: fill-only workgroups beside the strips', so that (frames x channels x workgroups)
+  // reaches the chip's 256 CUs and the fill duty -- most of the bytes of a large, mostly empty map --
+  // is spread over all of them (16 x 1280x960 -> 2048^2: 8 strips + 8)
+  {
+    const long units = (long)p.B * oc_total;
+    long f = (256 + units - 1) / units;
+    if (f > 4 * plan.P) f = 4 * plan.P;
+    if (f > p.mh / 16) f = p.mh / 16;
+    sa.fill_parts = f > plan.P ? (int)f : plan.P;
+  }
   sa.dc = p.dc; sa.valid_c = p.valid_c;
   sa.oc_total = oc_total;
   sa.slab_stride = rb.slab_cells;
@@ -375,6 +385,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
     if (e != hipSuccess) return e;
     StripArgs ia = sa;
     ia.value = nullptr; ia.out = nullptr; ia.mask = nullptr; ia.oc = 1; ia.ch0 = 0; ia.oc_total = 1;
+    ia.fill_parts = plan.P;
     e = launch(ifn, dim3(plan.P, 1, p.B), dim3(kScatterThreads), lds_bytes, s, ia);
     if (e != hipSuccess) return e;
   }
@@ -387,7 +398,8 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
   for (int ch0 = 0; ch0 < oc_total; ch0 += group) {
     const int oc = oc_total - ch0 < group ? oc_total - ch0 : group;
     sa.oc = oc; sa.ch0 = ch0;
-    e = launch(kfn, from_list ? dim3(oc, plan.P, p.B) : dim3(plan.P, oc, p.B), dim3(kScatterThreads), lds_bytes, s, sa);
+    e = launch(kfn, from_list ? dim3(oc, sa.fill_parts, p.B) : dim3(sa.fill_parts, oc, p.B), dim3(kScatterThreads),
+               lds_bytes, s, sa);
     if (e != hipSuccess) return e;
     StripCombineArgs ca;
     ca.b0 = 0; ca.oc = oc; ca.ch0 = ch0; ca.oc_total = oc_total; ca.mh = p.mh; ca.mw = p.mw;

@@ -203,6 +203,8 @@ struct StripArgs {
   float dmin, dmax, hmax;
   float Hm1, mhm1;
   int wp, P;
+  int fill_parts;             // workgroups per (frame, channel) that share the fill duty: the P strips' plus
+                              // fill-only ones (small batches: more workgroups than strips to fill the chip)
   int dc, valid_c;
   int oc, ch0, oc_total;      // channels of this launch's group / first channel / channels of out
   int slab_stride;            // cells per slab = cells of the LDS window region
@@ -274,6 +276,10 @@ k_strip_scatter(StripArgs a) {
   const int ch = a.ch0 + chl;
   const int dch = a.dc == 1 ? 0 : ch;
   const int nparts = a.P;
+  // a fill-only workgroup (part >= P) has no pixels and no window: its strip lies past the image's
+  // right edge (nx = 0 below), its window is empty, the tables are read as strip 0's and not used
+  const bool fill_only = part >= nparts;
+  const int tpart = fill_only ? 0 : part;
   // the strip's pixel rectangle and the first depth rows: kernel arguments only
   const int q0 = part * a.wp;
   int q1 = q0 + a.wp; if (q1 > a.W) q1 = a.W;
@@ -295,7 +301,7 @@ k_strip_scatter(StripArgs a) {
       const_cast<float*>(HAS_VALUE ? a.value + ((size_t)b * a.oc_total + ch) * N : a.value), 0,
       HAS_VALUE ? (unsigned)N * 4u : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_list = __builtin_amdgcn_make_buffer_rsrc(
-      a.list + (MODE != kProject ? ((size_t)b * nparts + part) * (size_t)a.H * a.wp : 0), 0,
+      a.list + (MODE != kProject ? ((size_t)b * nparts + tpart) * (size_t)a.H * a.wp : 0), 0,
       MODE != kProject ? (unsigned)a.H * (unsigned)a.wp * 2u : 0u, 0x00020000);
   const float qnan = __builtin_nanf("");
   float za[kRowsInFlight][VEC], zb_[kRowsInFlight][VEC];
@@ -346,10 +352,10 @@ k_strip_scatter(StripArgs a) {
   strip::RowEntry row_e = {0u, 0u};
   uint2 reach_e = make_uint2(0u, 0u);
   if ((int)threadIdx.x < a.max_rows) {
-    row_e = a.g_rows[((size_t)b * a.max_rows + threadIdx.x) * nparts + part];
+    row_e = a.g_rows[((size_t)b * a.max_rows + threadIdx.x) * nparts + tpart];
     reach_e = a.g_reach[(size_t)b * a.max_rows + threadIdx.x];
   }
-  const int2 w_raw = *reinterpret_cast<const int2*>(a.g_wins + (size_t)b * strip::kMaxStrips + part);
+  const int2 w_raw = *reinterpret_cast<const int2*>(a.g_wins + (size_t)b * strip::kMaxStrips + tpart);
   const int2 u_raw = *reinterpret_cast<const int2*>(a.g_unions + b);
   int flags = a.g_flags[b];
 #ifdef DM_STAMPS
@@ -384,7 +390,7 @@ k_strip_scatter(StripArgs a) {
   {
     // wave-uniform values: keep them in SGPRs
     w.x0 = __builtin_amdgcn_readfirstlane(w.x0); w.z0 = __builtin_amdgcn_readfirstlane(w.z0);
-    w.w = __builtin_amdgcn_readfirstlane(w.w); w.h = __builtin_amdgcn_readfirstlane(w.h);
+    w.w = __builtin_amdgcn_readfirstlane(fill_only ? 0 : w.w); w.h = __builtin_amdgcn_readfirstlane(w.h);   // (fill-only: no window)
     U.x0 = __builtin_amdgcn_readfirstlane(U.x0); U.z0 = __builtin_amdgcn_readfirstlane(U.z0);
     U.w = __builtin_amdgcn_readfirstlane(U.w); U.h = __builtin_amdgcn_readfirstlane(U.h);
     flags = __builtin_amdgcn_readfirstlane(flags);
@@ -393,14 +399,14 @@ k_strip_scatter(StripArgs a) {
   // the row tables -> LDS (rows past the union window's height hold whatever the table does: never used)
   if ((int)threadIdx.x < a.max_rows) { rows[threadIdx.x] = row_e; reach[threadIdx.x] = reach_e; }
   for (int r = threadIdx.x + kScatterThreads; r < U.h; r += kScatterThreads) {
-    rows[r] = a.g_rows[((size_t)b * a.max_rows + r) * nparts + part];
+    rows[r] = a.g_rows[((size_t)b * a.max_rows + r) * nparts + tpart];
     reach[r] = a.g_reach[(size_t)b * a.max_rows + r];
   }
   lds_barrier();
   DM_STAMP(2);
   DM_STAMP(3);
-  // Fill duty: map rows part, part + P, ... of (b, ch) outside the rows' reach spans (the hull of
-  // the strips' covers: inside it the flush below and the combine step write).  Wave-level: wave v takes the rows part + (v + 16 j) P,
+  // Fill duty: map rows part, part + F, ... (F = fill_parts) of (b, ch) outside the rows' reach spans (the hull of
+  // the strips' covers: inside it the flush below and the combine step write).  Wave-level: wave v takes the rows part + (v + 16 j) F,
   // one step stores 256 cells of a row (float4 per lane) and their mask bytes with SCALAR
   // addressing -- the map of this (frame, channel) as a raw buffer resource, the row and chunk
   // in the scalar offset, the lane's fixed 16 / 4 bytes in the vector offset.  A lane that has
@@ -408,7 +414,8 @@ k_strip_scatter(StripArgs a) {
   // past the end of the buffer and is dropped by the hardware's range check: no branch in the
   // loop, a handful of VALU instructions per KB.
   const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
-  const int fill_rows = (a.mh - part + nparts - 1) / nparts;
+  const int fparts = a.fill_parts;
+  const int fill_rows = (a.mh - part + fparts - 1) / fparts;
   const int chunks = (a.mw + 255) >> 8;
   const int fill_steps = a.out != nullptr && wave < fill_rows ? ((fill_rows - wave + 15) >> 4) * chunks : 0;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -419,7 +426,7 @@ k_strip_scatter(StripArgs a) {
       __builtin_amdgcn_make_buffer_rsrc(a.mask + map_base, 0, a.out ? map_cells : 0u, 0x00020000);
   const unsigned fill_bits = __float_as_uint(a.fill);
   const int lane4 = lane << 2;
-  int fs = 0, f_row = part + wave * nparts, f_chunk = 0;       // (wave-uniform)
+  int fs = 0, f_row = part + wave * fparts, f_chunk = 0;       // (wave-uniform)
   // the reach of a map row ({0, 0} outside U's rows), read from LDS TWO steps ahead: the steps
   // come in pairs, and a value read one step ahead would make the second step of a pair wait
   // for every LDS operation in flight (one counter), the pixel loop's atomics among them
@@ -432,7 +439,7 @@ k_strip_scatter(StripArgs a) {
   auto advance = [&](int& row, int& chunk) {
     const bool next_row = chunk + 1 == chunks;
     chunk = next_row ? 0 : chunk + 1;
-    row += next_row ? 16 * nparts : 0;
+    row += next_row ? 16 * fparts : 0;
   };
   int f_row2 = f_row, f_chunk2 = f_chunk;      // where the fill duty is two steps from now
   uint2 f_reach = reach_of(f_row2);

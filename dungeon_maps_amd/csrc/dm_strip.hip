@@ -17,6 +17,13 @@
 #include "dm_kernels.hpp"
 #include "dm_strip_kernels.hpp"
 
+// Workgroups per launch the strip path aims at by adding fill-only workgroups (0: none).  Measured
+// at 16 x 1280x960 -> 2048^2 (8 strips per frame): 8 + 8 workgroups per frame 120 us, 8 + 24: 142 us,
+// against 97-108 us on the window path with its row blocks -- so off, and such shapes stay there.
+#ifndef DM_X_FILL_TARGET
+#define DM_X_FILL_TARGET 0
+#endif
+
 namespace dm {
 
 void note_split(int pc, int pr, int pd, int path);     // dm_window.hip (dm_debug_last_split)
@@ -345,12 +352,10 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
   sa.hmax = p.has_hmax ? p.hmax : INFINITY;
   sa.Hm1 = (float)(p.H - 1); sa.mhm1 = (float)(p.mh - 1);
   sa.wp = plan.wp; sa.P = plan.P;
-  // small batches: fill-only workgroups beside the strips', so that (frames x channels x workgroups)
-  // reaches the chip's 256 CUs and the fill duty -- most of the bytes of a large, mostly empty map --
-  // is spread over all of them (16 x 1280x960 -> 2048^2: 8 strips + 8)
+  // (experiment, off: fill-only workgroups beside the strips' for small batches, DM_X_FILL_TARGET)
   {
     const long units = (long)p.B * oc_total;
-    long f = (256 + units - 1) / units;
+    long f = (DM_X_FILL_TARGET + units - 1) / units;
     if (f > 4 * plan.P) f = 4 * plan.P;
     if (f > p.mh / 16) f = p.mh / 16;
     sa.fill_parts = f > plan.P ? (int)f : plan.P;

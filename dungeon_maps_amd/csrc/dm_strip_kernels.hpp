@@ -90,9 +90,12 @@ struct StripPrepArgs {
   int* status;                // set non-zero when a frame's geometry does not fit the launch plan
 };
 
-constexpr int kPrepThreads = 256;
+constexpr int kPrepThreads = 1024;
+constexpr int kPrepLanes = 16;                 // lanes per row of the union window (>= kMaxStrips)
+static_assert(kPrepLanes >= strip::kMaxStrips, "one lane per strip");
+static_assert(4096 >= kListMaxGroups, "a row's groups fit the LDS list");
 constexpr int kPrepSlices = 4;                 // workgroups per frame, each a band of the union window's rows
-constexpr int kPrepListLds = 2048;             // list entries a workgroup collects in LDS before it appends them
+constexpr int kPrepListLds = 4096;             // list entries a workgroup collects in LDS before it appends them (>= the groups of a row)
 
 // kPrepSlices workgroups per frame: the frame's geometry (wave 0 of each) and, for the
 // workgroup's band of rows of the union window, the row table -- cover and owned span of every
@@ -147,47 +150,56 @@ k_strip_prepare(StripPrepArgs a) {
     if (threadIdx.x == 0) listed = 0;
     __syncthreads();
   };
-  const int P2 = nparts <= 4 ? 4 : 8;
-  const int sub = (int)threadIdx.x & (P2 - 1);
-  const int per_pass = kPrepThreads / P2;
+  // kPrepLanes lanes per row: the first P of them derive the strips' covers (exchanged by
+  // shuffles: owned spans, the hull), then all of them walk the hull's groups
+  const int sub = (int)threadIdx.x & (kPrepLanes - 1);
+  const int lane0 = (int)threadIdx.x & 63 & ~(kPrepLanes - 1);
+  // rows per pass: as many as the block has lanes for, and no more than fit the LDS list whatever they hold
+  const int groups_per_row = max(U.w >> 2, 1);
+  const int per_pass = min(kPrepThreads / kPrepLanes, max(kPrepListLds / groups_per_row, 1));
   const int band = (U.h + kPrepSlices - 1) / kPrepSlices;
   const int r_end = min(U.h, (slice + 1) * band);
   for (int r0 = slice * band; r0 < r_end; r0 += per_pass) {      // (uniform trip count: append() has barriers)
-    const int r = r0 + (int)threadIdx.x / P2;
-    if (r < r_end) {
+    const int r = r0 + (int)threadIdx.x / kPrepLanes;
+    if ((int)threadIdx.x / kPrepLanes < per_pass && r < r_end) {
       const int ps = sub < nparts ? sub : 0;
       uint32_t cover = strip::row_cover(geom.win[ps], geom.L[ps], geom.R[ps], U.z0 + r, a.mw);
       cover = sub < nparts ? cover : 0u;
-      int lo = (int)(cover & 0xffffu), hi = (int)(cover >> 16);
-      int rlo = cover ? (int)(cover & 0xffffu) : 32767, rhi = (int)(cover >> 16);
-      for (int m = 1; m < P2; ++m) {
-        const uint32_t other = (uint32_t)__shfl_xor((int)cover, m, 64);
-        strip::cut_span(lo, hi, other);
-        rlo = min(rlo, other ? (int)(other & 0xffffu) : 32767); rhi = max(rhi, (int)(other >> 16));
+      uint32_t cov[strip::kMaxStrips], own[strip::kMaxStrips];
+#pragma unroll
+      for (int q = 0; q < strip::kMaxStrips; ++q) cov[q] = (uint32_t)__shfl((int)cover, lane0 + q, 64);
+      int rlo = 32767, rhi = 0;
+#pragma unroll
+      for (int q = 0; q < strip::kMaxStrips; ++q) {
+        rlo = min(rlo, cov[q] ? (int)(cov[q] & 0xffffu) : 32767); rhi = max(rhi, (int)(cov[q] >> 16));
       }
-      const uint32_t owned = hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
+      // the owned span of strip `sub`: its cover cut by the others' in the order sub ^ 1, sub ^ 2, ...
+      // (strip::row_owned, the host's version)
+      const int P2 = nparts <= 4 ? 4 : 8;
+      int lo = (int)(cover & 0xffffu), hi = (int)(cover >> 16);
+#pragma unroll
+      for (int m = 1; m < strip::kMaxStrips; ++m) {
+        const uint32_t other = (uint32_t)__shfl((int)cover, lane0 + ((sub ^ m) & (strip::kMaxStrips - 1)), 64);
+        if (m < P2 && (sub ^ m) < nparts) strip::cut_span(lo, hi, other);
+      }
+      const uint32_t owned = (sub < nparts && hi > lo) ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
       if (sub < nparts) a.t.rows[((size_t)b * a.max_rows + r) * nparts + sub] = strip::RowEntry{cover, owned};
       if (sub == 0) a.t.reach[(size_t)b * a.max_rows + r] = rhi > rlo ? make_uint2((unsigned)rlo, (unsigned)(rhi - rlo)) : make_uint2(0u, 0u);
-      // the groups of [rlo, rhi) nobody owns: the P2 lanes of the row take every P2-th group
-      uint32_t cov[8], own[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        cov[q] = (uint32_t)__shfl((int)cover, ((int)threadIdx.x & 63 & ~(P2 - 1)) + (q & (P2 - 1)), 64);
-        own[q] = (uint32_t)__shfl((int)owned, ((int)threadIdx.x & 63 & ~(P2 - 1)) + (q & (P2 - 1)), 64);
-        if (q >= P2) { cov[q] = 0u; own[q] = 0u; }
-      }
-      for (int x = rlo + 4 * sub; x < rhi; x += 4 * P2) {
+      for (int q = 0; q < strip::kMaxStrips; ++q) own[q] = (uint32_t)__shfl((int)owned, lane0 + q, 64);
+      // the groups of [rlo, rhi) nobody owns: the row's lanes take every kPrepLanes-th group
+      for (int x = rlo + 4 * sub; x < rhi; x += 4 * kPrepLanes) {
         uint32_t hits = 0;
         bool mine = false;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < strip::kMaxStrips; ++q) {
           hits |= strip::in_span(cov[q], x) ? 1u << q : 0u;
           mine = mine | strip::in_span(own[q], x);
         }
         if (!mine) {
           const int at = atomicAdd(&listed, 1);
           if (at < kPrepListLds) found[at] = pack_shared(r, (x - U.x0) >> 2, hits);
-          else atomicOr(a.status, 2);         // (a pass of 64 rows with more than 2048 shared groups)
+          else atomicOr(a.status, 2);         // (a pass of rows with more than kPrepListLds shared groups)
         }
       }
     }

@@ -85,6 +85,7 @@ _SIGNATURES = {
     "dm_debug_last_path": (ctypes.c_int, []),
     "dm_debug_force_legacy_window": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_force_strips": (ctypes.c_int, [ctypes.c_int]),
+    "dm_debug_strip_value_list": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_strip_geometry": (ctypes.c_int, [
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dm_debug_strip_geometry_dev": (ctypes.c_int, [

@@ -242,7 +242,9 @@ StripKernel pick_value_kernel(bool is_max) {
 inline size_t pixel_list_bytes(const dm_params& p) {     // (B, P, H, wp) uint16: P * wp <= W + 32 per strip
   return up256((size_t)p.B * p.H * ((size_t)p.W + 32 * strip::kMaxStrips) * 2);
 }
-inline bool wants_pixel_list(const dm_params& p) { return p.vc >= kListMinChannels && p.dc == 1; }
+thread_local int g_no_value_list = 0;      // dm_debug_strip_value_list(0): every channel recomputes its cells
+inline bool list_shape(const dm_params& p) { return p.vc >= kListMinChannels && p.dc == 1; }   // (sizes the workspace)
+inline bool wants_pixel_list(const dm_params& p) { return list_shape(p) && !g_no_value_list; }
 
 // Device copy of a batch's camera state as the kernels read it ("prepared frames"):
 // [Cfg (kCfgBytes) | status word (256 B) | list counters | frame records | frame tables].
@@ -306,7 +308,7 @@ struct Layout {               // workspace of the strip path
 bool carve(const dm_params& p, void* ws, size_t ws_bytes, Layout& l) {
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return false;
   ws_bytes = ws_bytes / 256 * 256;
-  const size_t lb = wants_pixel_list(p) ? pixel_list_bytes(p) : 0;
+  const size_t lb = list_shape(p) ? pixel_list_bytes(p) : 0;
   if (ws_bytes < 512 + lb) return false;
   l.slabs = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + 256);
   l.slab_bytes = ws_bytes - 256 - lb;
@@ -416,7 +418,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
     for (int b0 = 0; b0 < p.B; b0 += per_launch) {
       const int nb = p.B - b0 < per_launch ? p.B - b0 : per_launch;
       ca.b0 = b0;
-      if (oc_total >= kListMinChannels) {
+      if (oc_total >= kListMinChannels) {        // (value maps of many channels: four entries per thread)
         const dim3 g(kCombineSlots / 4, (unsigned)(nb * oc));
         e = is_max ? launch(k_strip_combine<kMax, 4>, g, dim3(kCombineThreads), 0, s, ca)
                    : launch(k_strip_combine<kMin, 4>, g, dim3(kCombineThreads), 0, s, ca);
@@ -447,7 +449,7 @@ size_t strip_workspace_extra(const dm_params& p) {
     more_slabs = per_channel * (size_t)p.vc;
     if (more_slabs > ((size_t)2 << 30)) more_slabs = (size_t)2 << 30;
   }
-  return prepared_bytes(p) + 512 + more_slabs + (wants_pixel_list(p) ? pixel_list_bytes(p) : 0);
+  return prepared_bytes(p) + 512 + more_slabs + (list_shape(p) ? pixel_list_bytes(p) : 0);
 }
 
 namespace {
@@ -643,6 +645,12 @@ hipError_t run_strip_prepared(const dm_params& p, const dm_frames_plan& fp, void
 extern "C" __attribute__((visibility("default"))) int dm_debug_force_strips(int strips) {
   const int old = dm::g_force_strips;
   dm::g_force_strips = strips > 0 && strips <= dm::strip::kMaxStrips ? strips : 0;
+  return old;
+}
+
+extern "C" __attribute__((visibility("default"))) int dm_debug_strip_value_list(int on) {
+  const int old = !dm::g_no_value_list;
+  dm::g_no_value_list = on == 0;
   return old;
 }
 

@@ -337,6 +337,10 @@ int dm_debug_force_bands(int on);
  *                                column strips whatever the cost model says (0 = back to the
  *                                model); returns the previous setting.  Lets the tests run the
  *                                strip path on small images.
+ *   dm_debug_strip_value_list    0: value maps of three channels or more recompute every pixel's cell
+ *                                per channel on the strip path of the calling thread, instead of
+ *                                taking it from the list the index pass leaves (non-zero, the
+ *                                default); returns the previous setting.  Same results.
  *   dm_debug_strip_geometry      host only (no GPU needed): the strip path's geometry for `p` and
  *                                the given frames exactly as the kernels derive it.
  *                                out_geom (B, 8 + 4*8) int32 per frame: {ok | inside << 8 (bit s of
@@ -357,6 +361,7 @@ int dm_debug_force_bands(int on);
 int dm_debug_last_path(void);
 int dm_debug_force_legacy_window(int on);
 int dm_debug_force_strips(int strips);
+int dm_debug_strip_value_list(int on);
 int dm_debug_strip_geometry(const dm_params* p, const dm_frame* frames, int32_t* out_geom,
                             uint32_t* out_covers, int32_t* out_bound);
 int dm_debug_strip_geometry_dev(const dm_params* p, const dm_frame* frames_host,

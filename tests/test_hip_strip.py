@@ -79,11 +79,14 @@ def _projector(dmap, cfg):
   return dmap.MapProjector(**{k: v for k, v in cfg.items()})
 
 
+_LISTED = []      # calls per seed that took the value-list path (checked by the test below)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_strip_path_equals_oracle_and_other_paths(dmap, oracle, seed):
   lib = _lib()
   rng = np.random.default_rng(4000 + seed)
-  ran = 0
+  ran = listed = 0
   for it in range(14):
     B, H, W, depth, pose, cfg = _case(rng, big_offsets=(it % 5 == 4))
     if W % 4:
@@ -92,6 +95,7 @@ def test_strip_path_equals_oracle_and_other_paths(dmap, oracle, seed):
     if it % 3 == 1:
       C = int(rng.integers(2, 6))
       value = rng.uniform(-1, 2, size=(B, C, H, W)).astype(np.float32)
+      value.reshape(-1)[rng.integers(0, value.size, 200)] = np.nan     # (a NaN never replaces a number)
       cfg["fill_value"] = 0.0 if it % 2 else -np.inf
     if it % 4 == 2:
       valid = rng.uniform(0, 1, size=(B, 1, H, W)) > 0.2
@@ -128,7 +132,24 @@ def test_strip_path_equals_oracle_and_other_paths(dmap, oracle, seed):
     finally:
       lib.dm_debug_force_legacy_window(0)
     assert torch.equal(legacy[0], got[0]) and torch.equal(legacy[1], got[1])
+    if v is not None and v.shape[1] >= 3:
+      # value maps of three channels or more took the index pass + value pass; the same call with
+      # every channel recomputing its cells must give the same maps
+      lib.dm_debug_force_strips(strips); lib.dm_debug_strip_value_list(0)
+      try:
+        again = proj.orth_project(d, value_map=v, valid_map=m, cam_pose=pose, get_height_map=True)
+        assert lib.dm_debug_last_path() == 2
+      finally:
+        lib.dm_debug_force_strips(0); lib.dm_debug_strip_value_list(1)
+      for a_, b_ in zip(again, got):
+        assert torch.equal(a_, b_, ) or bool(((a_ == b_) | (a_.isnan() & b_.isnan())).all())
+      listed += 1
   assert ran >= 6
+  _LISTED.append(listed)
+
+
+def test_value_list_path_was_exercised():
+  assert sum(_LISTED) >= 4, _LISTED
 
 
 def test_cfg2_full_size_strip_path_vs_oracle(dmap, oracle):

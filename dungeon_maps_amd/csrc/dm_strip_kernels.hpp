@@ -274,11 +274,10 @@ k_strip_scatter(StripArgs a) {
   // alike): the window reduces the raw heights from the reduction's identity, and the flush
   // turns a cell into combine(fill, cell + cam_h) -- which is the fill value where nothing landed.
   constexpr bool kDeferCamH = !HAS_VALUE && LEAN && MODE == kProject;
-#ifndef DM_X_FILL_VALUE
-#define DM_X_FILL_VALUE 2
-#endif
-  // fill steps (wave-level, 1 KB each) per pipeline half-iteration
-  constexpr int kStripFillPerHalf = HAS_VALUE ? DM_X_FILL_VALUE : 2;
+  // fill steps (wave-level, 1 KB each) per pipeline half-iteration: three or four make every wait for
+  // the depth loads wait for older stores too (+2 us per extra step at cfg2), none or one moves
+  // the stores behind the loop for the same total
+  constexpr int kStripFillPerHalf = 2;
   extern __shared__ float lds[];
   // (the value pass runs channel-major: the workgroups of one (frame, strip) -- which read the same
   // part of the pixel list -- are dispatched together)

@@ -148,7 +148,7 @@ def test_strip_path_equals_oracle_and_other_paths(dmap, oracle, seed):
   _LISTED.append(listed)
 
 
-def test_value_list_path_was_exercised():
+def test_value_list_path_was_exercised(dmap):
   assert sum(_LISTED) >= 4, _LISTED
 
 

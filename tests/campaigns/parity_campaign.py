@@ -37,7 +37,7 @@ def one(seed):
     depth.reshape(-1)[idx] = np.resize(np.array([np.nan, np.inf, -np.inf, 0.0, -1.0, 1e30], np.float32), 12)
   pose = np.stack([rng.uniform(-2, 2, B), rng.uniform(-2, 2, B), rng.uniform(-np.pi, np.pi, B)],
                   axis=1).astype(np.float32)
-  per_frame = bool(rng.integers(2))
+  per_frame = bool(rng.integers(2)) and not ONE_PITCH
   pitch = rng.uniform(-0.9, 0.5, size=B if per_frame else 1).astype(np.float32)
   camh = rng.uniform(0.2, 2.0, size=B if per_frame else 1).astype(np.float32)
   is_max = bool(rng.integers(4))
@@ -72,6 +72,8 @@ def one(seed):
       value = rng.normal(size=(B, C, H, W)).astype(np.float32)
   proj = dmap.MapProjector(**cfg)
   get_h = value is not None
+  if ONE_PITCH:      # any number of column strips, whatever the cost model says (the strip path's own hook)
+    LIB.dm_debug_force_strips(int(rng.integers(0, 9)))
   outs = proj.orth_project(torch.from_numpy(depth).cuda(),
                            value_map=None if value is None else torch.from_numpy(value).cuda(),
                            valid_map=None if valid is None else torch.from_numpy(valid).cuda(),
@@ -80,6 +82,7 @@ def one(seed):
   LIB.dm_debug_last_split(split)
   STATS["banded"] += split[2] > 1
   STATS["generic"] += split[0] == 0
+  STATS["strip"] += LIB.dm_debug_last_path() == 2
   kw = dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose)
   want = oracle.orth_project(depth, value_map=value, valid_map=valid, get_height_map=get_h,
                              nthreads=16, **kw)
@@ -107,7 +110,8 @@ def one(seed):
 ODD = os.environ.get("DM_CAMPAIGN_ODD", "0") != "0"      # odd map widths
 SUM = os.environ.get("DM_CAMPAIGN_SUM", "0") != "0"      # reduction='sum' of one-hot values
 FINE = os.environ.get("DM_CAMPAIGN_FINE", "0") != "0"    # fine map_res: depth bands (forced)
-STATS = {"banded": 0, "generic": 0}
+ONE_PITCH = os.environ.get("DM_CAMPAIGN_ONE_PITCH", "0") != "0"   # one pitch per batch + forced strips: the strip path
+STATS = {"banded": 0, "generic": 0, "strip": 0}
 from dungeon_maps_amd import _native
 LIB = _native.lib()
 LIB.dm_debug_force_bands(1 if FINE else 0)
@@ -123,5 +127,5 @@ for s in range(first, first + count):
     print("MISMATCH seed", s, shape, "mask cells", bm, "map cells", bv, flush=True)
   if (s - first) % 50 == 49:
     print("  ... %d configurations, %d with mismatches" % (s - first + 1, bad), flush=True)
-print("done: %d configurations, %d with mismatches (%d took depth bands, %d the generic path)"
-      % (count, bad, STATS["banded"], STATS["generic"]))
+print("done: %d configurations, %d with mismatches (%d took the strip path, %d depth bands, %d the generic path)"
+      % (count, bad, STATS["strip"], STATS["banded"], STATS["generic"]))

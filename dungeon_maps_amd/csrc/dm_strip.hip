@@ -64,7 +64,7 @@ bool make_plan(const dm_params& p, Plan& plan, int strips = 0) {
   if (p.reduction != DM_REDUCE_MAX && p.reduction != DM_REDUCE_MIN) return false;
   if (p.mw % 4 != 0 || p.W % 4 != 0) return false;
   if (p.mw > 32767 || p.mh > 32767 || (int64_t)p.mh * p.mw >= (1ll << 28)) return false;   // (32-bit byte offsets)
-  if ((int64_t)p.H * p.W >= (1ll << 28)) return false;                                      // (the same for the images)
+  if ((int64_t)p.H * p.W >= (1ll << 28) || p.H >= (1 << 23) || p.W >= (1 << 23)) return false;   // (the same for the images; 24-bit row multiplies)
   if (!(p.fill == p.fill)) return false;
   if (!p.has_dmin || !p.has_dmax || !(p.dmin >= 0.0f) || !(p.dmax >= p.dmin) || !isfinite(p.dmax))
     return false;

@@ -324,10 +324,10 @@ k_strip_scatter(StripArgs a) {
     for (int u = 0; u < kRowsInFlight; ++u) {
       int rr = r + u * rows_per_iter;
       rr = rr < r1 ? rr : r1 - 1;              // tail rows repeat the last row (max / min: idempotent)
-      const int at = rr * a.W + q;             // (pixel index inside the image)
+      const int at = __mul24(rr, a.W) + q;     // (pixel index inside the image; 24-bit multiply: full rate)
       if (MODE == kFromList) {                 // four 16-bit cells instead of four depths
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-        const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(rs_list, (rr * a.wp + (q - q0)) << 1, 0, 0);
+        const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(rs_list, (__mul24(rr, a.wp) + (q - q0)) << 1, 0, 0);
         z[u][0] = __uint_as_float(c.x); z[u][1] = __uint_as_float(c.y);
       } else {
         const f32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_depth, at << 2, 0, 0);
@@ -645,7 +645,7 @@ k_strip_scatter(StripArgs a) {
             int rr = r + u * rows_per_iter;
             rr = rr < r1 ? rr : r1 - 1;
             __builtin_amdgcn_raw_buffer_store_b64((u32x2){li[0] | (li[1] << 16), li[2] | (li[3] << 16)}, rs_list,
-                                                  (rr * a.wp + (q - q0)) << 1, 0, 0);
+                                                  (__mul24(rr, a.wp) + (q - q0)) << 1, 0, 0);
             continue;
           }
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(li[0] == li[VEC - 1] && li[0] != dummy) != 0, 0)) {

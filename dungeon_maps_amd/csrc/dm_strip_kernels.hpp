@@ -865,7 +865,6 @@ k_strip_combine(StripCombineArgs a) {
     wq[q] = *reinterpret_cast<const int2*>(a.g_wins + (size_t)b * strip::kMaxStrips + (q < a.P ? q : 0));
   const float* const slabs = a.slabs + ((size_t)(b * a.oc + chl) * a.P) * a.slab_stride;
   const size_t fo = ((size_t)b * a.oc_total + a.ch0 + chl) * (size_t)a.mh * a.mw;
-  const float ident = RED == kMax ? -INFINITY : INFINITY;
   for (int base = first; base < listed; base += kCombineEntries * kStride) {
     if (base != first) {
 #pragma unroll

@@ -501,6 +501,42 @@ def other_configs(dmap, lib, dev):
   same = bool(np.array_equal(top.cpu().numpy(), want[0]) and np.array_equal(mask.cpu().numpy(), want[1]))
   entry("cfg1", us, wall, algorithmic_bytes(B, H, W, mh, mw, 0), same,
         "B=1, 320x240 -> 256x256 height map, orth_project per call")
+  # the same frame with the camera state prepared once and the call replayed from a HIP graph (what a
+  # fixed-rig loop can do: no host geometry, no copy, one graph launch per frame); events around
+  # 200 back-to-back replays, total / 200
+  try:
+    prep1 = proj.prepare(B, cam_pose=po)
+    outs = (torch.empty((B, 1, mh, mw), dtype=torch.float32, device=dev),
+            torch.empty((B, 1, mh, mw), dtype=torch.bool, device=dev))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      for _ in range(3):
+        prep1.orth_project(d, out=outs)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+      prep1.orth_project(d, out=outs)
+    for _ in range(5):
+      graph.replay()
+    torch.cuda.synchronize()
+    n = 200
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(n):
+      graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    wall_g = (time.perf_counter() - t0) / n * 1e6
+    us_g = e0.elapsed_time(e1) * 1e3 / n
+    same_g = bool(np.array_equal(outs[0].cpu().numpy(), want[0]) and np.array_equal(outs[1].cpu().numpy(), want[1]))
+    entry("cfg1_prepared_graph", us_g, wall_g, algorithmic_bytes(B, H, W, mh, mw, 0), same_g,
+          "the same frame through MapProjector.prepare + a captured HIP graph, per replay "
+          "(200 replays back to back)")
+    del graph, prep1
+  except Exception as e:      # (a library that cannot prepare this shape: reported, not fatal)
+    res["cfg1_prepared_graph"] = {"error": str(e)[:200]}
 
   # cfg3: B=64, 40-class one-hot object map (no height map), checked on frame 0
   B, H, W, mh, mw, C = WORKLOADS["cfg3"]

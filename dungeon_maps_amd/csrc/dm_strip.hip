@@ -439,7 +439,11 @@ thread_local int g_force_legacy = 0;       // dm_debug_force_legacy_window
 
 size_t strip_workspace_extra(const dm_params& p) {
   Plan plan;
-  if (!make_plan(p, plan)) return 0;
+  if (!make_plan(p, plan)) {       // (prepared frames take column strips where a plain call would not: prepare_plan)
+    int strips = (p.W + 39) / 40;
+    if (strips > strip::kMaxStrips) strips = strip::kMaxStrips;
+    if (strips < 1 || !make_plan(p, plan, strips)) return 0;
+  }
   // Value maps: room for the slabs of every channel (up to 2 GiB of address space, touched only
   // where strips share cells), so that all channels go through ONE scatter + merge launch pair
   // instead of one pair per group of channels that fits the LDS-window path's 256 MiB.
@@ -471,10 +475,22 @@ const Plan* cached_plan(const dm_params& p, int strips = 0) {
 
 // The plan and rig the call takes: the cost model's split, or -- when a strip's window would not
 // fit in LDS -- the same image cut into 2, 4, 8 strips.  NULL: the strip path does not apply.
-const Plan* plan_and_rig(const dm_params& p, const dm_frame* frames_host, const Rig** rig_out) {
+// A request to PREPARE frames takes column strips even where the cost model of a plain call would
+// split rows or depth (a single small frame: the plain call is cheaper on the window path, whose
+// geometry comes from the host; prepared, the strip path's two launches are all there is): about
+// 40 columns per strip.
+const Plan* prepare_plan(const dm_params& p) {
+  const Plan* plan = cached_plan(p);
+  if (plan || g_force_strips) return plan;
+  int strips = (p.W + 39) / 40;
+  if (strips > strip::kMaxStrips) strips = strip::kMaxStrips;
+  return strips >= 1 ? cached_plan(p, strips) : nullptr;
+}
+
+const Plan* plan_and_rig(const dm_params& p, const dm_frame* frames_host, const Rig** rig_out, bool for_prepare = false) {
   const int magnitude = validate_frames(p, frames_host, p.B);
   if (magnitude < 0) return nullptr;
-  const Plan* plan = cached_plan(p);
+  const Plan* plan = for_prepare ? prepare_plan(p) : cached_plan(p);
   if (!plan) return nullptr;
   const Rig* rg = rig_of(p, *plan, frames_host[0], magnitude);
   for (int strips = 2; !rg->fits && rg->cfg.cone_ok && strips <= strip::kMaxStrips && !g_force_strips; strips *= 2) {
@@ -603,7 +619,7 @@ hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const floa
                        fused_mask, static_cast<unsigned char*>(ws) + head, ws_bytes - head, after_projection, s);
 }
 
-size_t strip_prepared_bytes(const dm_params& p) { return cached_plan(p) ? prepared_bytes(p) : 0; }
+size_t strip_prepared_bytes(const dm_params& p) { return prepare_plan(p) ? prepared_bytes(p) : 0; }
 
 // dm_frames_prepare_f32: validate the batch's camera state, size the launches, upload, and derive
 // the frames' geometry and row tables on the device (k_strip_prepare).
@@ -611,7 +627,7 @@ hipError_t strip_prepare(const dm_params& p, const dm_frame* frames_host, void* 
                          size_t prepared_size, dm_frames_plan* plan_out, hipStream_t s) {
   if (g_force_legacy || p.B > 65535 || p.B < 1) return hipErrorNotSupported;
   const Rig* rg = nullptr;
-  const Plan* plan = plan_and_rig(p, frames_host, &rg);
+  const Plan* plan = plan_and_rig(p, frames_host, &rg, true);
   if (!plan) return hipErrorNotSupported;
   if (reinterpret_cast<uintptr_t>(prepared_dev) % 256 != 0 || prepared_size < prepared_bytes(p))
     return hipErrorInvalidValue;
@@ -630,7 +646,7 @@ hipError_t run_strip_prepared(const dm_params& p, const dm_frames_plan& fp, void
                               hipStream_t s) {
   if (!aligned_for_strips(depth, value, valid, out, mask, height, fused, fused_mask)) return hipErrorNotSupported;
   const Plan* plan = cached_plan(p);
-  if (plan && plan->P != fp.strips) plan = cached_plan(p, fp.strips);
+  if (!plan || plan->P != fp.strips) plan = cached_plan(p, fp.strips);
   if (!plan || plan->P != fp.strips || plan->wp != fp.strip_width) return hipErrorNotSupported;
   if (before_projection) {
     const hipError_t e = hipEventRecord(before_projection, s);

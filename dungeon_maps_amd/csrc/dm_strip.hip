@@ -20,6 +20,9 @@
 // Workgroups per launch the strip path aims at by adding fill-only workgroups (0: none).  Measured
 // at 16 x 1280x960 -> 2048^2 (8 strips per frame): 8 + 8 workgroups per frame 120 us, 8 + 24: 142 us,
 // against 97-108 us on the window path with its row blocks -- so off, and such shapes stay there.
+#ifndef DM_X_COMBINE_ENTRIES
+#define DM_X_COMBINE_ENTRIES 4      // list entries per thread of the combine kernel for value maps of many channels
+#endif
 #ifndef DM_X_FILL_TARGET
 #define DM_X_FILL_TARGET 0
 #endif
@@ -419,9 +422,9 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
       const int nb = p.B - b0 < per_launch ? p.B - b0 : per_launch;
       ca.b0 = b0;
       if (oc_total >= kListMinChannels) {        // (value maps of many channels: four entries per thread)
-        const dim3 g(kCombineSlots / 4, (unsigned)(nb * oc));
-        e = is_max ? launch(k_strip_combine<kMax, 4>, g, dim3(kCombineThreads), 0, s, ca)
-                   : launch(k_strip_combine<kMin, 4>, g, dim3(kCombineThreads), 0, s, ca);
+        const dim3 g(kCombineSlots / DM_X_COMBINE_ENTRIES, (unsigned)(nb * oc));
+        e = is_max ? launch(k_strip_combine<kMax, DM_X_COMBINE_ENTRIES>, g, dim3(kCombineThreads), 0, s, ca)
+                   : launch(k_strip_combine<kMin, DM_X_COMBINE_ENTRIES>, g, dim3(kCombineThreads), 0, s, ca);
       } else {
         const dim3 g(kCombineSlots, (unsigned)(nb * oc));
         e = is_max ? launch(k_strip_combine_one<kMax>, g, dim3(kCombineThreads), 0, s, ca)

@@ -428,7 +428,11 @@ k_strip_scatter(StripArgs a) {
   const int fparts = a.fill_parts;
   const int fill_rows = (a.mh - part + fparts - 1) / fparts;
   const int chunks = (a.mw + 255) >> 8;
+#ifdef DM_X_NOFILL2
+  const int fill_steps = 0;
+#else
   const int fill_steps = a.out != nullptr && wave < fill_rows ? ((fill_rows - wave + 15) >> 4) * chunks : 0;
+#endif
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const unsigned map_cells = (unsigned)a.mh * (unsigned)a.mw;
   const __amdgpu_buffer_rsrc_t rs_out =
@@ -538,8 +542,12 @@ k_strip_scatter(StripArgs a) {
                 li[k] = same ? dummy : li[k];
               }
             }
+#ifndef DM_X_NOATOMIC
 #pragma unroll
             for (int k = 0; k < VEC; ++k) lds_reduce<RED>(lds_at(li[k]), hv[k]);
+#else
+            if (li[0] + li[1] + li[2] + li[3] == 12345u && hv[0] + hv[1] + hv[2] + hv[3] == 1.5f) lds_reduce<RED>(lds_at(dummy), hv[0]);
+#endif
           }
           return;
         }

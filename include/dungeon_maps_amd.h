@@ -264,7 +264,13 @@ int dm_scatter_f32(const float* values_dev, const int64_t* index_dev, float* can
  *   dm_frames_prepared_bytes     device bytes a prepared batch of p->B frames needs (0: the strip
  *                                path never applies to `p`); the buffer must be 256-byte aligned.
  *   dm_frames_prepare_f32        validates `frames` (host, as for dm_orth_project_f32), fills
- *                                `plan_out` and enqueues ONE copy into `prepared_dev`.
+ *                                `plan_out` and enqueues ONE copy into `prepared_dev` plus one small
+ *                                kernel that derives the frames' geometry there (windows, per-row
+ *                                covers, the list of cells several strips share).  What it replaces
+ *                                in the reference: the per-call pose handling of
+ *                                MapProjector.orth_project (maps.py:1406-1465: cam_pose -> rotation
+ *                                and translation tensors, utils.py:229-330) hoisted out of the
+ *                                per-batch call.
  *   dm_orth_project_prepared_f32 dm_orth_project_f32 with the frames taken from `prepared_dev`.
  *                                A batch whose geometry does not fit `plan` (frames changed behind
  *                                the plan's back) projects nothing for the frames concerned and

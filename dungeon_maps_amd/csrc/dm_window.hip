@@ -53,6 +53,7 @@ bool window_path_supported(const dm_params& p) {
   if (p.reduction == DM_REDUCE_PROD) return false;      // generic path
   if (p.mw % 4 != 0) return false;
   if (p.mw > 32767 || p.mh > 32767) return false;   // Win16
+  if ((int64_t)p.mh * p.mw >= (1ll << 28)) return false;   // (32-bit byte offsets of the fill duty's buffer stores)
   if (!(p.fill == p.fill)) return false;       // NaN fill has no order
   return true;
 }

@@ -216,45 +216,45 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
 
   // Fill duty, interleaved with the scatter so that these stores ride under the
   // projection: map rows part, part + nparts, ... of (b, ch), minus the frame's union
-  // window U (k_window_merge writes U).  One float4 (+ 4 mask bytes) per thread and step,
-  // ALWAYS executed: an element that needs no store (inside U, or past the end) is
-  // redirected to `alt`, a cell of this workgroup's share that does get the fill value,
-  // so the stores are unconditional straight-line code and the compiler can count the
-  // pipelined loop's waits exactly.
+  // window U (k_window_merge writes U).  Wave-level, as in k_strip_scatter: wave v takes the
+  // rows part + (v + 16 j) nparts, one step stores 256 cells of a row (float4 per lane) and their
+  // mask bytes with SCALAR addressing -- the map of this (frame, channel) as a raw buffer
+  // resource, the row and chunk in the scalar offset, the lane's fixed 16 / 4 bytes in the vector
+  // offset.  A lane with nothing to write (inside U, past the row's end, past the wave's rows)
+  // gets a vector offset past the end of the buffer and is dropped by the hardware's range
+  // check: unconditional straight-line stores (the compiler can count the pipelined loop's
+  // waits exactly) at a handful of VALU instructions per KB.
   const Window U = {(short)(u_raw[0] & 0xffff), (short)(u_raw[0] >> 16),
                     (short)(u_raw[1] & 0xffff), (short)(u_raw[1] >> 16)};
-  const int g4 = a.mw >> 2;
   const int fill_rows = (a.mh - part + nparts - 1) / nparts;
   const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
-  // where redirected stores go: a cell of this share outside U if there is one (it gets
-  // the fill value anyway), else the share's first cell (inside U: k_window_merge,
-  // which runs after this kernel, overwrites it)
-  int alt_cell = part * a.mw;
-  if (fill_rows > 0 && U.w > 0 && U.h > 0 && U.x0 == 0) {
-    const int last_row = part + (fill_rows - 1) * nparts;
-    if (U.x0 + U.w < a.mw) alt_cell = part * a.mw + U.x0 + U.w;                  // right of U
-    else if (part >= U.z0 && last_row >= U.z0 + U.h) alt_cell = last_row * a.mw; // below U
-  }
   const bool do_fill = a.out != nullptr && fill_rows > 0;                       // wave-uniform
-  const int fill_total = do_fill ? fill_rows * g4 : 0;
-  const int fill_steps = (fill_total + kScatterThreads - 1) / kScatterThreads;
-  const float g4_inv = 1.0f / (float)g4;
-  int fs = 0;
+  const int f_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int f_lane4 = ((int)threadIdx.x & 63) << 2;
+  const int f_chunks = (a.mw + 255) >> 8;
+  const int fill_steps = do_fill && f_wave < fill_rows ? ((fill_rows - f_wave + 15) >> 4) * f_chunks : 0;
+  typedef unsigned int fill_u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned f_cells = (unsigned)a.mh * (unsigned)a.mw;     // (< 2^28: window_path_supported)
+  const __amdgpu_buffer_rsrc_t rs_fill_out =
+      __builtin_amdgcn_make_buffer_rsrc(a.out + map_base, 0, do_fill ? f_cells * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_fill_mask =
+      __builtin_amdgcn_make_buffer_rsrc(a.mask + map_base, 0, do_fill ? f_cells : 0u, 0x00020000);
+  const unsigned f_bits = __float_as_uint(a.fill);
+  int fs = 0, f_row = part + f_wave * nparts, f_chunk = 0;                      // (wave-uniform)
   auto fill_step = [&]() {
-    const int i = fs * kScatterThreads + (int)threadIdx.x;     // < 2^24
+    const int x = (f_chunk << 8) + f_lane4;
+    const bool live = fs < fill_steps;                                          // (scalar)
+    const bool in_rows = (unsigned)(f_row - U.z0) < (unsigned)U.h;              // (scalar)
+    const bool skip = !live | (x >= a.mw) | (in_rows & ((unsigned)(x - U.x0) < (unsigned)U.w));
+    // (the scalar offset must be the same in every lane, skipping or not)
+    const int cell0 = __builtin_amdgcn_readfirstlane(live ? f_row * a.mw + (f_chunk << 8) : 0);
+    __builtin_amdgcn_raw_buffer_store_b128((fill_u32x4){f_bits, f_bits, f_bits, f_bits}, rs_fill_out,
+                                           skip ? 0x7ffffff0 : f_lane4 << 2, cell0 << 2, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(0u, rs_fill_mask, skip ? 0x7ffffff0 : f_lane4, cell0, 0);
     ++fs;
-    int k = (int)((float)i * g4_inv);          // i / g4 without a division routine or a branch
-    k -= (k * g4 > i);
-    k += ((k + 1) * g4 <= i);
-    const int g = i - k * g4;
-    const int r = part + k * nparts, x = g << 2;
-    const bool skip = i >= fill_total || ((unsigned)(r - U.z0) < (unsigned)U.h &&
-                                          (unsigned)(x - U.x0) < (unsigned)U.w);
-    int cell = r * a.mw + x;
-    asm("" : "+v"(cell));                      // keep the select a v_cndmask
-    cell = skip ? alt_cell : cell;
-    *reinterpret_cast<float4*>(a.out + map_base + cell) = make_float4(a.fill, a.fill, a.fill, a.fill);
-    *reinterpret_cast<uint32_t*>(a.mask + map_base + cell) = 0u;
+    const bool next_row = f_chunk + 1 == f_chunks;
+    f_chunk = next_row ? 0 : f_chunk + 1;
+    f_row += next_row ? 16 * nparts : 0;
   };
   // device copies of the geometry for the kernels that follow (stored at the very end: a
   // store in flight makes its wave wait before the first depth loads)

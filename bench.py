@@ -585,7 +585,10 @@ def other_configs(dmap, lib, dev):
   alg = B * H * W * (4 + 8)
   res["cfg5_ego_flow"] = {"launch_us": us, "call_wall_us": wall, "algorithmic_bytes": alg,
                           "achieved_GBps": alg / us / 1e3, "frac": alg / us / 1e3 / HBM_PEAK_GBS,
-                          "workload": "camera_affine_grid of the same 16 frames (events around the call)"}
+                          "workload": "camera_affine_grid of the same 16 frames (events around the call)",
+                          "checked_by": "tests/test_hip_full_configs.py::test_cfg5_ego_flow_grid_1280x960 "
+                                        "(reference-generated fixture g8b; the oracle has no restatement of "
+                                        "camera_affine_grid to check a bench sample against)"}
   return res
 
 

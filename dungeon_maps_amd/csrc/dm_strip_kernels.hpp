@@ -187,8 +187,11 @@ k_strip_prepare(StripPrepArgs a) {
       if (sub == 0) a.t.reach[(size_t)b * a.max_rows + r] = rhi > rlo ? make_uint2((unsigned)rlo, (unsigned)(rhi - rlo)) : make_uint2(0u, 0u);
 #pragma unroll
       for (int q = 0; q < strip::kMaxStrips; ++q) own[q] = (uint32_t)__shfl((int)owned, lane0 + q, 64);
-      // the groups of [rlo, rhi) nobody owns: the row's lanes take every kPrepLanes-th group
-      for (int x = rlo + 4 * sub; x < rhi; x += 4 * kPrepLanes) {
+      // the groups of [rlo, rhi) nobody owns: the row's lanes take kPrepLanes neighbouring groups at
+      // a time and append theirs in lane order -- runs of up to kPrepLanes entries whose groups are
+      // neighbours in the slabs, so that the combine kernel's threads read them coalesced
+      for (int x0 = rlo; x0 < rhi; x0 += 4 * kPrepLanes) {       // (the same trips in all lanes of a row)
+        const int x = x0 + 4 * sub;
         uint32_t hits = 0;
         bool mine = false;
 #pragma unroll
@@ -196,8 +199,14 @@ k_strip_prepare(StripPrepArgs a) {
           hits |= strip::in_span(cov[q], x) ? 1u << q : 0u;
           mine = mine | strip::in_span(own[q], x);
         }
-        if (!mine) {
-          const int at = atomicAdd(&listed, 1);
+        const bool want = x < rhi && !mine;
+        const unsigned group_bits = (unsigned)((__builtin_amdgcn_ballot_w64(want) >> lane0) & ((1ull << kPrepLanes) - 1));
+        const int count = __builtin_popcount(group_bits);
+        int base = 0;
+        if (sub == 0 && count > 0) base = atomicAdd(&listed, count);
+        base = __shfl(base, lane0, 64);
+        if (want) {
+          const int at = base + __builtin_popcount(group_bits & ((1u << sub) - 1u));
           if (at < kPrepListLds) found[at] = pack_shared(r, (x - U.x0) >> 2, hits);
           else atomicOr(a.status, 2);         // (a pass of rows with more than kPrepListLds shared groups)
         }

@@ -249,6 +249,35 @@ def _prepared_checks(dmap, lib, proj, d, depth, poses, cfg):
     dmap.MapProjector(**dict(cfg, trunc_depth_max=None)).prepare(depth.shape[0], cam_pose=poses[0])
 
 
+def test_prepared_single_small_frame_equals_oracle(dmap, oracle):
+  """BASELINE configs[0] (B = 1, 320x240 -> 256x256): a plain call of this shape stays on the window
+  path, but MapProjector.prepare takes it (column strips of about 40 pixels) -- the prepared
+  projection must equal the oracle and the plain call, also for a two-frame batch with a valid map."""
+  lib = _lib()
+  rng = np.random.default_rng(321)
+  for B, with_valid in ((1, False), (2, True)):
+    H, W, mh, mw = 240, 320, 256, 256
+    depth = rng.uniform(0.1, 8.0, size=(B, 1, H, W)).astype(np.float32)
+    valid = (rng.uniform(size=(B, 1, H, W)) > 0.15) if with_valid else None
+    pose = np.stack([rng.uniform(-1, 1, B), rng.uniform(-1, 1, B), rng.uniform(-np.pi, np.pi, B)], 1).astype(np.float32)
+    cfg = dict(width=W, height=H, hfov=np.radians(70.), vfov=None, cam_pitch=np.radians(-20.), cam_height=0.88,
+               width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
+               trunc_depth_min=0.15, trunc_depth_max=5.05, trunc_height_max=None, clip_border=0,
+               to_global=True, flip_h=True, fill_value=-np.inf, reduction="max")
+    proj = dmap.MapProjector(**cfg)
+    d = torch.from_numpy(depth).cuda()
+    m = None if valid is None else torch.from_numpy(valid).cuda()
+    plain = proj.orth_project(d, valid_map=m, cam_pose=pose)
+    prep = proj.prepare(B, cam_pose=pose, valid_channels=1 if with_valid else 0)
+    got = prep.orth_project(d, valid_map=m)
+    assert lib.dm_debug_last_path() == 2 and prep.status() == 0
+    kw = dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose)
+    want = oracle.orth_project(depth, valid_map=valid, **kw)
+    np.testing.assert_array_equal(got[1].cpu().numpy(), want[1])
+    np.testing.assert_array_equal(got[0].cpu().numpy(), want[0])
+    assert torch.equal(got[0], plain[0]) and torch.equal(got[1], plain[1])
+
+
 def test_prepared_projection_replays_from_a_hip_graph(dmap):
   """dm_orth_project_prepared_f32's launch sequence depends only on the parameters and the
   pointers: captured into a HIP graph it replays bit-equal, and after update() (new poses into

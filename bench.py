@@ -240,16 +240,26 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
-  for _ in range(args.warmup):
-    step()
+  # the warm-up runs the timed loop's exact body: the steps' outputs are bound to `out` (so the
+  # caching allocator owns both sets of output blocks the loop alternates between before the clock
+  # starts -- a device allocation inside the timed region cost 50 us on one box and 2 ms on
+  # another) and every n-th step is bracketed by events
+  out = None
+  for j in range(args.warmup):
+    out = step(j % max(1, args.steps))
   if dist is not None:
     flush_ring()
     finish_reduce()
   barrier()
+  trace = [] if os.environ.get("DM_BENCH_TRACE") else None
+  segs0 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
   t0 = time.perf_counter()
   for i in range(args.steps):
     out = step(i)
+    if trace is not None:
+      trace.append(time.perf_counter())
   enqueue_s = time.perf_counter() - t0      # host time to issue the steps (<= elapsed)
+  segs1 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
   if dist is not None:            # every step's all-reduce + mask is inside the timed region
     flush_ring()
     finish_reduce()
@@ -343,6 +353,9 @@ def main():
       },
   }
 
+  if trace is not None:      # host time of every timed step's enqueue, us (DM_BENCH_TRACE=1)
+    result["host_step_us"] = [round((t - s0) * 1e6, 1) for s0, t in zip([t0] + trace[:-1], trace)]
+    result["device_allocations_in_timed_loop"] = segs1 - segs0
   if fused_only:
     result["roofline"]["kernel"] = ("dm_orth_project_fused_f32 launch sequence: "
                                     "k_window_scatter + k_fuse_windows")

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DUNGEON_MAPS_AMD_LIB") or os.path.join(
     HERE, "csrc", "libdungeon_maps_amd.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # dm_reduction
 REDUCE_MAX, REDUCE_MIN, REDUCE_SUM, REDUCE_MEAN, REDUCE_PROD = range(5)
@@ -47,8 +47,12 @@ class FuseSrc(ctypes.Structure):
 class FramesPlan(ctypes.Structure):
   """dm_frames_plan"""
   _fields_ = [(n, ctypes.c_int32) for n in (
-      "strips", "strip_width", "slab_cells", "max_rows", "max_union_cells", "slack_cells")] + [
-      ("reserved", ctypes.c_int32 * 2)]
+      "strips", "strip_width", "slab_cells", "max_rows", "max_union_cells", "slack_cells",
+      "magnitude")] + [("pitch", ctypes.c_float * 4), ("reserved", ctypes.c_int32)]
+
+
+# dm_status_bits
+STATUS_FRAME_DID_NOT_FIT, STATUS_LIST_OVERFLOW = 1, 2
 
 
 class NativeError(RuntimeError):
@@ -62,19 +66,21 @@ _SIGNATURES = {
     "dm_orth_project_f32": (ctypes.c_int, [
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+        ctypes.c_void_p]),
     "dm_frames_prepared_bytes": (ctypes.c_size_t, [ctypes.POINTER(Params)]),
     "dm_frames_prepare_f32": (ctypes.c_int, [
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
-        ctypes.POINTER(FramesPlan), ctypes.c_void_p]),
+        ctypes.POINTER(FramesPlan), ctypes.POINTER(FramesPlan), ctypes.c_void_p]),
     "dm_orth_project_prepared_f32": (ctypes.c_int, [
         ctypes.POINTER(Params), ctypes.POINTER(FramesPlan), ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+        ctypes.c_void_p]),
     "dm_orth_project_fused_f32": (ctypes.c_int, [
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "dm_debug_force_generic_path": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_force_bands": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_slab_budget": (ctypes.c_size_t, [ctypes.c_size_t]),
@@ -86,6 +92,7 @@ _SIGNATURES = {
     "dm_debug_force_legacy_window": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_force_strips": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_strip_value_list": (ctypes.c_int, [ctypes.c_int]),
+    "dm_debug_strip_slab_budget": (ctypes.c_size_t, [ctypes.c_size_t]),
     "dm_debug_strip_geometry": (ctypes.c_int, [
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dm_debug_strip_geometry_dev": (ctypes.c_int, [
@@ -171,3 +178,42 @@ def check(rc):
     msg = lib().dm_last_error()
     raise NativeError(f"dungeon_maps_amd native call failed ({rc}): "
                       f"{msg.decode() if msg else 'unknown error'}")
+
+
+# ---------------------------------------------------------------------------
+# Status word (dm_status_bits): one int32 of pinned host memory per process.  The kernels store
+# into it when they refuse a frame the host could not refuse up front (a prepared batch whose
+# device-side pose records changed behind its plan's back); the host looks at it -- a plain
+# memory read, no synchronisation -- in front of every projection call and raises.
+# ---------------------------------------------------------------------------
+_status = None
+
+
+def status_word():
+  """(pinned int32 tensor of one element, its address); allocated on first use."""
+  global _status
+  if _status is None:
+    import torch
+    t = torch.zeros(1, dtype=torch.int32).pin_memory()
+    _status = (t, t.numpy(), t.data_ptr())
+  return _status
+
+
+def status_ptr() -> int:
+  return status_word()[2]
+
+
+def check_status():
+  """Raise if an earlier projection flagged a frame (the flag is cleared by the raise)."""
+  if _status is None:
+    return
+  bits = int(_status[1][0])
+  if bits:
+    _status[1][0] = 0
+    what = []
+    if bits & STATUS_FRAME_DID_NOT_FIT:
+      what.append("a frame's camera state did not fit the launch plan it was projected with "
+                  "(a prepared batch's device buffer changed behind its plan): its maps hold the fill value")
+    if bits & STATUS_LIST_OVERFLOW:
+      what.append("a strip's shared-group list overflowed")
+    raise NativeError("an earlier projection reported: " + "; ".join(what or [f"status {bits}"]))

@@ -95,7 +95,7 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
                         const float* value_dev, const uint8_t* valid_dev, float* out_dev,
                         uint8_t* mask_dev, float* height_dev, float* fused_dev,
                         uint8_t* fused_mask_dev, void* workspace_dev, size_t workspace_bytes,
-                        void* stream) {
+                        int32_t* status_dev, void* stream) {
   int rc = check_params(p);
   if (rc != DM_OK) return rc;
   if (p->B == 0) return DM_OK;
@@ -126,7 +126,7 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
     const dm_params& pp = dm::bounded_depth_params(q, frames) ? q : *p;
     e = dm::run_strip(pp, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
                       p->vc ? height_dev : nullptr, fused_dev, fused_mask_dev, workspace_dev,
-                      workspace_bytes, pre, mid, s);
+                      workspace_bytes, status_dev, pre, mid, s);
     if (e == hipErrorNotSupported)
       e = dm::run_window(pp, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
                          p->vc ? height_dev : nullptr, fused_dev, fused_mask_dev, workspace_dev,
@@ -188,16 +188,20 @@ size_t dm_frames_prepared_bytes(const dm_params* p) {
 }
 
 int dm_frames_prepare_f32(const dm_params* p, const dm_frame* frames, void* prepared_dev,
-                          size_t prepared_bytes, dm_frames_plan* plan_out, void* stream) {
+                          size_t prepared_bytes, const dm_frames_plan* must_match,
+                          dm_frames_plan* plan_out, void* stream) {
   int rc = check_params(p);
   if (rc != DM_OK) return rc;
   if (!frames || !prepared_dev || !plan_out || p->B < 1)
     return fail(DM_ERR_INVALID_ARGUMENT, "frames/prepared/plan must not be NULL, B >= 1");
-  const hipError_t e = dm::strip_prepare(*p, frames, prepared_dev, prepared_bytes, plan_out,
+  const hipError_t e = dm::strip_prepare(*p, frames, prepared_dev, prepared_bytes, must_match, plan_out,
                                          static_cast<hipStream_t>(stream));
   if (e == hipErrorNotSupported)
     return fail(DM_ERR_UNSUPPORTED, "these parameters / frames cannot be prepared (the strip path does "
                                     "not apply): use dm_orth_project_f32");
+  if (e == hipErrorInvalidConfiguration)
+    return fail(DM_ERR_PLAN_MISMATCH, "the frames need a different launch plan than `must_match`; "
+                                      "nothing was uploaded");
   if (e == hipErrorInvalidValue)
     return fail(DM_ERR_WORKSPACE_TOO_SMALL, "prepared buffer: %zu B given, %zu B (256-byte aligned) needed",
                 prepared_bytes, dm::strip_prepared_bytes(*p));
@@ -205,11 +209,12 @@ int dm_frames_prepare_f32(const dm_params* p, const dm_frame* frames, void* prep
   return DM_OK;
 }
 
-int dm_orth_project_prepared_f32(const dm_params* p, const dm_frames_plan* plan, void* prepared_dev,
+int dm_orth_project_prepared_f32(const dm_params* p, const dm_frames_plan* plan, const void* prepared_dev,
                                  const float* depth_dev, const float* value_dev,
                                  const uint8_t* valid_dev, float* out_dev, uint8_t* mask_dev,
                                  float* height_dev, float* fused_dev, uint8_t* fused_mask_dev,
-                                 void* workspace_dev, size_t workspace_bytes, void* stream) {
+                                 void* workspace_dev, size_t workspace_bytes, int32_t* status_dev,
+                                 void* stream) {
   int rc = check_params(p);
   if (rc != DM_OK) return rc;
   if (!plan || !prepared_dev || !depth_dev || !out_dev || !mask_dev || p->B < 1)
@@ -228,8 +233,8 @@ int dm_orth_project_prepared_f32(const dm_params* p, const dm_frames_plan* plan,
   g_pre_event = nullptr;
   const hipError_t e = dm::run_strip_prepared(*p, *plan, prepared_dev, depth_dev, value_dev, valid_dev,
                                               out_dev, mask_dev, p->vc ? height_dev : nullptr, fused_dev,
-                                              fused_mask_dev, workspace_dev, workspace_bytes, pre, mid,
-                                              static_cast<hipStream_t>(stream));
+                                              fused_mask_dev, workspace_dev, workspace_bytes, status_dev,
+                                              pre, mid, static_cast<hipStream_t>(stream));
   if (e == hipErrorNotSupported)
     return fail(DM_ERR_UNSUPPORTED, "plan does not match the parameters, or misaligned pointers");
   if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
@@ -240,7 +245,8 @@ int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames,
                               const float* depth_dev, const float* value_dev,
                               const uint8_t* valid_dev, float* out_dev, uint8_t* mask_dev,
                               int accumulate, void* workspace_dev, size_t workspace_bytes,
-                              void* stream) {
+                              int32_t* status_dev, void* stream) {
+  (void)status_dev;
   int rc = check_params(p);
   if (rc != DM_OK) return rc;
   if (p->reduction != DM_REDUCE_MAX && p->reduction != DM_REDUCE_MIN)

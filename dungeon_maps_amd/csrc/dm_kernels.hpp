@@ -43,16 +43,18 @@ size_t strip_workspace_extra(const dm_params& p);
 hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const float* depth,
                      const float* value, const uint8_t* valid, float* out, uint8_t* mask,
                      float* height, float* fused, uint8_t* fused_mask, void* ws, size_t ws_bytes,
-                     hipEvent_t before_projection, hipEvent_t after_projection, hipStream_t s);
+                     int* status, hipEvent_t before_projection, hipEvent_t after_projection, hipStream_t s);
 
 size_t strip_prepared_bytes(const dm_params& p);
+// hipErrorInvalidConfiguration: the plan differs from `must_match` (nothing enqueued)
 hipError_t strip_prepare(const dm_params& p, const dm_frame* frames_host, void* prepared_dev,
-                         size_t prepared_size, dm_frames_plan* plan_out, hipStream_t s);
-hipError_t run_strip_prepared(const dm_params& p, const dm_frames_plan& fp, void* prepared_dev,
+                         size_t prepared_size, const dm_frames_plan* must_match, dm_frames_plan* plan_out,
+                         hipStream_t s);
+hipError_t run_strip_prepared(const dm_params& p, const dm_frames_plan& fp, const void* prepared_dev,
                               const float* depth, const float* value, const uint8_t* valid, float* out,
                               uint8_t* mask, float* height, float* fused, uint8_t* fused_mask, void* ws,
-                              size_t ws_bytes, hipEvent_t before_projection, hipEvent_t after_projection,
-                              hipStream_t s);
+                              size_t ws_bytes, int* status, hipEvent_t before_projection,
+                              hipEvent_t after_projection, hipStream_t s);
 
 // dm_points.hip -- exact point-set primitives (affine, quantise, flat scatter)
 hipError_t run_affine_points(const float* pts, const float* R, const float* t, int B,

@@ -3,11 +3,11 @@
 //
 // What the host does per call is pose independent: it validates the frame records (the
 // rotations have the axis-aligned pattern the fast arithmetic needs, one camera pitch for the
-// whole batch, magnitudes within the float32 slack), copies them to the device (or takes
-// them from the device as they are: dm_frames_prepare_f32 / dm_orth_project_prepared_f32)
-// and launches k_strip_prepare (the frames' geometry and row tables, on the device: once per
-// set of poses for prepared frames) and k_strip_scatter + k_strip_merge with sizes taken from
-// a bound that holds for EVERY yaw and position of the camera (cached per camera rig).
+// whole batch, magnitudes within the float32 slack) and launches k_strip_scatter +
+// k_strip_combine with sizes taken from a bound that holds for EVERY yaw and position of the
+// camera (cached per camera rig).  The frames' camera state travels in the scatter kernel's
+// arguments (48 bytes per frame, up to 64 frames per launch): no copy and no table kernel in
+// front of it -- the workgroups derive their frames' geometry themselves.
 #include <math.h>
 #include <string.h>
 
@@ -17,14 +17,8 @@
 #include "dm_kernels.hpp"
 #include "dm_strip_kernels.hpp"
 
-// Workgroups per launch the strip path aims at by adding fill-only workgroups (0: none).  Measured
-// at 16 x 1280x960 -> 2048^2 (8 strips per frame): 8 + 8 workgroups per frame 120 us, 8 + 24: 142 us,
-// against 97-108 us on the window path with its row blocks -- so off, and such shapes stay there.
 #ifndef DM_X_COMBINE_ENTRIES
 #define DM_X_COMBINE_ENTRIES 4      // list entries per thread of the combine kernel for value maps of many channels
-#endif
-#ifndef DM_X_FILL_TARGET
-#define DM_X_FILL_TARGET 0
 #endif
 
 namespace dm {
@@ -34,8 +28,6 @@ void note_split(int pc, int pr, int pd, int path);     // dm_window.hip (dm_debu
 namespace {
 
 inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
-constexpr size_t kCfgBytes = 1024;
-static_assert(sizeof(strip::Cfg) <= kCfgBytes, "Cfg slot");
 
 // Pose-independent plan of a call (the parameters alone).
 struct Plan {
@@ -54,8 +46,10 @@ struct Rig {
   float pitch[4];               // Rp[4], Rp[5], Rp[7], Rp[8]
   int slack;                    // cells of slack the bound was computed for
   int P;
+  int wp;                       // strip width the cones were derived for
   bool valid, fits;
   strip::Cfg cfg;
+  strip::RigArgs args;          // cfg as the kernels take it
   int slab_stride;              // cells of the largest window any strip can have
   int max_rows;                 // rows of the largest union window
   int max_union;                // cells of the largest union window
@@ -117,9 +111,10 @@ bool make_plan(const dm_params& p, Plan& plan, int strips = 0) {
   return true;
 }
 
-// The frame records the strip path can take: axis-aligned rotations (the fast arithmetic),
-// one pitch for the batch, finite values; returns the cells of slack that cover every frame
-// (>= what the device computes for it) or -1.
+// The frame records the strip path can take: axis-aligned rotations (the fast arithmetic) whose
+// yaw block is orthonormal (the launch bound rotates the cones rigidly), one pitch for the
+// batch, finite values; returns the cells of slack that cover every frame (>= what the device
+// computes for it) or -1.
 int validate_frames(const dm_params& p, const dm_frame* f, int B) {
   double worst = 0.0;
   const double inv = 1.0 / (double)p.res;
@@ -127,10 +122,16 @@ int validate_frames(const dm_params& p, const dm_frame* f, int B) {
     const float* rp = f[b].Rp;
     const float* ry = f[b].Ry;
     if (!(rp[0] == 1.0f && rp[1] == 0.0f && rp[2] == 0.0f && rp[3] == 0.0f && rp[6] == 0.0f)) return -1;
-    if (p.to_global &&
-        !(ry[1] == 0.0f && ry[3] == 0.0f && ry[4] == 1.0f && ry[5] == 0.0f && ry[7] == 0.0f))
-      return -1;
+    if (p.to_global) {
+      if (!(ry[1] == 0.0f && ry[3] == 0.0f && ry[4] == 1.0f && ry[5] == 0.0f && ry[7] == 0.0f)) return -1;
+      // (a scaled or sheared yaw block would move points further than the bound assumes)
+      const double y0 = ry[0], y2 = ry[2], y6 = ry[6], y8 = ry[8];
+      if (!(fabs(y0 * y0 + y2 * y2 - 1.0) < 1e-5 && fabs(y6 * y6 + y8 * y8 - 1.0) < 1e-5 &&
+            fabs(y0 * y6 + y2 * y8) < 1e-5))
+        return -1;
+    }
     if (rp[4] != f[0].Rp[4] || rp[5] != f[0].Rp[5] || rp[7] != f[0].Rp[7] || rp[8] != f[0].Rp[8]) return -1;
+    if (!isfinite(f[b].cam_height)) return -1;
     double m = fabs((double)f[b].width_offset) + fabs((double)f[b].height_offset) + (double)p.mh;
     if (p.to_global) m += 2.0 * (fabs((double)f[b].tx) + fabs((double)f[b].tz)) * inv;
     m = 2.0 * m;
@@ -142,15 +143,17 @@ int validate_frames(const dm_params& p, const dm_frame* f, int B) {
 
 // Cfg and launch bound of a rig.  The bound: the truncated cones are rotated in 1440 steps;
 // between two steps an extent grows by at most Rmax * dtheta.
-void compute_rig(const dm_params& p, const Plan& plan, const dm_frame& f0, int magnitude, Rig& rg) {
-  rg.key = p; rg.P = plan.P; rg.valid = true; rg.fits = false;
-  rg.pitch[0] = f0.Rp[4]; rg.pitch[1] = f0.Rp[5]; rg.pitch[2] = f0.Rp[7]; rg.pitch[3] = f0.Rp[8];
+void compute_rig(const dm_params& p, const Plan& plan, const float* pitch4, int magnitude, Rig& rg) {
+  rg.key = p; rg.P = plan.P; rg.wp = plan.wp; rg.valid = true; rg.fits = false;
+  memcpy(rg.pitch, pitch4, sizeof(rg.pitch));
+  float Rp[9] = {1.0f, 0.0f, 0.0f, 0.0f, pitch4[0], pitch4[1], 0.0f, pitch4[2], pitch4[3]};
   strip::Cfg& c = rg.cfg;
   memset(&c, 0, sizeof(c));
   c.P = plan.P; c.mw = p.mw; c.mh = p.mh; c.flip_h = p.flip_h != 0;
   c.inv = (float)(1.0 / (double)p.res);
   memcpy(c.live, plan.live, sizeof(c.live));
-  strip::cfg_rig(c, f0.Rp, plan.ax_lo, plan.ax_hi, plan.ay_lo, plan.ay_hi, p.dmin, p.dmax);
+  strip::cfg_rig(c, Rp, plan.ax_lo, plan.ax_hi, plan.ay_lo, plan.ay_hi, p.dmin, p.dmax);
+  rg.args = strip::rig_args(c, Rp, plan.ax_lo, plan.ax_hi, plan.ay_lo, plan.ay_hi, p.dmin, p.dmax);
   // slack that covers every frame of the batch (>= the device's own: same formula, larger m)
   const double slack_d = 2.0 + 16.0 * ((double)magnitude + 2.0 * (double)c.reach) * (1.0 / 8388608.0) + 0.01;
   rg.slack = slack_d > 16.0 ? -1 : (int)ceil(slack_d);
@@ -189,30 +192,40 @@ void compute_rig(const dm_params& p, const Plan& plan, const dm_frame& f0, int m
   if (uw > p.mw) uw = p.mw;
   if (uh > p.mh) uh = p.mh;
   rg.slab_stride = ((int)ceil(area) + 3) & ~3;
-  rg.max_rows = (int)ceil(uh);
-  rg.max_union = (((int)ceil(uw) + 2 * strip::kSpanAlign + 3) & ~3) * rg.max_rows;
-  rg.fits = strip_lds_bytes(rg.slab_stride, rg.max_rows, p.H) <= (size_t)kMaxLdsBytes;
+  rg.max_rows = ((int)ceil(uh) + 3) & ~3;       // (whole float4s: the LDS tables behind it stay 16-byte aligned)
+  const int uw4 = ((int)ceil(uw) + 2 * strip::kSpanAlign + 3) & ~3;
+  rg.max_union = uw4 * rg.max_rows;
+  // (the shared-group entries hold 12 bits of row and of float4 group: the device checks the same)
+  rg.fits = strip_lds_bytes(rg.slab_stride, rg.max_rows, p.H, plan.P) <= (size_t)kMaxLdsBytes &&
+            rg.max_rows <= kListMaxRows && uw4 <= 4 * kListMaxGroups;
 }
 
-const Rig* rig_of(const dm_params& p, const Plan& plan, const dm_frame& f0, int magnitude) {
+// The magnitude only matters through the slack it implies, so it is quantised: one rig serves
+// every batch whose frames stay within the same 2^17 cells (below 2^18: one rig for all), and a
+// rig is a pure function of (parameters, plan, pitch, quantised magnitude) -- what a prepared
+// batch's plan records is enough to find the same rig again.
+inline int quantised_magnitude(int magnitude) {
+  if (magnitude < (1 << 18)) return 1 << 18;
+  const int64_t up = ((int64_t)magnitude + (1 << 17)) / (1 << 17) * (1 << 17);
+  return up > 0x7fffffff ? 0x7fffffff : (int)up;
+}
+
+const Rig* rig_of(const dm_params& p, const Plan& plan, const float* pitch4, int magnitude) {
   thread_local Rig slots[4] = {};
   thread_local int slot_mag[4] = {0, 0, 0, 0};
   thread_local int next = 0;
-  // (the magnitude only matters through the slack it implies: reuse a rig computed for a
-  // magnitude at least as large and at most 2^20 larger -- the same slack up to 2 cells)
+  const int mag_q = quantised_magnitude(magnitude);
   for (int i = 0; i < 4; ++i) {
     Rig& r = slots[i];
-    if (r.valid && r.P == plan.P && memcmp(&r.key, &p, sizeof(dm_params)) == 0 &&
-        r.pitch[0] == f0.Rp[4] && r.pitch[1] == f0.Rp[5] && r.pitch[2] == f0.Rp[7] && r.pitch[3] == f0.Rp[8] &&
-        magnitude <= slot_mag[i] && slot_mag[i] - magnitude < (1 << 19))
+    if (r.valid && r.P == plan.P && r.wp == plan.wp && slot_mag[i] == mag_q &&
+        memcmp(&r.key, &p, sizeof(dm_params)) == 0 && memcmp(r.pitch, pitch4, sizeof(r.pitch)) == 0)
       return &r;
   }
   Rig& r = slots[next];
-  const int mag_up = magnitude < (1 << 18) ? (1 << 18) : magnitude + (1 << 17);   // a little headroom
-  slot_mag[next] = mag_up;
+  slot_mag[next] = mag_q;
   next = (next + 1) % 4;
   r = Rig{};
-  compute_rig(p, plan, f0, mag_up, r);
+  compute_rig(p, plan, pitch4, mag_q, r);
   return &r;
 }
 
@@ -246,75 +259,47 @@ inline size_t pixel_list_bytes(const dm_params& p) {     // (B, P, H, wp) uint16
   return up256((size_t)p.B * p.H * ((size_t)p.W + 32 * strip::kMaxStrips) * 2);
 }
 thread_local int g_no_value_list = 0;      // dm_debug_strip_value_list(0): every channel recomputes its cells
+thread_local size_t g_strip_slab_budget = 0;    // dm_debug_strip_slab_budget: bytes of slabs per channel group (0: all there is)
 inline bool list_shape(const dm_params& p) { return p.vc >= kListMinChannels && p.dc == 1; }   // (sizes the workspace)
 inline bool wants_pixel_list(const dm_params& p) { return list_shape(p) && !g_no_value_list; }
 
-// Device copy of a batch's camera state as the kernels read it ("prepared frames"):
-// [Cfg (kCfgBytes) | status word (256 B) | list counters | frame records | frame tables].
-// Lives at the head of the workspace for dm_orth_project_f32 (staged by one copy per call, the
-// tables by k_strip_prepare right behind it) or in a buffer of the caller's that
-// dm_frames_prepare_f32 filled once (dm_orth_project_prepared_f32: no copy and no geometry,
-// host or device).
-struct PreparedView {
-  const strip::Cfg* cfg;
-  int* status;
-  const float* frames;        // (B, 32)
-  FrameTables t;              // sized from the parameters alone; indexed with the plan's max_rows, P, list_cap
-};
-constexpr size_t kStatusBytes = 256;
-// entries of a frame's shared-group list: every float4 group of the largest union window
-inline size_t list_cap_bound(const dm_params& p) {
-  const size_t rows = p.mh < kListMaxRows ? p.mh : kListMaxRows;
-  const size_t groups = p.mw / 4 < kListMaxGroups ? p.mw / 4 : kListMaxGroups;
-  return rows * groups;
-}
+// Workspace of the strip path:
+//   [frame tables: wins (B, 8), unions (B), list counts (B, 8) | shared-group lists (B, P, seg_cap) |
+//    slabs ... | pixel list]
+// The tables are written by the scatter kernel for the kernels behind it; nothing is staged
+// from the host.  seg_cap = slab_cells / 4 (a strip lists at most the groups of its window).
 inline size_t tables_bytes(const dm_params& p) {
   return up256((size_t)p.B * strip::kMaxStrips * sizeof(Win16)) + up256((size_t)p.B * sizeof(Win16)) +
-         up256((size_t)p.B * sizeof(int)) +
-         up256((size_t)p.B * p.mh * strip::kMaxStrips * sizeof(strip::RowEntry)) +
-         up256((size_t)p.B * p.mh * sizeof(uint2)) + up256((size_t)p.B * list_cap_bound(p) * sizeof(uint32_t));
+         up256((size_t)p.B * strip::kMaxStrips * sizeof(int));
 }
-inline size_t counts_bytes(const dm_params& p) { return up256((size_t)p.B * sizeof(int)); }
-inline size_t staged_bytes(const dm_params& p) {      // what the host copies: Cfg, status, list counters (zero), frame records
-  return kCfgBytes + kStatusBytes + counts_bytes(p) + up256((size_t)p.B * sizeof(dm_frame));
+inline size_t lists_bytes(const dm_params& p, int P, int slab_cells) {
+  return up256((size_t)p.B * P * (size_t)(slab_cells / 4) * sizeof(uint32_t));
 }
-inline size_t prepared_bytes(const dm_params& p) { return staged_bytes(p) + tables_bytes(p); }
-inline PreparedView view_prepared(const dm_params& p, void* dev) {
-  unsigned char* base = static_cast<unsigned char*>(dev);
-  PreparedView v;
-  v.cfg = reinterpret_cast<const strip::Cfg*>(base);
-  v.status = reinterpret_cast<int*>(base + kCfgBytes);
-  v.t.counts = reinterpret_cast<int*>(base + kCfgBytes + kStatusBytes);
-  v.frames = reinterpret_cast<const float*>(base + kCfgBytes + kStatusBytes + counts_bytes(p));
-  base += staged_bytes(p);
-  v.t.wins = reinterpret_cast<Win16*>(base); base += up256((size_t)p.B * strip::kMaxStrips * sizeof(Win16));
-  v.t.unions = reinterpret_cast<Win16*>(base); base += up256((size_t)p.B * sizeof(Win16));
-  v.t.flags = reinterpret_cast<int*>(base); base += up256((size_t)p.B * sizeof(int));
-  v.t.rows = reinterpret_cast<strip::RowEntry*>(base); base += up256((size_t)p.B * p.mh * strip::kMaxStrips * sizeof(strip::RowEntry));
-  v.t.reach = reinterpret_cast<uint2*>(base); base += up256((size_t)p.B * p.mh * sizeof(uint2));
-  v.t.list = reinterpret_cast<uint32_t*>(base);
-  return v;
-}
-// entries per frame of the shared-group lists of a plan
-inline int list_cap_of(const dm_params& p, const dm_frames_plan& fp) {
-  const size_t cap = (size_t)fp.max_union_cells / 4 + 1;
-  return (int)(cap < list_cap_bound(p) ? cap : list_cap_bound(p));
+// (from the parameters alone: as many strips and as large windows as LDS can hold)
+inline size_t lists_bytes_bound(const dm_params& p) {
+  return lists_bytes(p, strip::kMaxStrips, kMaxLdsBytes / 4);
 }
 
-struct Layout {               // workspace of the strip path
+struct Layout {
+  FrameTables t;
   float* slabs;
   size_t slab_bytes;
   uint16_t* pixel_list;       // value maps of many channels: the pixels' cells (or NULL)
 };
 
-// [256 B | slabs ... | pixel list]
-bool carve(const dm_params& p, void* ws, size_t ws_bytes, Layout& l) {
+bool carve(const dm_params& p, int P, int slab_cells, void* ws, size_t ws_bytes, Layout& l) {
   if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return false;
   ws_bytes = ws_bytes / 256 * 256;
   const size_t lb = list_shape(p) ? pixel_list_bytes(p) : 0;
-  if (ws_bytes < 512 + lb) return false;
-  l.slabs = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + 256);
-  l.slab_bytes = ws_bytes - 256 - lb;
+  const size_t head = tables_bytes(p) + lists_bytes(p, P, slab_cells);
+  if (ws_bytes < head + 256 + lb) return false;
+  unsigned char* base = static_cast<unsigned char*>(ws);
+  l.t.wins = reinterpret_cast<Win16*>(base); base += up256((size_t)p.B * strip::kMaxStrips * sizeof(Win16));
+  l.t.unions = reinterpret_cast<Win16*>(base); base += up256((size_t)p.B * sizeof(Win16));
+  l.t.counts = reinterpret_cast<int*>(base); base += up256((size_t)p.B * strip::kMaxStrips * sizeof(int));
+  l.t.list = reinterpret_cast<uint32_t*>(base); base += lists_bytes(p, P, slab_cells);
+  l.slabs = reinterpret_cast<float*>(base);
+  l.slab_bytes = ws_bytes - head - lb;
   l.pixel_list = lb ? reinterpret_cast<uint16_t*>(static_cast<unsigned char*>(ws) + ws_bytes - lb) : nullptr;
   return true;
 }
@@ -340,14 +325,38 @@ hipError_t raise_lds_limit(const void* key) {
   return hipSuccess;
 }
 
-// One pass over the channels of `out`: scatter (+ owned groups straight to the map) and merge.
-hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan& rb, const PreparedView& pv,
-                      const Layout& l,
-                      const float* depth, const float* value, const uint8_t* valid, float* out,
-                      uint8_t* mask, int oc_total, float fill, bool is_max, size_t slab_bytes,
-                      hipStream_t s) {
-  StripArgs sa;
-  memset(&sa, 0, sizeof(sa));
+// Where a launch's camera state comes from: the host's frame records (copied into the kernel
+// arguments, up to kPoseFrames frames per launch) or a device buffer of StripPose records.
+struct PoseSource {
+  const dm_frame* host;       // or NULL
+  const float* dev;           // (B, kPoseFloats) or NULL
+  bool to_global;
+};
+
+inline void fill_poses(StripArgs& sa, const PoseSource& src, int b0, int nb) {
+  sa.b0 = b0;
+  sa.poses_dev = src.dev;
+  if (src.dev) return;
+  for (int i = 0; i < nb; ++i) {
+    const dm_frame& f = src.host[b0 + i];
+    StripPose& q = sa.poses[i];
+    // (a local map: neutral yaw, no translation -- exact: x * 1 + z * 0 + 0)
+    q.y0 = src.to_global ? f.Ry[0] : 1.0f; q.y2 = src.to_global ? f.Ry[2] : 0.0f;
+    q.y6 = src.to_global ? f.Ry[6] : 0.0f; q.y8 = src.to_global ? f.Ry[8] : 1.0f;
+    q.tx = src.to_global ? f.tx : 0.0f; q.tz = src.to_global ? f.tz : 0.0f;
+    q.wo = f.width_offset; q.ho = f.height_offset; q.cam_h = f.cam_height;
+    q.pad0 = q.pad1 = q.pad2 = 0.0f;
+  }
+}
+
+// One pass over the channels of `out`: scatter (+ owned groups straight to the map) and combine,
+// kPoseFrames frames per launch.
+hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const PoseSource& poses,
+                      const Layout& l, const float* depth, const float* value, const uint8_t* valid,
+                      float* out, uint8_t* mask, int oc_total, float fill, bool is_max, size_t slab_bytes,
+                      int* status, hipStream_t s) {
+  thread_local StripArgs sa;       // (3.5 KB: not on the stack of every caller)
+  memset(&sa, 0, offsetof(StripArgs, poses));
   sa.W = p.W; sa.H = p.H;
   sa.clip = p.clip_border > 0 ? p.clip_border : 0;
   sa.flip_h = p.flip_h != 0;
@@ -356,27 +365,20 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
   sa.dmin = p.dmin; sa.dmax = p.dmax;
   sa.hmax = p.has_hmax ? p.hmax : INFINITY;
   sa.Hm1 = (float)(p.H - 1); sa.mhm1 = (float)(p.mh - 1);
+  sa.p4 = rg.pitch[0]; sa.p5 = rg.pitch[1]; sa.p7 = rg.pitch[2]; sa.p8 = rg.pitch[3];
   sa.wp = plan.wp; sa.P = plan.P;
-  // (experiment, off: fill-only workgroups beside the strips' for small batches, DM_X_FILL_TARGET)
-  {
-    const long units = (long)p.B * oc_total;
-    long f = (DM_X_FILL_TARGET + units - 1) / units;
-    if (f > 4 * plan.P) f = 4 * plan.P;
-    if (f > p.mh / 16) f = p.mh / 16;
-    sa.fill_parts = f > plan.P ? (int)f : plan.P;
-  }
   sa.dc = p.dc; sa.valid_c = p.valid_c;
   sa.oc_total = oc_total;
-  sa.slab_stride = rb.slab_cells;
-  sa.max_rows = rb.max_rows;
+  sa.slab_stride = rg.slab_stride;
+  sa.max_rows = rg.max_rows;
+  sa.seg_cap = rg.slab_stride / 4;
   sa.fill = fill;
-  sa.b0 = 0;
-  sa.frames = pv.frames;
   sa.depth = depth; sa.value = value; sa.valid = valid;
   sa.slabs = l.slabs;
   sa.out = out; sa.mask = mask; sa.mh = p.mh; sa.mw = p.mw;
-  sa.g_wins = pv.t.wins; sa.g_unions = pv.t.unions; sa.g_flags = pv.t.flags; sa.g_rows = pv.t.rows;
-  sa.g_reach = pv.t.reach;
+  sa.t = l.t;
+  sa.status = status;
+  sa.rig = rg.args;
 #ifdef DM_STAMPS
   sa.stamps = g_stamp_buffer;
 #endif
@@ -387,50 +389,61 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const dm_frames_plan
                                     : pick_strip_kernel(is_max, has_valid, has_value, plan.lean);
   hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn));
   if (e != hipSuccess) return e;
-  const size_t lds_bytes = strip_lds_bytes(rb.slab_cells, rb.max_rows, p.H);
+  const size_t lds_bytes = strip_lds_bytes(rg.slab_stride, rg.max_rows, p.H, plan.P);
   if (lds_bytes > (size_t)kMaxLdsBytes) return hipErrorNotSupported;
+  StripKernel ifn = nullptr;
   if (from_list) {            // the index pass: every pixel's cell inside its strip's window, once for all channels
-    const StripKernel ifn = pick_index_kernel(has_valid, plan.lean);
+    ifn = pick_index_kernel(has_valid, plan.lean);
     e = raise_lds_limit(reinterpret_cast<const void*>(ifn));
-    if (e != hipSuccess) return e;
-    StripArgs ia = sa;
-    ia.value = nullptr; ia.out = nullptr; ia.mask = nullptr; ia.oc = 1; ia.ch0 = 0; ia.oc_total = 1;
-    ia.fill_parts = plan.P;
-    e = launch(ifn, dim3(plan.P, 1, p.B), dim3(kScatterThreads), lds_bytes, s, ia);
     if (e != hipSuccess) return e;
   }
   // channel groups: the slabs of one group fit the slab region
-  const size_t per_channel = (size_t)p.B * plan.P * rb.slab_cells * 4;
+  const size_t per_channel = (size_t)p.B * plan.P * rg.slab_stride * 4;
+  if (g_strip_slab_budget && slab_bytes > g_strip_slab_budget) slab_bytes = g_strip_slab_budget;
   int group = (int)(slab_bytes / (per_channel ? per_channel : 1));
   if (group < 1) return hipErrorNotSupported;
   if (group > oc_total) group = oc_total;
   if (group > 65535) group = 65535;
-  for (int ch0 = 0; ch0 < oc_total; ch0 += group) {
-    const int oc = oc_total - ch0 < group ? oc_total - ch0 : group;
-    sa.oc = oc; sa.ch0 = ch0;
-    e = launch(kfn, from_list ? dim3(oc, sa.fill_parts, p.B) : dim3(sa.fill_parts, oc, p.B), dim3(kScatterThreads),
-               lds_bytes, s, sa);
-    if (e != hipSuccess) return e;
-    StripCombineArgs ca;
-    ca.b0 = 0; ca.oc = oc; ca.ch0 = ch0; ca.oc_total = oc_total; ca.mh = p.mh; ca.mw = p.mw;
-    ca.P = plan.P; ca.slab_stride = rb.slab_cells; ca.list_cap = list_cap_of(p, rb); ca.fill = fill;
-    ca.g_wins = pv.t.wins; ca.g_unions = pv.t.unions; ca.g_counts = pv.t.counts; ca.g_list = pv.t.list;
-    ca.slabs = l.slabs; ca.out = out; ca.mask = mask;
-    // grid.y = frames * channels <= 65535 per launch
-    const int per_launch = 65535 / oc > 0 ? 65535 / oc : 1;
-    for (int b0 = 0; b0 < p.B; b0 += per_launch) {
-      const int nb = p.B - b0 < per_launch ? p.B - b0 : per_launch;
-      ca.b0 = b0;
-      if (oc_total >= kListMinChannels) {        // (value maps of many channels: four entries per thread)
-        const dim3 g(kCombineSlots / DM_X_COMBINE_ENTRIES, (unsigned)(nb * oc));
-        e = is_max ? launch(k_strip_combine<kMax, DM_X_COMBINE_ENTRIES>, g, dim3(kCombineThreads), 0, s, ca)
-                   : launch(k_strip_combine<kMin, DM_X_COMBINE_ENTRIES>, g, dim3(kCombineThreads), 0, s, ca);
-      } else {
-        const dim3 g(kCombineSlots, (unsigned)(nb * oc));
-        e = is_max ? launch(k_strip_combine_one<kMax>, g, dim3(kCombineThreads), 0, s, ca)
-                   : launch(k_strip_combine_one<kMin>, g, dim3(kCombineThreads), 0, s, ca);
-      }
+  for (int b0 = 0; b0 < p.B; b0 += kPoseFrames) {
+    const int nb = p.B - b0 < kPoseFrames ? p.B - b0 : kPoseFrames;
+    fill_poses(sa, poses, b0, nb);
+    if (from_list) {
+      StripArgs& ia = sa;       // (the same arguments, no maps, one "channel")
+      const float* keep_value = ia.value; float* keep_out = ia.out; uint8_t* keep_mask = ia.mask;
+      ia.value = nullptr; ia.out = nullptr; ia.mask = nullptr; ia.oc = 1; ia.ch0 = 0; ia.oc_total = 1;
+      e = launch(ifn, dim3(plan.P, 1, nb), dim3(kScatterThreads), lds_bytes, s, ia);
+      ia.value = keep_value; ia.out = keep_out; ia.mask = keep_mask; ia.oc_total = oc_total;
       if (e != hipSuccess) return e;
+    }
+    for (int ch0 = 0; ch0 < oc_total; ch0 += group) {
+      const int oc = oc_total - ch0 < group ? oc_total - ch0 : group;
+      sa.oc = oc; sa.ch0 = ch0;
+      e = launch(kfn, from_list ? dim3(oc, plan.P, nb) : dim3(plan.P, oc, nb), dim3(kScatterThreads),
+                 lds_bytes, s, sa);
+      if (e != hipSuccess) return e;
+      StripCombineArgs ca;
+      ca.b0 = b0; ca.oc = oc; ca.ch0 = ch0; ca.oc_total = oc_total; ca.mh = p.mh; ca.mw = p.mw;
+      ca.P = plan.P; ca.slab_stride = rg.slab_stride; ca.seg_cap = sa.seg_cap; ca.fill = fill;
+      ca.g_wins = l.t.wins; ca.g_unions = l.t.unions; ca.g_counts = l.t.counts; ca.g_list = l.t.list;
+      ca.slabs = l.slabs; ca.out = out; ca.mask = mask;
+      // grid.y = frames * channels <= 65535 per launch
+      const int per_launch = 65535 / oc > 0 ? 65535 / oc : 1;
+      for (int c0 = 0; c0 < nb; c0 += per_launch) {
+        const int nc = nb - c0 < per_launch ? nb - c0 : per_launch;
+        ca.b0 = b0 + c0;
+        if (oc_total >= kListMinChannels) {        // (value maps of many channels: four entries per thread)
+          // (at least one block per strip's list segment)
+          const int blocks = kCombineSlots / DM_X_COMBINE_ENTRIES > plan.P ? kCombineSlots / DM_X_COMBINE_ENTRIES : plan.P;
+          const dim3 g(blocks, (unsigned)(nc * oc));
+          e = is_max ? launch(k_strip_combine<kMax, DM_X_COMBINE_ENTRIES>, g, dim3(kCombineThreads), 0, s, ca)
+                     : launch(k_strip_combine<kMin, DM_X_COMBINE_ENTRIES>, g, dim3(kCombineThreads), 0, s, ca);
+        } else {
+          const dim3 g(kCombineSlots > plan.P ? kCombineSlots : plan.P, (unsigned)(nc * oc));
+          e = is_max ? launch(k_strip_combine_one<kMax>, g, dim3(kCombineThreads), 0, s, ca)
+                     : launch(k_strip_combine_one<kMin>, g, dim3(kCombineThreads), 0, s, ca);
+        }
+        if (e != hipSuccess) return e;
+      }
     }
   }
   return hipSuccess;
@@ -442,13 +455,13 @@ thread_local int g_force_legacy = 0;       // dm_debug_force_legacy_window
 
 size_t strip_workspace_extra(const dm_params& p) {
   Plan plan;
-  if (!make_plan(p, plan)) {       // (prepared frames take column strips where a plain call would not: prepare_plan)
+  if (!make_plan(p, plan)) {       // (small batches take column strips where the cost model would cut rows: fallback_plan)
     int strips = (p.W + 39) / 40;
     if (strips > strip::kMaxStrips) strips = strip::kMaxStrips;
     if (strips < 1 || !make_plan(p, plan, strips)) return 0;
   }
   // Value maps: room for the slabs of every channel (up to 2 GiB of address space, touched only
-  // where strips share cells), so that all channels go through ONE scatter + merge launch pair
+  // where strips share cells), so that all channels go through ONE scatter + combine launch pair
   // instead of one pair per group of channels that fits the LDS-window path's 256 MiB.
   size_t more_slabs = 0;
   if (p.vc > 1) {
@@ -456,7 +469,7 @@ size_t strip_workspace_extra(const dm_params& p) {
     more_slabs = per_channel * (size_t)p.vc;
     if (more_slabs > ((size_t)2 << 30)) more_slabs = (size_t)2 << 30;
   }
-  return prepared_bytes(p) + 512 + more_slabs + (list_shape(p) ? pixel_list_bytes(p) : 0);
+  return tables_bytes(p) + lists_bytes_bound(p) + 512 + more_slabs + (list_shape(p) ? pixel_list_bytes(p) : 0);
 }
 
 namespace {
@@ -476,32 +489,33 @@ const Plan* cached_plan(const dm_params& p, int strips = 0) {
   return s.ok ? &s.plan : nullptr;
 }
 
-// The plan and rig the call takes: the cost model's split, or -- when a strip's window would not
-// fit in LDS -- the same image cut into 2, 4, 8 strips.  NULL: the strip path does not apply.
-// A request to PREPARE frames takes column strips even where the cost model of a plain call would
-// split rows or depth (a single small frame: the plain call is cheaper on the window path, whose
-// geometry comes from the host; prepared, the strip path's two launches are all there is): about
-// 40 columns per strip.
-const Plan* prepare_plan(const dm_params& p) {
+// The plan a call starts from: the cost model's split when that is column strips only; where
+// the model would also cut rows or depth -- small batches, whose few workgroups the window path
+// multiplies -- the strip path still takes calls of few frames (its launches carry no table
+// copy): column strips of about 40 pixels.
+constexpr int kSmallBatchPixels = 1 << 20;       // fallback only below this many pixels per call
+const Plan* starting_plan(const dm_params& p, bool prepared) {
   const Plan* plan = cached_plan(p);
   if (plan || g_force_strips) return plan;
+  if (!prepared && (int64_t)p.B * p.H * p.W > kSmallBatchPixels) return nullptr;
   int strips = (p.W + 39) / 40;
   if (strips > strip::kMaxStrips) strips = strip::kMaxStrips;
   return strips >= 1 ? cached_plan(p, strips) : nullptr;
 }
 
-const Plan* plan_and_rig(const dm_params& p, const dm_frame* frames_host, const Rig** rig_out, bool for_prepare = false) {
-  const int magnitude = validate_frames(p, frames_host, p.B);
-  if (magnitude < 0) return nullptr;
-  const Plan* plan = for_prepare ? prepare_plan(p) : cached_plan(p);
+// The plan and rig the call takes: the starting plan, or -- when a strip's window would not fit
+// in LDS -- the same image cut into 2, 4, 8 strips.  NULL: the strip path does not apply.
+const Plan* plan_and_rig(const dm_params& p, const float* pitch4, int magnitude, const Rig** rig_out,
+                         bool prepared = false) {
+  const Plan* plan = starting_plan(p, prepared);
   if (!plan) return nullptr;
-  const Rig* rg = rig_of(p, *plan, frames_host[0], magnitude);
+  const Rig* rg = rig_of(p, *plan, pitch4, magnitude);
   for (int strips = 2; !rg->fits && rg->cfg.cone_ok && strips <= strip::kMaxStrips && !g_force_strips; strips *= 2) {
     if (strips <= plan->P) continue;
     const Plan* narrower = cached_plan(p, strips);
     if (!narrower) break;
     plan = narrower;
-    rg = rig_of(p, *plan, frames_host[0], magnitude);
+    rg = rig_of(p, *plan, pitch4, magnitude);
   }
   *rig_out = rg;
   return rg->fits ? plan : nullptr;
@@ -515,39 +529,30 @@ bool aligned_for_strips(const float* depth, const float* value, const uint8_t* v
          reinterpret_cast<uintptr_t>(value) % 16 == 0;
 }
 
-// [Cfg | status | frame records] of a batch as one block of host memory (thread-local staging).
-const std::vector<unsigned char>& stage_prepared(const dm_params& p, const Rig& rg, const dm_frame* frames_host) {
-  thread_local std::vector<unsigned char> stage;
-  stage.resize(staged_bytes(p));
-  memset(stage.data(), 0, kCfgBytes + kStatusBytes + counts_bytes(p));
-  memcpy(stage.data(), &rg.cfg, sizeof(strip::Cfg));
-  dm_frame* f = reinterpret_cast<dm_frame*>(stage.data() + kCfgBytes + kStatusBytes + counts_bytes(p));
-  memcpy(f, frames_host, (size_t)p.B * sizeof(dm_frame));
-  if (!p.to_global) {       // local map: neutral yaw, no translation (exact: x * 1 + z * 0 + 0)
-    static const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    for (int b = 0; b < p.B; ++b) { memcpy(f[b].Ry, eye, sizeof(eye)); f[b].tx = 0.0f; f[b].tz = 0.0f; }
-  }
-  return stage;
+// Does the workspace hold what the call needs?  (nothing may be enqueued before the answer is yes)
+bool workspace_fits(const dm_params& p, const Plan& plan, const Rig& rg, bool with_height, void* ws,
+                    size_t ws_bytes, Layout& l, size_t& hm) {
+  if (!carve(p, plan.P, rg.slab_stride, ws, ws_bytes, l)) return false;
+  hm = with_height ? up256((size_t)p.B * p.dc * p.mh * p.mw) : 0;
+  return l.slab_bytes >= hm + (size_t)p.B * plan.P * rg.slab_stride * 4;
 }
 
-// The launch sequence proper: nothing here depends on the poses (graph capturable).
-hipError_t launch_strips(const dm_params& p, const Plan& plan, const dm_frames_plan& fp, const PreparedView& pv,
-                         const float* depth, const float* value, const uint8_t* valid, float* out,
-                         uint8_t* mask, float* height, float* fused, uint8_t* fused_mask, void* ws,
-                         size_t ws_bytes, hipEvent_t after_projection, hipStream_t s) {
+// The launch sequence proper: nothing here depends on the poses but the kernel arguments (graph
+// capturable: a captured launch replays the poses it was captured with, or reads them from the
+// device buffer of prepared frames).
+hipError_t launch_strips(const dm_params& p, const Plan& plan, const Rig& rg, const PoseSource& poses,
+                         const Layout& l, size_t hm, const float* depth, const float* value,
+                         const uint8_t* valid, float* out, uint8_t* mask, float* height, float* fused,
+                         uint8_t* fused_mask, int* status, hipEvent_t after_projection, hipStream_t s) {
   const int oc_total = p.vc ? p.vc : p.dc;
-  Layout l;
-  if (!carve(p, ws, ws_bytes, l)) return hipErrorNotSupported;
-  const size_t hm = (height && value) ? up256((size_t)p.B * p.dc * p.mh * p.mw) : 0;
-  if (l.slab_bytes < hm + (size_t)p.B * plan.P * fp.slab_cells * 4) return hipErrorNotSupported;
   const bool is_max = p.reduction == DM_REDUCE_MAX;
-  hipError_t e = strip_pass(p, plan, fp, pv, l, depth, value, valid, out, mask, oc_total, p.fill, is_max,
-                            l.slab_bytes - hm, s);
+  hipError_t e = strip_pass(p, plan, rg, poses, l, depth, value, valid, out, mask, oc_total, p.fill, is_max,
+                            l.slab_bytes - hm, status, s);
   if (e != hipSuccess) return e;
   if (height && value) {      // maps.py:332-350: second projection of the heights, NINF fill, max
     uint8_t* scratch_mask = reinterpret_cast<uint8_t*>(l.slabs) + l.slab_bytes - hm;   // (tail of the slab region)
-    e = strip_pass(p, plan, fp, pv, l, depth, nullptr, valid, height, scratch_mask, p.dc, -INFINITY, true,
-                   l.slab_bytes - hm, s);
+    e = strip_pass(p, plan, rg, poses, l, depth, nullptr, valid, height, scratch_mask, p.dc, -INFINITY, true,
+                   l.slab_bytes - hm, status, s);
     if (e != hipSuccess) return e;
   }
   if (after_projection) {
@@ -558,7 +563,7 @@ hipError_t launch_strips(const dm_params& p, const Plan& plan, const dm_frames_p
     FuseArgs fa;
     fa.B = p.B; fa.b0 = 0; fa.accumulate = 0;
     fa.dc = oc_total; fa.mh = p.mh; fa.mw = p.mw; fa.fill = p.fill;
-    fa.unions = pv.t.unions; fa.maps = out; fa.fused = fused; fa.fused_mask = fused_mask;
+    fa.unions = l.t.unions; fa.maps = out; fa.fused = fused; fa.fused_mask = fused_mask;
     const dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kFuseGroups - 1) / kFuseGroups), oc_total);
     const dim3 blk(kFuseGroups * kFuseLanes);
     e = is_max ? launch(k_fuse_unions<true>, g, blk, 0, s, fa)
@@ -569,20 +574,13 @@ hipError_t launch_strips(const dm_params& p, const Plan& plan, const dm_frames_p
   return hipSuccess;
 }
 
-// k_strip_prepare behind the copy of a batch's camera state: geometry and row tables of every frame.
-hipError_t launch_prepare(const dm_params& p, const dm_frames_plan& fp, const PreparedView& pv, hipStream_t s) {
-  StripPrepArgs pa;
-  pa.cfg = pv.cfg; pa.frames = pv.frames;
-  pa.slab_stride = fp.slab_cells; pa.max_rows = fp.max_rows; pa.mw = p.mw; pa.list_cap = list_cap_of(p, fp);
-  pa.t = pv.t; pa.status = pv.status;
-  return launch(k_strip_prepare, dim3(p.B, kPrepSlices), dim3(kPrepThreads), 0, s, pa);
-}
-
-dm_frames_plan plan_of(const Plan& plan, const Rig& rg) {
+dm_frames_plan plan_of(const Plan& plan, const Rig& rg, int magnitude) {
   dm_frames_plan fp;
   memset(&fp, 0, sizeof(fp));
   fp.strips = plan.P; fp.strip_width = plan.wp; fp.slab_cells = rg.slab_stride;
   fp.max_rows = rg.max_rows; fp.max_union_cells = rg.max_union; fp.slack_cells = rg.slack;
+  fp.magnitude = magnitude;
+  memcpy(fp.pitch, rg.pitch, sizeof(fp.pitch));
   return fp;
 }
 
@@ -592,71 +590,89 @@ dm_frames_plan plan_of(const Plan& plan, const Rig& rg) {
 hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const float* depth,
                      const float* value, const uint8_t* valid, float* out, uint8_t* mask,
                      float* height, float* fused, uint8_t* fused_mask, void* ws, size_t ws_bytes,
-                     hipEvent_t before_projection, hipEvent_t after_projection, hipStream_t s) {
+                     int* status, hipEvent_t before_projection, hipEvent_t after_projection, hipStream_t s) {
   if (g_force_legacy || p.B > 65535) return hipErrorNotSupported;
   if (!aligned_for_strips(depth, value, valid, out, mask, height, fused, fused_mask)) return hipErrorNotSupported;
+  const int magnitude = validate_frames(p, frames_host, p.B);
+  if (magnitude < 0) return hipErrorNotSupported;
+  const float pitch4[4] = {frames_host[0].Rp[4], frames_host[0].Rp[5], frames_host[0].Rp[7], frames_host[0].Rp[8]};
   const Rig* rg = nullptr;
-  const Plan* plan = plan_and_rig(p, frames_host, &rg);
+  const Plan* plan = plan_and_rig(p, pitch4, magnitude, &rg);
   if (!plan) return hipErrorNotSupported;
-  const size_t head = prepared_bytes(p);
-  if (reinterpret_cast<uintptr_t>(ws) % 256 != 0 || ws_bytes < head) return hipErrorNotSupported;
-  const dm_frames_plan fp = plan_of(*plan, *rg);
-  {   // would the rest fit?  (nothing may be enqueued before the answer is yes)
-    Layout l;
-    if (!carve(p, static_cast<unsigned char*>(ws) + head, ws_bytes - head, l)) return hipErrorNotSupported;
-    const size_t hm = (height && value) ? up256((size_t)p.B * p.dc * p.mh * p.mw) : 0;
-    if (l.slab_bytes < hm + (size_t)p.B * plan->P * fp.slab_cells * 4) return hipErrorNotSupported;
-  }
-  hipError_t e = hipSuccess;
-  if (before_projection) {
-    e = hipEventRecord(before_projection, s);
-    if (e != hipSuccess) return e;
-  }
-  // one stream-ordered copy (the runtime has copied pageable memory out by the time it returns)
-  const std::vector<unsigned char>& stage = stage_prepared(p, *rg, frames_host);
-  e = hipMemcpyAsync(ws, stage.data(), stage.size(), hipMemcpyHostToDevice, s);
-  if (e != hipSuccess) return e;
-  e = launch_prepare(p, fp, view_prepared(p, ws), s);
-  if (e != hipSuccess) return e;
-  return launch_strips(p, *plan, fp, view_prepared(p, ws), depth, value, valid, out, mask, height, fused,
-                       fused_mask, static_cast<unsigned char*>(ws) + head, ws_bytes - head, after_projection, s);
-}
-
-size_t strip_prepared_bytes(const dm_params& p) { return prepare_plan(p) ? prepared_bytes(p) : 0; }
-
-// dm_frames_prepare_f32: validate the batch's camera state, size the launches, upload, and derive
-// the frames' geometry and row tables on the device (k_strip_prepare).
-hipError_t strip_prepare(const dm_params& p, const dm_frame* frames_host, void* prepared_dev,
-                         size_t prepared_size, dm_frames_plan* plan_out, hipStream_t s) {
-  if (g_force_legacy || p.B > 65535 || p.B < 1) return hipErrorNotSupported;
-  const Rig* rg = nullptr;
-  const Plan* plan = plan_and_rig(p, frames_host, &rg, true);
-  if (!plan) return hipErrorNotSupported;
-  if (reinterpret_cast<uintptr_t>(prepared_dev) % 256 != 0 || prepared_size < prepared_bytes(p))
-    return hipErrorInvalidValue;
-  *plan_out = plan_of(*plan, *rg);
-  const std::vector<unsigned char>& stage = stage_prepared(p, *rg, frames_host);
-  const hipError_t e = hipMemcpyAsync(prepared_dev, stage.data(), stage.size(), hipMemcpyHostToDevice, s);
-  if (e != hipSuccess) return e;
-  return launch_prepare(p, *plan_out, view_prepared(p, prepared_dev), s);
-}
-
-// dm_orth_project_prepared_f32
-hipError_t run_strip_prepared(const dm_params& p, const dm_frames_plan& fp, void* prepared_dev,
-                              const float* depth, const float* value, const uint8_t* valid, float* out,
-                              uint8_t* mask, float* height, float* fused, uint8_t* fused_mask, void* ws,
-                              size_t ws_bytes, hipEvent_t before_projection, hipEvent_t after_projection,
-                              hipStream_t s) {
-  if (!aligned_for_strips(depth, value, valid, out, mask, height, fused, fused_mask)) return hipErrorNotSupported;
-  const Plan* plan = cached_plan(p);
-  if (!plan || plan->P != fp.strips) plan = cached_plan(p, fp.strips);
-  if (!plan || plan->P != fp.strips || plan->wp != fp.strip_width) return hipErrorNotSupported;
+  Layout l;
+  size_t hm = 0;
+  if (!workspace_fits(p, *plan, *rg, height && value, ws, ws_bytes, l, hm)) return hipErrorNotSupported;
   if (before_projection) {
     const hipError_t e = hipEventRecord(before_projection, s);
     if (e != hipSuccess) return e;
   }
-  return launch_strips(p, *plan, fp, view_prepared(p, prepared_dev), depth, value, valid, out, mask, height,
-                       fused, fused_mask, ws, ws_bytes, after_projection, s);
+  const PoseSource poses = {frames_host, nullptr, p.to_global != 0};
+  return launch_strips(p, *plan, *rg, poses, l, hm, depth, value, valid, out, mask, height, fused, fused_mask,
+                       status, after_projection, s);
+}
+
+size_t strip_prepared_bytes(const dm_params& p) {
+  return starting_plan(p, true) ? up256((size_t)p.B * sizeof(StripPose)) : 0;
+}
+
+// dm_frames_prepare_f32: validate the batch's camera state, size the launches (the plan) and --
+// only when that plan is the one the caller expects, if it expects one -- upload the frames' pose
+// records.  Nothing is enqueued otherwise.
+hipError_t strip_prepare(const dm_params& p, const dm_frame* frames_host, void* prepared_dev,
+                         size_t prepared_size, const dm_frames_plan* must_match, dm_frames_plan* plan_out,
+                         hipStream_t s) {
+  if (g_force_legacy || p.B > 65535 || p.B < 1) return hipErrorNotSupported;
+  const int magnitude = validate_frames(p, frames_host, p.B);
+  if (magnitude < 0) return hipErrorNotSupported;
+  const float pitch4[4] = {frames_host[0].Rp[4], frames_host[0].Rp[5], frames_host[0].Rp[7], frames_host[0].Rp[8]};
+  const Rig* rg = nullptr;
+  const Plan* plan = plan_and_rig(p, pitch4, magnitude, &rg, true);
+  if (!plan) return hipErrorNotSupported;
+  if (reinterpret_cast<uintptr_t>(prepared_dev) % 256 != 0 || prepared_size < up256((size_t)p.B * sizeof(StripPose)))
+    return hipErrorInvalidValue;
+  const dm_frames_plan fp = plan_of(*plan, *rg, quantised_magnitude(magnitude));
+  if (must_match && memcmp(must_match, &fp, sizeof(fp)) != 0) return hipErrorInvalidConfiguration;
+  *plan_out = fp;
+  thread_local std::vector<StripPose> stage;
+  stage.resize(p.B);
+  for (int b0 = 0; b0 < p.B; ++b0) {
+    const dm_frame& f = frames_host[b0];
+    StripPose& q = stage[b0];
+    const bool g = p.to_global != 0;
+    q.y0 = g ? f.Ry[0] : 1.0f; q.y2 = g ? f.Ry[2] : 0.0f; q.y6 = g ? f.Ry[6] : 0.0f; q.y8 = g ? f.Ry[8] : 1.0f;
+    q.tx = g ? f.tx : 0.0f; q.tz = g ? f.tz : 0.0f;
+    q.wo = f.width_offset; q.ho = f.height_offset; q.cam_h = f.cam_height;
+    q.pad0 = q.pad1 = q.pad2 = 0.0f;
+  }
+  // one stream-ordered copy (the runtime has copied pageable memory out by the time it returns)
+  return hipMemcpyAsync(prepared_dev, stage.data(), (size_t)p.B * sizeof(StripPose), hipMemcpyHostToDevice, s);
+}
+
+// dm_orth_project_prepared_f32
+hipError_t run_strip_prepared(const dm_params& p, const dm_frames_plan& fp, const void* prepared_dev,
+                              const float* depth, const float* value, const uint8_t* valid, float* out,
+                              uint8_t* mask, float* height, float* fused, uint8_t* fused_mask, void* ws,
+                              size_t ws_bytes, int* status, hipEvent_t before_projection,
+                              hipEvent_t after_projection, hipStream_t s) {
+  if (!aligned_for_strips(depth, value, valid, out, mask, height, fused, fused_mask)) return hipErrorNotSupported;
+  const Plan* plan = cached_plan(p);
+  if (!plan || plan->P != fp.strips) plan = cached_plan(p, fp.strips);
+  if (!plan || plan->P != fp.strips || plan->wp != fp.strip_width) return hipErrorNotSupported;
+  const Rig* rg = rig_of(p, *plan, fp.pitch, fp.magnitude);
+  // (the plan the caller holds must be the one these parameters give: sizes of LDS tables and slabs)
+  if (!rg->fits || rg->slab_stride != fp.slab_cells || rg->max_rows != fp.max_rows ||
+      rg->max_union != fp.max_union_cells || rg->slack != fp.slack_cells)
+    return hipErrorNotSupported;
+  Layout l;
+  size_t hm = 0;
+  if (!workspace_fits(p, *plan, *rg, height && value, ws, ws_bytes, l, hm)) return hipErrorNotSupported;
+  if (before_projection) {
+    const hipError_t e = hipEventRecord(before_projection, s);
+    if (e != hipSuccess) return e;
+  }
+  const PoseSource poses = {nullptr, static_cast<const float*>(prepared_dev), p.to_global != 0};
+  return launch_strips(p, *plan, *rg, poses, l, hm, depth, value, valid, out, mask, height, fused, fused_mask,
+                       status, after_projection, s);
 }
 
 }  // namespace dm
@@ -670,6 +686,12 @@ extern "C" __attribute__((visibility("default"))) int dm_debug_force_strips(int 
 extern "C" __attribute__((visibility("default"))) int dm_debug_strip_value_list(int on) {
   const int old = !dm::g_no_value_list;
   dm::g_no_value_list = on == 0;
+  return old;
+}
+
+extern "C" __attribute__((visibility("default"))) size_t dm_debug_strip_slab_budget(size_t bytes) {
+  const size_t old = dm::g_strip_slab_budget;
+  dm::g_strip_slab_budget = bytes;
   return old;
 }
 
@@ -698,7 +720,8 @@ extern "C" __attribute__((visibility("default"))) int dm_debug_strip_geometry(
     return plan.P;
   }
   Rig rg = {};
-  compute_rig(*p, plan, frames[0], magnitude < (1 << 18) ? (1 << 18) : magnitude + (1 << 17), rg);
+  const float pitch4[4] = {frames[0].Rp[4], frames[0].Rp[5], frames[0].Rp[7], frames[0].Rp[8]};
+  compute_rig(*p, plan, pitch4, quantised_magnitude(magnitude), rg);
   if (out_bound) {
     out_bound[0] = rg.slack; out_bound[1] = rg.fits; out_bound[2] = rg.slab_stride;
     out_bound[3] = rg.max_rows; out_bound[4] = rg.max_union;
@@ -706,7 +729,7 @@ extern "C" __attribute__((visibility("default"))) int dm_debug_strip_geometry(
   const int stride = 8 + 4 * strip::kMaxStrips;
   for (int b = 0; b < p->B; ++b) {
     dm_frame f = frames[b];
-    if (!p->to_global) {      // as staged for the device: neutral yaw, no translation
+    if (!p->to_global) {      // as passed to the device: neutral yaw, no translation
       static const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
       memcpy(f.Ry, eye, sizeof(eye)); f.tx = 0.0f; f.tz = 0.0f;
     }
@@ -725,6 +748,7 @@ extern "C" __attribute__((visibility("default"))) int dm_debug_strip_geometry(
       const int P2 = plan.P <= 4 ? 4 : 8;
       for (int z = 0; z < p->mh; ++z) {
         for (int s = 0; s < plan.P; ++s) cover[s] = strip::row_cover(g.win[s], g.L[s], g.R[s], z, p->mw);
+        for (int s = plan.P; s < strip::kMaxStrips; ++s) cover[s] = 0u;
         for (int s = 0; s < plan.P; ++s) {
           uint32_t* o2 = out_covers + (((size_t)b * p->mh + z) * plan.P + s) * 2;
           o2[0] = cover[s];
@@ -736,10 +760,10 @@ extern "C" __attribute__((visibility("default"))) int dm_debug_strip_geometry(
   return plan.P;
 }
 
-// GPU: the same geometry from k_strip_geometry_dump (the device's lane-parallel evaluation),
-// for the test that host and device agree bit for bit.  frames_dev (B, 32) f32 (a local map's
-// records with a neutral yaw), frames_host: the same records on the host (for the rig);
-// geom_dev: B * sizeof(FrameGeom) + 1024 bytes of device scratch.
+// GPU: the same geometry from k_strip_geometry_dump (the device's lane-parallel evaluation, the
+// function the scatter kernel's head runs), for the test that host and device agree bit for bit.
+// frames_dev (B, 32) f32 (a local map's records with a neutral yaw), frames_host: the same records
+// on the host (for the rig); geom_dev: B * sizeof(FrameGeom) + B * 48 bytes of device scratch.
 extern "C" __attribute__((visibility("default"))) int dm_debug_strip_geometry_dev(
     const dm_params* p, const dm_frame* frames_host, const float* frames_dev, void* geom_dev,
     size_t geom_bytes, void* stream) {
@@ -750,15 +774,14 @@ extern "C" __attribute__((visibility("default"))) int dm_debug_strip_geometry_de
   const int magnitude = validate_frames(*p, frames_host, p->B);
   if (magnitude < 0) return 0;
   Rig rg = {};
-  compute_rig(*p, plan, frames_host[0], magnitude < (1 << 18) ? (1 << 18) : magnitude + (1 << 17), rg);
-  const size_t need = (size_t)p->B * sizeof(strip::FrameGeom) + kCfgBytes;
+  const float pitch4[4] = {frames_host[0].Rp[4], frames_host[0].Rp[5], frames_host[0].Rp[7], frames_host[0].Rp[8]};
+  compute_rig(*p, plan, pitch4, quantised_magnitude(magnitude), rg);
+  const size_t need = (size_t)p->B * sizeof(strip::FrameGeom) + (size_t)p->B * sizeof(StripPose);
   if (geom_bytes < need) return -(int)need;
-  strip::Cfg* cfg_dev = reinterpret_cast<strip::Cfg*>(static_cast<unsigned char*>(geom_dev) +
-                                                      (size_t)p->B * sizeof(strip::FrameGeom));
+  float* poses_dev = reinterpret_cast<float*>(static_cast<unsigned char*>(geom_dev) + (size_t)p->B * sizeof(strip::FrameGeom));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (hipMemcpyAsync(cfg_dev, &rg.cfg, sizeof(strip::Cfg), hipMemcpyHostToDevice, s) != hipSuccess) return -2;
-  if (hipStreamSynchronize(s) != hipSuccess) return -2;       // (rg is a local)
-  hipLaunchKernelGGL(k_strip_geometry_dump, dim3(p->B), dim3(64), 0, s, cfg_dev, frames_dev,
+  hipLaunchKernelGGL(k_pose_records, dim3((p->B + 63) / 64), dim3(64), 0, s, frames_dev, poses_dev, p->B);
+  hipLaunchKernelGGL(k_strip_geometry_dump, dim3(p->B), dim3(64), 0, s, rg.args, poses_dev,
                      static_cast<strip::FrameGeom*>(geom_dev));
   return hipGetLastError() == hipSuccess ? plan.P : -2;
 }

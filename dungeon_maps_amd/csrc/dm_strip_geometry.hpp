@@ -57,6 +57,33 @@ struct Cfg {
   float czl[kMaxStrips][8];
 };
 
+// The same pose-independent inputs as the kernels take them -- by value, in their kernel
+// arguments, so that a launch needs no table in device memory: Cfg without its corner tables,
+// which every lane derives for its strip with the host's expressions (strip_corners).
+struct RigArgs {
+  int P, mw, mh, flip_h, cone_ok;
+  int live_mask;                // bit s: strip s has pixels left after clip_border
+  float inv, reach;
+  float g0, g1;                 // z1 = g * depth at the extreme live rows (cfg_rig)
+  float dmin, dmax;
+  float ax_lo[kMaxStrips], ax_hi[kMaxStrips];     // ray slopes of each strip's first / last live column
+  float tmin[kMaxStrips], tmax[kMaxStrips];
+};
+
+// Corners of a strip's truncated cone in the camera's local frame, in cells (index bit 0 =
+// near/far, bit 1 = ax lo/hi, bit 2 = ay lo/hi): one expression for host and device.
+__host__ __device__ inline void strip_corners(float ax_lo, float ax_hi, float g0, float g1, float dmin,
+                                              float dmax, float inv, float* cx, float* cz) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float d = (k & 1) ? dmax : dmin;
+    const float ax = (k & 2) ? ax_hi : ax_lo;
+    const float g = (k & 4) ? g1 : g0;
+    cx[k] = ax * d * inv;
+    cz[k] = g * d * inv;
+  }
+}
+
 // One frame's geometry (L1): windows and cone edges of every strip.
 // Edge lines in cell coordinates: a cell centre (x, z) is inside the widened cone of strip p
 // iff  L.nx * x + L.nz * z + L.k >= 0  and  R.nx * x + R.nz * z + R.k >= 0.
@@ -101,15 +128,27 @@ __host__ inline void cfg_rig(Cfg& c, const float* Rp, const float* ax_lo, const 
       c.tmin[s] = fmin2(fmin2(t0, t1), fmin2(t2, t3));
       c.tmax[s] = fmax2(fmax2(t0, t1), fmax2(t2, t3));
     }
-    for (int k = 0; k < 8; ++k) {
-      const float d = (k & 1) ? dmax : dmin;
-      const float ax = (k & 2) ? ax_hi[s] : ax_lo[s];
-      const float g = (k & 4) ? g1 : g0;
-      c.cxl[s][k] = ax * d * c.inv;
-      c.czl[s][k] = g * d * c.inv;
-    }
+    strip_corners(ax_lo[s], ax_hi[s], g0, g1, dmin, dmax, c.inv, c.cxl[s], c.czl[s]);
   }
   c.reach = dmax * c.inv * (amax + gmax);
+}
+
+// The kernel-argument form of a Cfg (same values; the corners are re-derived on the device).
+__host__ inline RigArgs rig_args(const Cfg& c, const float* Rp, const float* ax_lo, const float* ax_hi,
+                                 float ay_lo, float ay_hi, float dmin, float dmax) {
+  RigArgs r;
+  r.P = c.P; r.mw = c.mw; r.mh = c.mh; r.flip_h = c.flip_h; r.cone_ok = c.cone_ok;
+  r.live_mask = 0;
+  r.inv = c.inv; r.reach = c.reach;
+  r.g0 = Rp[5] * ay_lo + Rp[8]; r.g1 = Rp[5] * ay_hi + Rp[8];
+  r.dmin = dmin; r.dmax = dmax;
+  for (int s = 0; s < kMaxStrips; ++s) {
+    const bool on = s < c.P && c.live[s];
+    r.live_mask |= on ? 1 << s : 0;
+    r.ax_lo[s] = on ? ax_lo[s] : 0.0f; r.ax_hi[s] = on ? ax_hi[s] : 0.0f;
+    r.tmin[s] = c.tmin[s]; r.tmax[s] = c.tmax[s];
+  }
+  return r;
 }
 
 // The pose-dependent rest: the yaw rotation's four entries (identity for a local map), the
@@ -120,7 +159,8 @@ __host__ inline void cfg_rig(Cfg& c, const float* Rp, const float* ax_lo, const 
 // slack grows with the magnitude (16 ulp_f32), and past 16 cells the strip path is not used.
 struct Pose { float y0, y2, y6, y8, xd, zd, slack; int ok; };
 
-__host__ __device__ inline Pose pose_of(const Cfg& c, float y0, float y2, float y6, float y8, float tx,
+template <class C>
+__host__ __device__ inline Pose pose_of(const C& c, float y0, float y2, float y6, float y8, float tx,
                                         float tz, float wo, float ho) {
   Pose p;
   const float fs = c.flip_h ? -1.0f : 1.0f;                 // maps.py:1006-1009: zf -> (mh - 1) - zf
@@ -138,7 +178,8 @@ __host__ __device__ inline Pose pose_of(const Cfg& c, float y0, float y2, float 
 }
 
 // Window from the bounding box [lx, hx] x [lz, hz] of the eight corners.
-__host__ __device__ inline Win16 window_of(const Cfg& c, float lx, float hx, float lz, float hz,
+template <class C>
+__host__ __device__ inline Win16 window_of(const C& c, float lx, float hx, float lz, float hz,
                                            float slack, bool& inside) {
   float x0 = floorf(floorf(lx + 0.5f) - slack), x1 = ceilf(floorf(hx + 0.5f) + slack + 1.0f);
   float z0 = floorf(floorf(lz + 0.5f) - slack), z1 = ceilf(floorf(hz + 0.5f) + slack + 1.0f);
@@ -158,7 +199,8 @@ __host__ __device__ inline Win16 window_of(const Cfg& c, float lx, float hx, flo
 // Edge line of the cone through A with direction D = t * U + F (U, F: the camera's right /
 // forward vectors in cells per metre).  left: the edge at tmin (inside: t >= tmin), else the
 // edge at tmax.  The margin (half a cell plus the slack, in the line's own units) is in k.
-__host__ __device__ inline Line cone_edge(const Cfg& c, const Pose& p, float t, bool left) {
+template <class C>
+__host__ __device__ inline Line cone_edge(const C& c, const Pose& p, float t, bool left) {
   const float Dx = (t * p.y0 + p.y6) * c.inv, Dz = (t * p.y2 + p.y8) * c.inv;
   // sgn = sign of cr(F, U) = y6 * y2 - y8 * y0 (orientation: flips with flip_h)
   const float sgn = (p.y6 * p.y2 - p.y8 * p.y0) < 0.0f ? -1.0f : 1.0f;
@@ -171,7 +213,8 @@ __host__ __device__ inline Line cone_edge(const Cfg& c, const Pose& p, float t, 
 }
 
 // One strip's window and cone edges for a pose: the strip's local corners rotated by the yaw.
-__host__ __device__ inline void strip_geometry(const Cfg& c, const Pose& p, const float* cxl,
+template <class C>
+__host__ __device__ inline void strip_geometry(const C& c, const Pose& p, const float* cxl,
                                                const float* czl, float tmin, float tmax, bool live,
                                                Win16& w, Line& L, Line& R, bool& inside) {
   float lx = INFINITY, hx = -INFINITY, lz = INFINITY, hz = -INFINITY;

@@ -1,16 +1,19 @@
-// Device side of the strip path (dm_strip.hip launches it): k_strip_prepare, k_strip_scatter,
-// k_strip_combine.  Same pixel arithmetic and LDS-window scatter as k_window_scatter
-// (dm_window_kernels.hpp), but
-//   * the geometry (windows, cone edges, per-row covers: dm_strip_geometry.hpp) is derived ON
-//     THE DEVICE from the frame records, by k_strip_prepare -- nothing of a call is computed
-//     on the host, so the launch sequence depends only on pointers and call-wide constants
-//     (graph capturable), and with prepared frames it is derived once per set of poses;
+// Device side of the strip path (dm_strip.hip launches it): k_strip_scatter and k_strip_combine.
+// Same pixel arithmetic and LDS-window scatter as k_window_scatter (dm_window_kernels.hpp), but
+//   * a launch is STATELESS: the camera state of its (up to kPoseFrames) frames travels in the
+//     kernel arguments (48 bytes per frame: yaw entries, translation, offsets, camera height),
+//     or is read from a caller's device buffer (prepared frames) -- no table is staged to the
+//     device and no kernel runs in front of the scatter kernel;
+//   * the geometry (windows, cone edges, per-row covers: dm_strip_geometry.hpp) is derived by
+//     every workgroup for its own frame, in the kernel's head, straight into LDS;
 //   * every float4 group of a strip's window that no other strip can reach is written
 //     straight from LDS to the map; only groups two or more strips can reach go through a
-//     slab, and k_strip_combine visits exactly those (a list k_strip_prepare leaves behind);
+//     slab, and k_strip_combine visits exactly those -- the strips list them while they flush;
 //   * the rest of the map -- everything outside the hull of the covers on each row -- gets
 //     the fill value from the scatter kernel's fill duty.
 #pragma once
+
+#include <stddef.h>
 
 #include "dm_strip_geometry.hpp"
 #include "dm_window_kernels.hpp"
@@ -20,201 +23,145 @@ namespace {
 
 static_assert(sizeof(strip::FrameGeom) == 336, "FrameGeom layout (tests/test_hip_strip.py reads it)");
 
-// LDS of k_strip_scatter, in floats: [window region: slab_stride | 64 scratch cells |
-// this strip's row entries: 2 * max_rows | the rows' reach spans: 2 * max_rows | ray slopes of
-// the image rows: H].
-__host__ __device__ inline size_t strip_lds_bytes(int slab_cells, int max_rows, int H) {
-  return ((size_t)slab_cells + 64 + 4 * (size_t)max_rows + (size_t)H + 4) * 4;
-}
-
-// L1 geometry of one frame by ONE wave: lane s < kMaxStrips derives strip s (the same calls as
-// strip::frame_geometry, the host's serial version), the union window is reduced over the lanes.
-// y0..ho: the frame record's yaw entries, translation and offsets.
-__device__ inline void strip_geometry_wave(const strip::Cfg& c, float y0, float y2, float y6, float y8,
-                                           float tx, float tz, float wo, float ho, int lane,
-                                           strip::FrameGeom* g) {
-  using namespace strip;
-  const int s = lane < kMaxStrips ? lane : kMaxStrips - 1;
-  float cx[8], cz[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { cx[k] = c.cxl[s][k]; cz[k] = c.czl[s][k]; }
-  const float tmin = c.tmin[s], tmax = c.tmax[s];
-  const bool live = (lane < c.P) & (c.live[s] != 0);
-  const Pose p = pose_of(c, y0, y2, y6, y8, tx, tz, wo, ho);
-  Win16 w;
-  Line L, R;
-  bool in = false;
-  strip_geometry(c, p, cx, cz, tmin, tmax, live, w, L, R, in);
-  if (lane < kMaxStrips) { g->win[lane] = w; g->L[lane] = L; g->R[lane] = R; }
-  const unsigned long long in_mask = __builtin_amdgcn_ballot_w64(in & (lane < kMaxStrips));
-  const bool some = (lane < kMaxStrips) & (w.w > 0);
-  int ux0 = some ? w.x0 : 32767, ux1 = some ? w.x0 + w.w : 0;
-  int uz0 = some ? w.z0 : 32767, uz1 = some ? w.z0 + w.h : 0;
-#pragma unroll
-  for (int m = 1; m < kMaxStrips; m <<= 1) {
-    ux0 = min(ux0, __shfl_xor(ux0, m, 64)); ux1 = max(ux1, __shfl_xor(ux1, m, 64));
-    uz0 = min(uz0, __shfl_xor(uz0, m, 64)); uz1 = max(uz1, __shfl_xor(uz1, m, 64));
-  }
-  if (lane == 0) {
-    g->U = ux1 > ux0 ? Win16{(short)ux0, (short)uz0, (short)(ux1 - ux0), (short)(uz1 - uz0)}
-                     : Win16{0, 0, 0, 0};
-    g->ok = p.ok;
-    g->inside = (int)(in_mask & 0xffu);
-  }
-}
-
-// What k_strip_prepare leaves in device memory for a batch ("frame tables"): read-only for
-// k_strip_scatter, k_strip_combine and the batch fuse.
-struct FrameTables {
-  Win16* wins;                // (B, kMaxStrips)
-  Win16* unions;              // (B)   union windows, x in whole kSpanAlign groups
-  int* flags;                 // (B)   FrameGeom::inside
-  int* counts;                // (B)   entries of the frame's shared-group list (may exceed list_cap: clamp)
-  strip::RowEntry* rows;      // (B, max_rows, P)   per row and strip: cover, owned
-  uint2* reach;               // (B, max_rows)      per row: {lo, width} of the hull of the covers
-  uint32_t* list;             // (B, list_cap)      the groups of the reach spans nobody owns
-};
-
-// An entry of a frame's shared-group list: row of the union window (12 bits), float4 group of the
+// An entry of a strip's shared-group list: row of the union window (12 bits), float4 group of the
 // union window's row (12 bits), bit s of the top byte: strip s's cover holds the group.
 __host__ __device__ inline uint32_t pack_shared(int row, int group, uint32_t hits) {
   return (uint32_t)row | ((uint32_t)group << 12) | (hits << 24);
 }
 constexpr int kListMaxRows = 4096, kListMaxGroups = 4096;
 
-struct StripPrepArgs {
-  const strip::Cfg* cfg;      // device copy (in front of the frame records)
-  const float* frames;        // (B, 32) dm_frame records in device memory
-  int slab_stride, max_rows, mw, list_cap;
-  FrameTables t;
-  int* status;                // set non-zero when a frame's geometry does not fit the launch plan
+// Camera state of one frame as the kernels read it (dm_frame without what the batch shares:
+// the pitch rotation lives in StripArgs).
+constexpr int kPoseFloats = 12;
+constexpr int kPoseFrames = 64;                // frames per launch: 3 KB of kernel arguments
+struct StripPose { float y0, y2, y6, y8, tx, tz, wo, ho, cam_h, pad0, pad1, pad2; };
+static_assert(sizeof(StripPose) == kPoseFloats * 4, "pose record");
+
+// L1 geometry of one frame as k_strip_scatter keeps it in LDS (the values of strip::FrameGeom,
+// laid out for 16-byte reads).
+struct alignas(16) GeomLds {
+  Win16 win[strip::kMaxStrips];
+  strip::Line L[strip::kMaxStrips], R[strip::kMaxStrips];
+  Win16 U;                    // bounding box of the windows
+  int ok, inside;             // FrameGeom::ok, FrameGeom::inside
+  // list entries of this strip per chunk of 64 rows of the union window (then: before the chunk);
+  // [kListMaxRows / 64]: all of them
+  int chunk_entries[kListMaxRows / 64 + 1];
+  int pad[3];
 };
+constexpr int kGeomFloats = sizeof(GeomLds) / 4;
+static_assert(sizeof(GeomLds) % 16 == 0, "GeomLds size");
 
-constexpr int kPrepThreads = 1024;
-constexpr int kPrepLanes = 16;                 // lanes per row of the union window (>= kMaxStrips)
-static_assert(kPrepLanes >= strip::kMaxStrips, "one lane per strip");
-static_assert(4096 >= kListMaxGroups, "a row's groups fit the LDS list");
-constexpr int kPrepSlices = 4;                 // workgroups per frame, each a band of the union window's rows
-constexpr int kPrepListLds = 4096;             // list entries a workgroup collects in LDS before it appends them (>= the groups of a row)
+// LDS of k_strip_scatter, in floats: [window region: slab_stride | 64 scratch cells | the
+// covers of all strips on every row of the union window: (4 or 8) * max_rows | this strip's owned
+// spans: max_rows | the rows' reach spans: 2 * max_rows | where each row's list entries go:
+// max_rows | ray slopes of the image rows: H | the frame's geometry and list bookkeeping (GeomLds)].
+__host__ __device__ inline int strips_pow2(int P) { return P <= 4 ? 4 : 8; }     // row stride of the cover table
+__host__ __device__ inline size_t strip_lds_bytes(int slab_cells, int max_rows, int H, int P) {
+  return ((size_t)slab_cells + 64 + (size_t)(strips_pow2(P) + 4) * (size_t)max_rows + (size_t)H + 4) * 4 + sizeof(GeomLds) + 16;
+}
 
-// kPrepSlices workgroups per frame: the frame's geometry (wave 0 of each) and, for the
-// workgroup's band of rows of the union window, the row table -- cover and owned span of every
-// strip (thread = (row, strip), the strips of a row in neighbouring lanes, which exchange their
-// covers by shuffles), the hull of the covers per row ("reach": outside it the map holds the
-// fill value) and the list of the float4 groups inside the hulls that no strip owns (several
-// strips reach them, or none: what is left to combine after the strips have written their own
-// groups; collected in LDS, appended with one atomic per workgroup to the frame's list, whose
-// counter the host zeroed with the staged copy).  Runs once per set of poses
-// (dm_frames_prepare_f32) or in front of the projection kernels (dm_orth_project_f32).
-__global__ void __launch_bounds__(kPrepThreads)
-k_strip_prepare(StripPrepArgs a) {
-  __shared__ strip::FrameGeom geom;
-  __shared__ int listed, list_base;
-  __shared__ uint32_t found[kPrepListLds];
-  const int b = blockIdx.x, slice = blockIdx.y;
-  const float* f = a.frames + (size_t)b * 32;
-  if (threadIdx.x == 0) listed = 0;
-  if (threadIdx.x < 64)
-    strip_geometry_wave(*a.cfg, f[10], f[12], f[16], f[18], f[19], f[20], f[21], f[22], (int)threadIdx.x, &geom);
-  __syncthreads();
-  const int nparts = a.cfg->P;
-  Window U = widen(geom.U);
-  {   // the union window in whole span groups (covers reach that far)
-    const int ux1 = min((U.x0 + U.w + strip::kSpanAlign - 1) & ~(strip::kSpanAlign - 1), a.mw);
-    U.x0 &= ~(strip::kSpanAlign - 1);
-    U.w = U.w > 0 ? ux1 - U.x0 : 0;
+// Cross-lane moves as DPP modifiers of VALU instructions (no LDS crossbar round trip).
+// quad_perm [1,0,3,2] = 0xB1 (lane ^ 1), [2,3,0,1] = 0x4E (lane ^ 2), row_half_mirror = 0x141
+// (lane -> 7 - lane within 8), row_mirror = 0x140 (lane -> 15 - lane within 16), row_shr:n = 0x110 + n,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL>
+__device__ inline float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ inline int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+// min / max over aligned groups of 8 lanes, the result in every lane of the group
+__device__ inline float min8(float v) {
+  v = fminf(v, dpp_f<0xB1>(v)); v = fminf(v, dpp_f<0x4E>(v)); return fminf(v, dpp_f<0x141>(v));
+}
+__device__ inline float max8(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); return fmaxf(v, dpp_f<0x141>(v));
+}
+// inclusive prefix sum over the 64 lanes of a wave (the scan of LLVM's atomic optimizer for GFX9)
+__device__ inline int wave_inclusive_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
+// The geometry of one frame by ONE wave, all 64 lanes: lane = strip * 8 + corner.  Same float32
+// operations as strip::frame_geometry (the host's serial version): the corners from
+// strip::strip_corners' expressions, rotated as strip::strip_geometry does, their bounding box
+// reduced over a strip's eight lanes (min / max of finite values: order independent), the window
+// and the two cone edges by the calls the host makes.  Lane 8 s stores strip s.
+__device__ inline void frame_geometry_wave64(const strip::RigArgs& c, const StripPose& ps, int lane, GeomLds* g) {
+  using namespace strip;
+  const int st = lane >> 3, k = lane & 7;
+  float ax_lo = 0.0f, ax_hi = 0.0f, tmin = 0.0f, tmax = 0.0f;
+#pragma unroll
+  for (int q = 0; q < kMaxStrips; ++q) {       // (wave-uniform loads, picked by selects)
+    const bool me = st == q;
+    ax_lo = me ? c.ax_lo[q] : ax_lo; ax_hi = me ? c.ax_hi[q] : ax_hi;
+    tmin = me ? c.tmin[q] : tmin; tmax = me ? c.tmax[q] : tmax;
   }
-  // a frame that does not fit what the host sized the launches for: flag it and project nothing
-  // (cannot happen when the host derived the sizes from these very frames)
-  bool fits = geom.ok != 0 && U.h <= a.max_rows && U.h <= kListMaxRows && U.w <= 4 * kListMaxGroups;
-  for (int s = 0; s < strip::kMaxStrips; ++s) fits = fits && (int)geom.win[s].w * geom.win[s].h <= a.slab_stride;
-  if (!fits) {
-    if (threadIdx.x == 0 && slice == 0 && (U.w > 0 || !geom.ok)) atomicOr(a.status, 1);
-    U = Window{0, 0, 0, 0};
+  const bool live = (st < c.P) & (((c.live_mask >> st) & 1) != 0);
+  const float d = (k & 1) ? c.dmax : c.dmin;
+  const float ax = (k & 2) ? ax_hi : ax_lo;
+  const float gg = (k & 4) ? c.g1 : c.g0;
+  float cx = ax * d * c.inv, cz = gg * d * c.inv;                 // strip_corners
+  cx = live ? cx : 0.0f; cz = live ? cz : 0.0f;                   // (cfg_rig: a dead strip's corners are zero)
+  const Pose p = pose_of(c, ps.y0, ps.y2, ps.y6, ps.y8, ps.tx, ps.tz, ps.wo, ps.ho);
+  const float xf = p.y0 * cx + p.y6 * cz + p.xd;                  // strip_geometry
+  const float zf = p.y2 * cx + p.y8 * cz + p.zd;
+  const float lx = min8(xf), hx = max8(xf), lz = min8(zf), hz = max8(zf);
+  const bool on = live & (p.ok != 0);
+  bool in = false;
+  const Win16 ww = window_of(c, lx, hx, lz, hz, p.slack, in);
+  const Line l = cone_edge(c, p, tmin, true), r = cone_edge(c, p, tmax, false);
+  const bool inside = on & in & (ww.w > 0);
+  const Win16 w = on ? ww : Win16{0, 0, 0, 0};
+  if (k == 0) {
+    g->win[st] = w;
+    g->L[st] = on ? l : Line{0.0f, 0.0f, 0.0f, 0.0f};
+    g->R[st] = on ? r : Line{0.0f, 0.0f, 0.0f, 0.0f};
   }
-  if (slice == 0) {
-    if (threadIdx.x < strip::kMaxStrips)
-      a.t.wins[(size_t)b * strip::kMaxStrips + threadIdx.x] = fits ? geom.win[threadIdx.x] : Win16{0, 0, 0, 0};
-    if (threadIdx.x == 0) { a.t.unions[b] = narrow16(U); a.t.flags[b] = fits ? geom.inside : 0; }
+  const unsigned long long in_mask = __builtin_amdgcn_ballot_w64(inside & (k == 0));
+  const bool some = w.w > 0;               // (the same in a strip's eight lanes)
+  int ux0 = some ? w.x0 : 32767, ux1 = some ? w.x0 + w.w : 0;
+  int uz0 = some ? w.z0 : 32767, uz1 = some ? w.z0 + w.h : 0;
+  // over the strips: the two strips of a row of 16 lanes by row_mirror, the four rows by readlane
+  ux0 = min(ux0, dpp_i<0x140>(ux0)); ux1 = max(ux1, dpp_i<0x140>(ux1));
+  uz0 = min(uz0, dpp_i<0x140>(uz0)); uz1 = max(uz1, dpp_i<0x140>(uz1));
+  {
+    auto rows4 = [](int v, bool take_min) {
+      const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+      const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+      return take_min ? min(min(a, b), min(c, d)) : max(max(a, b), max(c, d));
+    };
+    ux0 = rows4(ux0, true); ux1 = rows4(ux1, false); uz0 = rows4(uz0, true); uz1 = rows4(uz1, false);
   }
-  // appends the entries collected in LDS to the frame's list (all threads call it)
-  auto append = [&]() {
-    __syncthreads();
-    const int n = listed < kPrepListLds ? listed : kPrepListLds;
-    if (threadIdx.x == 0) list_base = n > 0 ? atomicAdd(a.t.counts + b, n) : 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += kPrepThreads)
-      if (list_base + i < a.list_cap) a.t.list[(size_t)b * a.list_cap + list_base + i] = found[i];
-    if (threadIdx.x == 0 && list_base + n > a.list_cap) atomicOr(a.status, 2);   // (cannot happen: the list holds every group of U)
-    __syncthreads();
-    if (threadIdx.x == 0) listed = 0;
-    __syncthreads();
-  };
-  // kPrepLanes lanes per row: the first P of them derive the strips' covers (exchanged by
-  // shuffles: owned spans, the hull), then all of them walk the hull's groups
-  const int sub = (int)threadIdx.x & (kPrepLanes - 1);
-  const int lane0 = (int)threadIdx.x & 63 & ~(kPrepLanes - 1);
-  // rows per pass: as many as the block has lanes for, and no more than fit the LDS list whatever they hold
-  const int groups_per_row = max(U.w >> 2, 1);
-  const int per_pass = min(kPrepThreads / kPrepLanes, max(kPrepListLds / groups_per_row, 1));
-  const int band = (U.h + kPrepSlices - 1) / kPrepSlices;
-  const int r_end = min(U.h, (slice + 1) * band);
-  for (int r0 = slice * band; r0 < r_end; r0 += per_pass) {      // (uniform trip count: append() has barriers)
-    const int r = r0 + (int)threadIdx.x / kPrepLanes;
-    if ((int)threadIdx.x / kPrepLanes < per_pass && r < r_end) {
-      const int ps = sub < nparts ? sub : 0;
-      uint32_t cover = strip::row_cover(geom.win[ps], geom.L[ps], geom.R[ps], U.z0 + r, a.mw);
-      cover = sub < nparts ? cover : 0u;
-      uint32_t cov[strip::kMaxStrips], own[strip::kMaxStrips];
+  if (lane == 0) {
+    g->U = ux1 > ux0 ? Win16{(short)ux0, (short)uz0, (short)(ux1 - ux0), (short)(uz1 - uz0)} : Win16{0, 0, 0, 0};
+    g->ok = p.ok;
+    int bits = 0;
 #pragma unroll
-      for (int q = 0; q < strip::kMaxStrips; ++q) cov[q] = (uint32_t)__shfl((int)cover, lane0 + q, 64);
-      int rlo = 32767, rhi = 0;
-#pragma unroll
-      for (int q = 0; q < strip::kMaxStrips; ++q) {
-        rlo = min(rlo, cov[q] ? (int)(cov[q] & 0xffffu) : 32767); rhi = max(rhi, (int)(cov[q] >> 16));
-      }
-      // the owned span of strip `sub`: its cover cut by the others' in the order sub ^ 1, sub ^ 2, ...
-      // (strip::row_owned, the host's version)
-      const int P2 = nparts <= 4 ? 4 : 8;
-      int lo = (int)(cover & 0xffffu), hi = (int)(cover >> 16);
-#pragma unroll
-      for (int m = 1; m < strip::kMaxStrips; ++m) {
-        const uint32_t other = (uint32_t)__shfl((int)cover, lane0 + ((sub ^ m) & (strip::kMaxStrips - 1)), 64);
-        if (m < P2 && (sub ^ m) < nparts) strip::cut_span(lo, hi, other);
-      }
-      const uint32_t owned = (sub < nparts && hi > lo) ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
-      if (sub < nparts) a.t.rows[((size_t)b * a.max_rows + r) * nparts + sub] = strip::RowEntry{cover, owned};
-      if (sub == 0) a.t.reach[(size_t)b * a.max_rows + r] = rhi > rlo ? make_uint2((unsigned)rlo, (unsigned)(rhi - rlo)) : make_uint2(0u, 0u);
-#pragma unroll
-      for (int q = 0; q < strip::kMaxStrips; ++q) own[q] = (uint32_t)__shfl((int)owned, lane0 + q, 64);
-      // the groups of [rlo, rhi) nobody owns: the row's lanes take kPrepLanes neighbouring groups at
-      // a time and append theirs in lane order -- runs of up to kPrepLanes entries whose groups are
-      // neighbours in the slabs, so that the combine kernel's threads read them coalesced
-      for (int x0 = rlo; x0 < rhi; x0 += 4 * kPrepLanes) {       // (the same trips in all lanes of a row)
-        const int x = x0 + 4 * sub;
-        uint32_t hits = 0;
-        bool mine = false;
-#pragma unroll
-        for (int q = 0; q < strip::kMaxStrips; ++q) {
-          hits |= strip::in_span(cov[q], x) ? 1u << q : 0u;
-          mine = mine | strip::in_span(own[q], x);
-        }
-        const bool want = x < rhi && !mine;
-        const unsigned group_bits = (unsigned)((__builtin_amdgcn_ballot_w64(want) >> lane0) & ((1ull << kPrepLanes) - 1));
-        const int count = __builtin_popcount(group_bits);
-        int base = 0;
-        if (sub == 0 && count > 0) base = atomicAdd(&listed, count);
-        base = __shfl(base, lane0, 64);
-        if (want) {
-          const int at = base + __builtin_popcount(group_bits & ((1u << sub) - 1u));
-          if (at < kPrepListLds) found[at] = pack_shared(r, (x - U.x0) >> 2, hits);
-          else atomicOr(a.status, 2);         // (a pass of rows with more than kPrepListLds shared groups)
-        }
-      }
-    }
-    append();
+    for (int q = 0; q < kMaxStrips; ++q) bits |= (int)((in_mask >> (8 * q)) & 1ull) << q;
+    g->inside = bits;
   }
 }
+
+// What a launch leaves in device memory for the kernels behind it (k_strip_combine, the batch
+// fuse): written by the scatter kernel's workgroups, never read by them.
+struct FrameTables {
+  Win16* wins;                // (B, kMaxStrips)
+  Win16* unions;              // (B)   union windows, x in whole kSpanAlign groups
+  int* counts;                // (B, kMaxStrips)   entries of each strip's shared-group list
+  uint32_t* list;             // (B, P, seg_cap)   the groups of a strip's cover nobody owns and no
+                              //                   lower strip's cover holds
+};
+
+// Status bits the kernels set (dm_status_bits in the header)
+constexpr int kStatusFrameDidNotFit = 1, kStatusListOverflow = 2;
 
 struct StripArgs {
   int W, H;
@@ -223,16 +170,16 @@ struct StripArgs {
   float fx_inv, fy_inv, res_inv;
   float dmin, dmax, hmax;
   float Hm1, mhm1;
+  float p4, p5, p7, p8;       // the batch's pitch rotation (Rp[4], Rp[5], Rp[7], Rp[8])
   int wp, P;
-  int fill_parts;             // workgroups per (frame, channel) that share the fill duty: the P strips' plus
-                              // fill-only ones (small batches: more workgroups than strips to fill the chip)
   int dc, valid_c;
   int oc, ch0, oc_total;      // channels of this launch's group / first channel / channels of out
   int slab_stride;            // cells per slab = cells of the LDS window region
-  int max_rows;               // rows of a frame's row table (>= the union window's height)
+  int max_rows;               // rows the LDS row tables hold (>= the union window's height)
+  int seg_cap;                // entries a strip's shared-group list holds
   float fill;
-  int b0;
-  const float* frames;        // (B, 32) dm_frame records in device memory
+  int b0;                     // first frame of this launch
+  const float* poses_dev;     // (B, kPoseFloats) in device memory (prepared frames), or NULL: `poses`
   const float* depth;
   const float* value;         // (B, oc_total, H, W) or NULL: project the heights
   const uint8_t* valid;
@@ -240,15 +187,14 @@ struct StripArgs {
   float* out;
   uint8_t* mask;
   int mh, mw;
-  const Win16* g_wins;        // frame tables (k_strip_prepare)
-  const Win16* g_unions;
-  const int* g_flags;
-  const strip::RowEntry* g_rows;
-  const uint2* g_reach;
+  FrameTables t;
+  int* status;                // device-visible status word (or NULL)
   uint16_t* list;             // (B, P, H, wp) cells of the pixels inside their strips' windows (index / value pass)
 #ifdef DM_STAMPS
   long long* stamps;
 #endif
+  strip::RigArgs rig;
+  StripPose poses[kPoseFrames];     // this launch's frames (b0 ...), unless poses_dev
 };
 
 // RED: kMin / kMax.  Always the fast geometry (axis-aligned rotations, exact FMA division),
@@ -256,7 +202,7 @@ struct StripArgs {
 //
 // The pixel loop is bound by VALU issue (tools/strip_stamps.py with the DM_X_* switches: 21 us
 // of arithmetic against 15 us of memory traffic at cfg2), so everything a pixel does not need
-// is kept out of it: the geometry comes from k_strip_prepare, the ray slope of an image row from
+// is kept out of it: the geometry is derived once in the kernel's head, the ray slope of an image row from
 // a table in LDS, the fill duty is wave-level stores with scalar addressing, and a strip whose
 // window the map's borders did not clip (FrameGeom::inside) skips the window test -- every
 // pixel with a depth in range then lands inside the window by construction.
@@ -296,10 +242,6 @@ k_strip_scatter(StripArgs a) {
   const int ch = a.ch0 + chl;
   const int dch = a.dc == 1 ? 0 : ch;
   const int nparts = a.P;
-  // a fill-only workgroup (part >= P) has no pixels and no window: its strip lies past the image's
-  // right edge (nx = 0 below), its window is empty, the tables are read as strip 0's and not used
-  const bool fill_only = part >= nparts;
-  const int tpart = fill_only ? 0 : part;
   // the strip's pixel rectangle and the first depth rows: kernel arguments only
   const int q0 = part * a.wp;
   int q1 = q0 + a.wp; if (q1 > a.W) q1 = a.W;
@@ -321,7 +263,7 @@ k_strip_scatter(StripArgs a) {
       const_cast<float*>(HAS_VALUE ? a.value + ((size_t)b * a.oc_total + ch) * N : a.value), 0,
       HAS_VALUE ? (unsigned)N * 4u : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_list = __builtin_amdgcn_make_buffer_rsrc(
-      a.list + (MODE != kProject ? ((size_t)b * nparts + tpart) * (size_t)a.H * a.wp : 0), 0,
+      a.list + (MODE != kProject ? ((size_t)b * nparts + part) * (size_t)a.H * a.wp : 0), 0,
       MODE != kProject ? (unsigned)a.H * (unsigned)a.wp * 2u : 0u, 0x00020000);
   const float qnan = __builtin_nanf("");
   float za[kRowsInFlight][VEC], zb_[kRowsInFlight][VEC];
@@ -361,87 +303,94 @@ k_strip_scatter(StripArgs a) {
     first_rows_loaded = true;
   }
 
-  // the frame's record and tables: one batch of scalar loads, pinned
-  const float* tf = a.frames + (size_t)b * 32;
-  float p4 = tf[4], p5 = tf[5], p7 = tf[7], p8 = tf[8], cam_h = tf[9];
-  float fy0 = tf[10], fy2 = tf[12], fy6 = tf[16], fy8 = tf[18], ftx = tf[19], ftz = tf[20];
-  float wo = tf[21], ho = tf[22];
-  // this strip's row entries (cover, owned span) and the rows' reach spans: requested right behind
-  // the first depth rows, for as many rows as the table holds (the union window's height is not
-  // known yet, and waiting for it would put two round trips in a row into the kernel's head)
-  strip::RowEntry row_e = {0u, 0u};
-  uint2 reach_e = make_uint2(0u, 0u);
-  if ((int)threadIdx.x < a.max_rows) {
-    row_e = a.g_rows[((size_t)b * a.max_rows + threadIdx.x) * nparts + tpart];
-    reach_e = a.g_reach[(size_t)b * a.max_rows + threadIdx.x];
-  }
-  const int2 w_raw = *reinterpret_cast<const int2*>(a.g_wins + (size_t)b * strip::kMaxStrips + tpart);
-  const int2 u_raw = *reinterpret_cast<const int2*>(a.g_unions + b);
-  int flags = a.g_flags[b];
+  // the frame's camera state: one batch of scalar loads from the kernel arguments (this launch's
+  // frames travel in them) or from the caller's device buffer (prepared frames) -- one uniform
+  // pointer into the constant address space either way
+  typedef const __attribute__((address_space(4))) float cfloat;
+  cfloat* const pr = a.poses_dev
+      ? (cfloat*)(a.poses_dev + (size_t)b * kPoseFloats)
+      : (cfloat*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() +
+                  offsetof(StripArgs, poses)) + bl * kPoseFloats;
 #ifdef DM_STAMPS
   long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   DM_STAMP(0);
   const int table_off = a.slab_stride + 64;
-  strip::RowEntry* rows = reinterpret_cast<strip::RowEntry*>(lds + table_off);   // this strip's entry of every row of U
-  uint2* reach = reinterpret_cast<uint2*>(lds + table_off + 2 * a.max_rows);     // {lo, width} of every row of U
-  float* aytab = lds + table_off + 4 * a.max_rows;
+  const int P2 = strips_pow2(nparts);
+  uint32_t* covers = reinterpret_cast<uint32_t*>(lds + table_off);                       // [row of U][strip], row stride P2
+  uint32_t* owned_t = covers + P2 * a.max_rows;                                          // this strip's owned span of every row of U
+  uint2* reach = reinterpret_cast<uint2*>(lds + table_off + (P2 + 1) * a.max_rows);       // {lo, width} of every row of U
+  int* list_at = reinterpret_cast<int*>(lds + table_off + (P2 + 3) * a.max_rows);        // list entries of this strip before the row, within its chunk of 64 rows
+  float* aytab = lds + table_off + (P2 + 4) * a.max_rows;
+  GeomLds* geom = reinterpret_cast<GeomLds*>(aytab + ((a.H + 3) & ~3));
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = (int)threadIdx.x & 63;
-  // The whole window region of LDS gets the fill value, the ray-slope table its H entries
-  // (maps.py:670-678; border rows poisoned), under the first depth rows in flight.
-  const float lds_init = kDeferCamH ? (RED == kMax ? -INFINITY : INFINITY) : a.fill;
-  if (MODE != kIndexOut)
-    for (int i = threadIdx.x * 4; i < a.slab_stride + 64; i += kScatterThreads * 4)
-      *reinterpret_cast<float4*>(lds + i) = make_float4(lds_init, lds_init, lds_init, lds_init);
-  for (int r = threadIdx.x; r < a.H; r += kScatterThreads) {
-    float yr = (float)r;
-    yr = a.flip_h ? a.Hm1 - yr : yr;
-    float ay = div_markstein(yr - a.cy, a.fy, a.fy_inv);
-    if (!LEAN) ay = (r < a.clip || r >= a.H - a.clip) ? qnan : ay;
-    aytab[r] = ay;
+  if (wave == 0) {
+    // The frame's geometry: wave 0 derives it (lane = strip x corner) into LDS, from the start of
+    // the kernel, while the other fifteen waves initialise the window and the ray-slope table;
+    // everybody reads it behind the barrier.
+    StripPose ps;
+    ps.y0 = pr[0]; ps.y2 = pr[1]; ps.y6 = pr[2]; ps.y8 = pr[3]; ps.tx = pr[4]; ps.tz = pr[5]; ps.wo = pr[6]; ps.ho = pr[7];
+    ps.cam_h = pr[8]; ps.pad0 = ps.pad1 = ps.pad2 = 0.0f;
+    frame_geometry_wave64(a.rig, ps, lane, geom);
+  } else {
+    // The whole window region of LDS gets the fill value, the ray-slope table its H entries
+    // (maps.py:670-678; border rows poisoned), under the first depth rows in flight.
+    constexpr int kInitThreads = kScatterThreads - 64;
+    const int t = (int)threadIdx.x - 64;
+    const float lds_init = kDeferCamH ? (RED == kMax ? -INFINITY : INFINITY) : a.fill;
+    if (MODE != kIndexOut)
+      for (int i = t * 4; i < a.slab_stride + 64; i += kInitThreads * 4)
+        *reinterpret_cast<float4*>(lds + i) = make_float4(lds_init, lds_init, lds_init, lds_init);
+    for (int r = t; r < a.H; r += kInitThreads) {
+      float yr = (float)r;
+      yr = a.flip_h ? a.Hm1 - yr : yr;
+      float ay = div_markstein(yr - a.cy, a.fy, a.fy_inv);
+      if (!LEAN) ay = (r < a.clip || r >= a.H - a.clip) ? qnan : ay;
+      aytab[r] = ay;
+    }
   }
   DM_STAMP(1);
-  // (the scalar loads are waited for only here, under the LDS work above; pinned: one batch)
-  asm volatile("" : "+s"(p4), "+s"(p5), "+s"(p7), "+s"(p8), "+s"(cam_h), "+s"(fy0), "+s"(fy2),
-                    "+s"(fy6), "+s"(fy8), "+s"(ftx), "+s"(ftz), "+s"(wo), "+s"(ho));
-  Window w = {(short)(w_raw.x & 0xffff), (short)(w_raw.x >> 16), (short)(w_raw.y & 0xffff), (short)(w_raw.y >> 16)};
-  Window U = {(short)(u_raw.x & 0xffff), (short)(u_raw.x >> 16), (short)(u_raw.y & 0xffff), (short)(u_raw.y >> 16)};
+  lds_barrier();
+  DM_STAMP(7);
+  Window U = widen(geom->U);
+  {   // the union window in whole span groups (covers reach that far)
+    const int ux1 = min((U.x0 + U.w + strip::kSpanAlign - 1) & ~(strip::kSpanAlign - 1), a.mw);
+    U.x0 &= ~(strip::kSpanAlign - 1);
+    U.w = U.w > 0 ? ux1 - U.x0 : 0;
+  }
+  // A frame that does not fit what the host sized the launch for (cannot happen when the host
+  // derived the sizes from these very frames: a caller's device buffer changed behind the
+  // plan's back): flag it and project nothing -- every cell of its maps gets the fill value.
+  bool fits = geom->ok != 0 && U.h <= a.max_rows && U.h <= kListMaxRows && U.w <= 4 * kListMaxGroups;
+  {
+    const Win16 mine = geom->win[lane & (strip::kMaxStrips - 1)];
+    fits = fits && __builtin_amdgcn_ballot_w64((int)mine.w * mine.h > a.slab_stride) == 0;
+  }
+  Window w = widen(geom->win[part]);
+  int flags = geom->inside;
   {
     // wave-uniform values: keep them in SGPRs
+    const int fit = __builtin_amdgcn_readfirstlane((int)fits);
     w.x0 = __builtin_amdgcn_readfirstlane(w.x0); w.z0 = __builtin_amdgcn_readfirstlane(w.z0);
-    w.w = __builtin_amdgcn_readfirstlane(fill_only ? 0 : w.w); w.h = __builtin_amdgcn_readfirstlane(w.h);   // (fill-only: no window)
+    w.w = __builtin_amdgcn_readfirstlane(fit ? w.w : 0); w.h = __builtin_amdgcn_readfirstlane(fit ? w.h : 0);
     U.x0 = __builtin_amdgcn_readfirstlane(U.x0); U.z0 = __builtin_amdgcn_readfirstlane(U.z0);
-    U.w = __builtin_amdgcn_readfirstlane(U.w); U.h = __builtin_amdgcn_readfirstlane(U.h);
-    flags = __builtin_amdgcn_readfirstlane(flags);
+    U.w = __builtin_amdgcn_readfirstlane(fit ? U.w : 0); U.h = __builtin_amdgcn_readfirstlane(fit ? U.h : 0);
+    flags = __builtin_amdgcn_readfirstlane(fit ? flags : 0);
+    fits = fit != 0;
   }
   const int area = w.w * w.h;
-  // the row tables -> LDS (rows past the union window's height hold whatever the table does: never used)
-  if ((int)threadIdx.x < a.max_rows) { rows[threadIdx.x] = row_e; reach[threadIdx.x] = reach_e; }
-  for (int r = threadIdx.x + kScatterThreads; r < U.h; r += kScatterThreads) {
-    rows[r] = a.g_rows[((size_t)b * a.max_rows + r) * nparts + tpart];
-    reach[r] = a.g_reach[(size_t)b * a.max_rows + r];
+  // what the kernels behind this one read of the frame: by the first strip's workgroup of the
+  // launch's first channel
+  if (part == 0 && chl == 0 && wave == 0) {
+    if (lane < strip::kMaxStrips) a.t.wins[(size_t)b * strip::kMaxStrips + lane] = fits ? geom->win[lane] : Win16{0, 0, 0, 0};
+    if (lane == 0) {
+      a.t.unions[b] = narrow16(U);
+      if (!fits && a.status) __hip_atomic_store(a.status, kStatusFrameDidNotFit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
-  lds_barrier();
-  DM_STAMP(2);
-  DM_STAMP(3);
-  // Fill duty: map rows part, part + F, ... (F = fill_parts) of (b, ch) outside the rows' reach spans (the hull of
-  // the strips' covers: inside it the flush below and the combine step write).  Wave-level: wave v takes the rows part + (v + 16 j) F,
-  // one step stores 256 cells of a row (float4 per lane) and their mask bytes with SCALAR
-  // addressing -- the map of this (frame, channel) as a raw buffer resource, the row and chunk
-  // in the scalar offset, the lane's fixed 16 / 4 bytes in the vector offset.  A lane that has
-  // nothing to write (inside the reach, past the row's end, past the wave's rows) gets a vector offset
-  // past the end of the buffer and is dropped by the hardware's range check: no branch in the
-  // loop, a handful of VALU instructions per KB.
+  // the maps of this (frame, channel) as raw buffer resources (the fill duty's and the flush's stores)
   const size_t map_base = ((size_t)b * a.oc_total + ch) * (size_t)a.mh * a.mw;
-  const int fparts = a.fill_parts;
-  const int fill_rows = (a.mh - part + fparts - 1) / fparts;
-  const int chunks = (a.mw + 255) >> 8;
-#ifdef DM_X_NOFILL2
-  const int fill_steps = 0;
-#else
-  const int fill_steps = a.out != nullptr && wave < fill_rows ? ((fill_rows - wave + 15) >> 4) * chunks : 0;
-#endif
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const unsigned map_cells = (unsigned)a.mh * (unsigned)a.mw;
   const __amdgpu_buffer_rsrc_t rs_out =
@@ -449,6 +398,195 @@ k_strip_scatter(StripArgs a) {
   const __amdgpu_buffer_rsrc_t rs_mask =
       __builtin_amdgcn_make_buffer_rsrc(a.mask + map_base, 0, a.out ? map_cells : 0u, 0x00020000);
   const unsigned fill_bits = __float_as_uint(a.fill);
+  // The row tables, one thread per row of the union window (whole waves: the rows of a wave are a
+  // chunk of 64): the cover of every strip on the row (strip::row_cover), this strip's owned
+  // span (strip::row_owned: its cover cut by the others'), the hull of the covers ("reach":
+  // outside it the map holds the fill value), and where the row's entries of the strip's
+  // shared-group list go -- a strip lists the groups of its cover that it does not own, in x
+  // order, so a row's entries follow those of the rows before it: a scan over the chunk (here)
+  // and over the chunks (wave 0, behind the barrier).  Straight-line code over 4 or 8 strips, the
+  // covers in registers (a dead strip has an empty window and an empty cover).
+  auto row_tables = [&](auto p2_tag) {
+    constexpr int kP2 = decltype(p2_tag)::value;
+    for (int r0 = wave * 64; r0 < U.h; r0 += kScatterThreads) {       // (wave-uniform trips: the scan's shuffles)
+      const int r = r0 + lane;
+      const bool live = r < U.h;
+      uint32_t cov[kP2];
+      int rlo = 32767, rhi = 0;
+#pragma unroll
+      for (int q = 0; q < kP2; ++q) {
+        // (the strips' windows and edges: broadcast reads of the geometry in LDS)
+        const Win16 gw = geom->win[q];
+        const strip::Line gl = geom->L[q], gr = geom->R[q];
+        cov[q] = strip::row_cover(gw, gl, gr, U.z0 + r, a.mw);
+        rlo = min(rlo, cov[q] ? (int)(cov[q] & 0xffffu) : 32767); rhi = max(rhi, (int)(cov[q] >> 16));
+      }
+      // this strip's cover and its owned span: the cover cut by the others' in strip::row_owned's
+      // order (part ^ 1, part ^ 2, ...), picked with selects (part is wave-uniform)
+      uint32_t mine = cov[0];
+#pragma unroll
+      for (int q = 1; q < kP2; ++q) mine = part == q ? cov[q] : mine;
+      int lo = (int)(mine & 0xffffu), hi = (int)(mine >> 16);
+#pragma unroll
+      for (int m = 1; m < kP2; ++m) {
+        const int o = part ^ m;
+        uint32_t other = cov[0];
+#pragma unroll
+        for (int q = 1; q < kP2; ++q) other = o == q ? cov[q] : other;
+        strip::cut_span(lo, hi, other);
+      }
+      const uint32_t owned = hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
+      // entries of this strip's list on the row: the groups of its cover outside the owned span
+      int entries = (int)((mine >> 16) - (mine & 0xffffu)) - (hi > lo ? hi - lo : 0);
+      entries = live ? entries >> 2 : 0;
+      const int before = wave_inclusive_scan(entries);       // over the wave's rows
+      if (lane == 63) geom->chunk_entries[r0 >> 6] = before;
+      // A hole between covers inside the hull: some cover ends inside the hull where no other cover
+      // continues.
+      bool hole = false;
+#pragma unroll
+      for (int q = 0; q < kP2; ++q) {
+        const int end = (int)(cov[q] >> 16);
+        bool continued = (cov[q] == 0u) | (end >= rhi);
+#pragma unroll
+        for (int o = 0; o < kP2; ++o)
+          if (o != q) continued = continued | (((int)(cov[o] & 0xffffu) <= end) & (end < (int)(cov[o] >> 16)));
+        hole = hole | !continued;
+      }
+      if (live) {
+        if (kP2 == 4) {
+          *reinterpret_cast<uint4*>(covers + r * 4) = make_uint4(cov[0], cov[1], cov[2], cov[3]);
+        } else {
+          *reinterpret_cast<uint4*>(covers + r * 8) = make_uint4(cov[0], cov[1], cov[2], cov[3]);
+          *reinterpret_cast<uint4*>(covers + r * 8 + 4) = make_uint4(cov[4 % kP2], cov[5 % kP2], cov[6 % kP2], cov[7 % kP2]);
+        }
+        owned_t[r] = owned;
+        reach[r] = rhi > rlo ? make_uint2((unsigned)rlo, (unsigned)(rhi - rlo)) : make_uint2(0u, 0u);
+        list_at[r] = before - entries;
+        // Groups of the hull in no strip's cover (not seen in practice, but nothing rules them
+        // out) are written here, with the fill value, by the workgroup whose fill duty owns the
+        // map row.
+        if (__builtin_expect(hole, 0)) {
+          if (MODE != kIndexOut && (U.z0 + r) % nparts == part) {
+            for (int x = rlo; x < rhi; x += 4) {
+              bool any = false;
+#pragma unroll
+              for (int q = 0; q < kP2; ++q) any = any | strip::in_span(cov[q], x);
+              if (!any) {
+                const int cell = (U.z0 + r) * a.mw + x;
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, cell << 2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, cell, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+  };
+  // (more than four strips -- small frames, narrow windows: the same with rolled loops over the
+  // covers in LDS, which keeps the registers of the eight-strip case out of this kernel's budget)
+  auto row_tables_rolled = [&]() {
+    for (int r0 = wave * 64; r0 < U.h; r0 += kScatterThreads) {
+      const int r = r0 + lane;
+      const bool live = r < U.h;
+      uint32_t* const crow = covers + (live ? r : 0) * P2;
+      int rlo = 32767, rhi = 0;
+      uint32_t mine = 0u;
+      if (live) {
+#pragma unroll 2
+        for (int q = 0; q < P2; ++q) {
+          const Win16 gw = geom->win[q];
+          const strip::Line gl = geom->L[q], gr = geom->R[q];
+          const uint32_t c = strip::row_cover(gw, gl, gr, U.z0 + r, a.mw);
+          crow[q] = c;
+          rlo = min(rlo, c ? (int)(c & 0xffffu) : 32767); rhi = max(rhi, (int)(c >> 16));
+          mine = q == part ? c : mine;
+        }
+      }
+      int lo = (int)(mine & 0xffffu), hi = (int)(mine >> 16);
+      bool hole = false;
+      if (live) {       // (the thread's own LDS stores read back)
+#pragma unroll 1
+        for (int m = 1; m < P2; ++m) strip::cut_span(lo, hi, crow[part ^ m]);
+#pragma unroll 1
+        for (int q = 0; q < P2; ++q) {
+          const uint32_t cq = crow[q];
+          const int end = (int)(cq >> 16);
+          bool continued = (cq == 0u) | (end >= rhi);
+#pragma unroll 1
+          for (int o = 0; o < P2; ++o) {
+            const uint32_t co = crow[o];
+            continued = continued | ((o != q) & ((int)(co & 0xffffu) <= end) & (end < (int)(co >> 16)));
+          }
+          hole = hole | !continued;
+        }
+      }
+      int entries = (int)((mine >> 16) - (mine & 0xffffu)) - (hi > lo ? hi - lo : 0);
+      entries = live ? entries >> 2 : 0;
+      const int before = wave_inclusive_scan(entries);
+      if (lane == 63) geom->chunk_entries[r0 >> 6] = before;
+      if (live) {
+        owned_t[r] = hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
+        reach[r] = rhi > rlo ? make_uint2((unsigned)rlo, (unsigned)(rhi - rlo)) : make_uint2(0u, 0u);
+        list_at[r] = before - entries;
+        if (__builtin_expect(hole, 0)) {
+          if (MODE != kIndexOut && (U.z0 + r) % nparts == part) {
+            for (int x = rlo; x < rhi; x += 4) {
+              bool any = false;
+#pragma unroll 1
+              for (int q = 0; q < P2; ++q) any = any | strip::in_span(crow[q], x);
+              if (!any) {
+                const int cell = (U.z0 + r) * a.mw + x;
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, cell << 2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, cell, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+  };
+  if (P2 == 4) row_tables(std::integral_constant<int, 4>{}); else row_tables_rolled();
+  DM_STAMP(8);
+  // What the pixel loop reads of the kernel arguments and of the frame's pose is (re)loaded HERE,
+  // through pointers the compiler cannot see through: a scalar whose live range crossed the
+  // geometry code above would be spilled as a whole and reloaded at every use inside the loop.
+  typedef const __attribute__((address_space(4))) StripArgs cargs;
+  cargs* la = (cargs*)__builtin_amdgcn_kernarg_segment_ptr();
+  cfloat* pl = pr;
+  asm volatile("" : "+s"(la), "+s"(pl));
+  float fy0 = pl[0], fy2 = pl[1], fy6 = pl[2], fy8 = pl[3], ftx = pl[4], ftz = pl[5];
+  float wo = pl[6], ho = pl[7], cam_h = pl[8];
+  float p4 = la->p4, p5 = la->p5, p7 = la->p7, p8 = la->p8;
+  // (one batch of scalar loads, pinned)
+  asm volatile("" : "+s"(p4), "+s"(p5), "+s"(p7), "+s"(p8), "+s"(cam_h), "+s"(fy0), "+s"(fy2),
+                    "+s"(fy6), "+s"(fy8), "+s"(ftx), "+s"(ftz), "+s"(wo), "+s"(ho));
+  lds_barrier();
+  DM_STAMP(2);
+  if (wave == 0) {       // list entries before each chunk of 64 rows (the flush reads them behind the next barrier)
+    const int chunks_u = (U.h + 63) >> 6;                      // <= kListMaxRows / 64 = 64
+    const int mine = lane < chunks_u ? geom->chunk_entries[lane] : 0;
+    const int before = wave_inclusive_scan(mine);
+    geom->chunk_entries[lane] = before - mine;
+    if (lane == 63) geom->chunk_entries[kListMaxRows / 64] = before;
+  }
+  DM_STAMP(3);
+  // Fill duty: map rows part, part + P, ... of (b, ch) outside the rows' reach spans (the hull of
+  // the strips' covers: inside it the flush below and the combine step write).  Wave-level: wave v takes the rows part + (v + 16 j) F,
+  // one step stores 256 cells of a row (float4 per lane) and their mask bytes with SCALAR
+  // addressing -- the map of this (frame, channel) as a raw buffer resource, the row and chunk
+  // in the scalar offset, the lane's fixed 16 / 4 bytes in the vector offset.  A lane that has
+  // nothing to write (inside the reach, past the row's end, past the wave's rows) gets a vector offset
+  // past the end of the buffer and is dropped by the hardware's range check: no branch in the
+  // loop, a handful of VALU instructions per KB.
+  const int fparts = nparts;
+  const int fill_rows = (la->mh - part + fparts - 1) / fparts;
+  const int chunks = (la->mw + 255) >> 8;
+#ifdef DM_X_NOFILL2
+  const int fill_steps = 0;
+#else
+  const int fill_steps = la->out != nullptr && wave < fill_rows ? ((fill_rows - wave + 15) >> 4) * chunks : 0;
+#endif
   const int lane4 = lane << 2;
   int fs = 0, f_row = part + wave * fparts, f_chunk = 0;       // (wave-uniform)
   // the reach of a map row ({0, 0} outside U's rows), read from LDS TWO steps ahead: the steps
@@ -473,10 +611,10 @@ k_strip_scatter(StripArgs a) {
   auto fill_step = [&]() {
     const int x = (f_chunk << 8) + lane4;
     const bool live = fs < fill_steps;                                              // (scalar)
-    const bool skip = !live | (x >= a.mw) | ((unsigned)(x - (int)f_reach.x) < f_reach.y);
+    const bool skip = !live | (x >= la->mw) | ((unsigned)(x - (int)f_reach.x) < f_reach.y);
     // (the scalar offset must be the same in every lane, skipping or not: a lane-dependent one
     // costs a waterfall loop per store)
-    const int cell0 = __builtin_amdgcn_readfirstlane(live ? f_row * a.mw + (f_chunk << 8) : 0);
+    const int cell0 = __builtin_amdgcn_readfirstlane(live ? f_row * la->mw + (f_chunk << 8) : 0);
     __builtin_amdgcn_raw_buffer_store_b128((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out,
                                            skip ? 0x7ffffff0 : lane4 << 2, cell0 << 2, 0);
     __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, skip ? 0x7ffffff0 : lane4, cell0, 0);
@@ -488,13 +626,13 @@ k_strip_scatter(StripArgs a) {
   };
   // (a local map's records carry a neutral yaw and no translation: dm_strip.hip stage_frames)
   const float y0 = fy0, y2r = fy2, y6 = fy6, y8 = fy8, tx = ftx, tz = ftz;
-  const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
+  const float flip_s = la->flip_h ? -1.0f : 1.0f, flip_c = la->flip_h ? la->mhm1 : 0.0f;
   // LDS addresses of the pixel loop as plain 32-bit byte addresses (an LDS pointer IS that), so
   // that the window's origin and the base of `lds` fold into one scalar:
   // address = (z * w + x) * 4 + origin
   typedef __attribute__((address_space(3))) float lds_float;
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_float*)lds;
-  const unsigned dummy = lds_base + (((unsigned)a.slab_stride + (unsigned)lane) << 2);   // 64 scratch cells
+  const unsigned dummy = lds_base + (((unsigned)la->slab_stride + (unsigned)lane) << 2);   // 64 scratch cells
   const int origin = (int)lds_base - 4 * (w.z0 * w.w + w.x0);
   auto lds_at = [](unsigned addr) { return (lds_float*)(uintptr_t)addr; };
 
@@ -504,9 +642,9 @@ k_strip_scatter(StripArgs a) {
       float ax[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
-        const float d = (float)(q + k) - a.cx;
-        ax[k] = div_markstein(d, a.fx, a.fx_inv);
-        if (!LEAN) ax[k] = (q + k < a.clip || q + k >= a.W - a.clip) ? qnan : ax[k];
+        const float d = (float)(q + k) - la->cx;
+        ax[k] = div_markstein(d, la->fx, la->fx_inv);
+        if (!LEAN) ax[k] = (q + k < la->clip || q + k >= la->W - la->clip) ? qnan : ax[k];
       }
       const int step = rows_per_iter * kRowsInFlight;
       auto load_rows = [&](float (&z)[kRowsInFlight][VEC],
@@ -592,7 +730,7 @@ k_strip_scatter(StripArgs a) {
             const f2 z1 = __builtin_elementwise_fma(zz, (f2){p8, p8}, Y * p5);
             const f2 x2 = __builtin_elementwise_fma(z1, (f2){y6, y6}, X * y0) + tx;      // maps.py:884-892
             const f2 z2 = __builtin_elementwise_fma(z1, (f2){y8, y8}, X * y2r) + tz;
-            const f2 ri = {a.res_inv, a.res_inv}, nres = {-a.res, -a.res};
+            const f2 ri = {la->res_inv, la->res_inv}, nres = {-la->res, -la->res};
             const f2 qx = x2 * ri, qz = z2 * ri;                             // exact division
             f2 xf2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nres, qx, x2), ri, qx) + wo;
             f2 zf2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nres, qz, z2), ri, qz) + ho;
@@ -610,9 +748,9 @@ k_strip_scatter(StripArgs a) {
             const int ix = floor_to_int(xf), iz = floor_to_int(zf);
             // (bitwise &: the short-circuit form compiles to a branch per pixel, and a branch in
             // this loop costs its counted waits)
-            bool ok = (zz >= a.dmin) & (zz <= a.dmax);
+            bool ok = (zz >= la->dmin) & (zz <= la->dmax);
             if (kTest) ok = ok & ((unsigned)(ix - w.x0) < (unsigned)w.w) & ((unsigned)(iz - w.z0) < (unsigned)w.h);
-            if (!LEAN) ok = ok & !__builtin_isunordered(xf, zf) & (h1 <= a.hmax);
+            if (!LEAN) ok = ok & !__builtin_isunordered(xf, zf) & (h1 <= la->hmax);
             const float sval = HAS_VALUE ? sv[u][k] : h1;
             if (HAS_VALUE) ok = ok & (sval == sval);             // NaN never replaces a number
             // (window coordinates fit 24 bits: |cell coordinates| < 2^23, dm_strip.hip validate_frames)
@@ -628,7 +766,7 @@ k_strip_scatter(StripArgs a) {
               // rare: some thread's four pixels may share a cell -- the plain way, validity as a value
 #pragma unroll
               for (int k = 0; k < VEC; ++k) {
-                const bool ok = (z[u][k] >= a.dmin) & (z[u][k] <= a.dmax);
+                const bool ok = (z[u][k] >= la->dmin) & (z[u][k] <= la->dmax);
                 li[k] = ok ? li[k] : dummy;
               }
 #pragma unroll
@@ -646,12 +784,12 @@ k_strip_scatter(StripArgs a) {
                 if (RED == kMax)
                   asm volatile("v_cmpx_le_f32_e32 vcc, %0, %2\n\tv_cmpx_ge_f32_e32 vcc, %1, %2\n\t"
                                "ds_max_f32 %3, %4\n\ts_mov_b64 exec, %5"
-                               :: "s"(a.dmin), "s"(a.dmax), "v"(z[u][k]), "v"(li[k]), "v"(hv[k]), "s"(exec_all)
+                               :: "s"(la->dmin), "s"(la->dmax), "v"(z[u][k]), "v"(li[k]), "v"(hv[k]), "s"(exec_all)
                                : "vcc", "memory");
                 else
                   asm volatile("v_cmpx_le_f32_e32 vcc, %0, %2\n\tv_cmpx_ge_f32_e32 vcc, %1, %2\n\t"
                                "ds_min_f32 %3, %4\n\ts_mov_b64 exec, %5"
-                               :: "s"(a.dmin), "s"(a.dmax), "v"(z[u][k]), "v"(li[k]), "v"(hv[k]), "s"(exec_all)
+                               :: "s"(la->dmin), "s"(la->dmax), "v"(z[u][k]), "v"(li[k]), "v"(hv[k]), "s"(exec_all)
                                : "vcc", "memory");
               }
             }
@@ -662,7 +800,7 @@ k_strip_scatter(StripArgs a) {
             int rr = r + u * rows_per_iter;
             rr = rr < r1 ? rr : r1 - 1;
             __builtin_amdgcn_raw_buffer_store_b64((u32x2){li[0] | (li[1] << 16), li[2] | (li[3] << 16)}, rs_list,
-                                                  (__mul24(rr, a.wp) + (q - q0)) << 1, 0, 0);
+                                                  (__mul24(rr, la->wp) + (q - q0)) << 1, 0, 0);
             continue;
           }
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(li[0] == li[VEC - 1] && li[0] != dummy) != 0, 0)) {
@@ -749,33 +887,80 @@ k_strip_scatter(StripArgs a) {
   DM_STAMP(5);
   // Flush, 16 lanes per window row: the groups of this strip's cover go straight to the map where
   // the strip owns them (no other strip's cover reaches them), else to the slab: k_strip_combine
-  // combines those with the other strips'.
-  if (area > 0 && MODE != kIndexOut) {
+  // combines those with the other strips'.  The strip also LISTS such a group for the combine
+  // kernel when no lower strip's cover holds it (so every shared group is listed exactly once;
+  // a group some strip owns lies in no other strip's cover and is never listed): an entry with
+  // the covers that hold the group, appended to this strip's segment of the frame's list.  The
+  // index pass (no window) only lists; the value pass (kFromList) only flushes.
+  // What only the flush needs is read from the kernel arguments AGAIN, behind the loop, through a
+  // pointer the compiler cannot see through: kept live across the pixel loop these values (and the
+  // addresses derived from them) cost SGPR spills inside it.
+  cargs* fa = (cargs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(fa));
+  const int fP2 = strips_pow2(fa->P);
+  const uint32_t* const fcovers = reinterpret_cast<const uint32_t*>(lds + fa->slab_stride + 64);
+  const uint32_t* const fowned = fcovers + fP2 * fa->max_rows;
+  const int* const flist_at = reinterpret_cast<const int*>(fcovers + (fP2 + 3) * fa->max_rows);
+  const GeomLds* const fgeom = reinterpret_cast<const GeomLds*>(
+      reinterpret_cast<const float*>(fcovers) + (fP2 + 4) * fa->max_rows + ((fa->H + 3) & ~3));
+  const bool emit = MODE != kFromList && chl == 0;
+  if (area > 0 && (MODE != kIndexOut || emit)) {
     const int l16 = (int)threadIdx.x & 15;
-    const int unit = b * a.oc + chl;             // (frame, channel): the P workgroups that share a map
-    float* slab = a.slabs + ((size_t)unit * nparts + part) * a.slab_stride;
+    const int unit = b * fa->oc + chl;             // (frame, channel): the P workgroups that share a map
+    float* slab = fa->slabs + ((size_t)unit * nparts + part) * fa->slab_stride;
+    uint32_t* seg = fa->t.list + ((size_t)b * nparts + part) * fa->seg_cap;
+    const uint32_t lower = (1u << part) - 1u;
     for (int row = (int)threadIdx.x >> 4; row < w.h; row += kScatterThreads / 16) {
       const int z = w.z0 + row;
-      const strip::RowEntry e = rows[z - U.z0];
-      const int lo = (int)(e.cover & 0xffffu), hi = (int)(e.cover >> 16);
+      const int ur = z - U.z0;
+      const uint32_t cover = fcovers[ur * fP2 + part], owned = fowned[ur];
+      const int lo = (int)(cover & 0xffffu), hi = (int)(cover >> 16);
+      const int olo = owned ? (int)(owned & 0xffffu) : lo, ohi = owned ? (int)(owned >> 16) : lo;
       const int cell0 = row * w.w - w.x0;
+      // where the row's list entries start: those of the rows before it in its chunk + of the chunks before
+      const int at0 = emit ? flist_at[ur] + fgeom->chunk_entries[ur >> 6] : 0;
       for (int x = lo + (l16 << 2); x < hi; x += 64) {
-        float4 v = *reinterpret_cast<const float4*>(lds + cell0 + x);
-        if (kDeferCamH) {
-          v.x = combine<RED>(v.x + cam_h, a.fill); v.y = combine<RED>(v.y + cam_h, a.fill);
-          v.z = combine<RED>(v.z + cam_h, a.fill); v.w = combine<RED>(v.w + cam_h, a.fill);
+        const bool mine = (x >= olo) & (x < ohi);
+        if (MODE != kIndexOut) {
+          float4 v = *reinterpret_cast<const float4*>(lds + cell0 + x);
+          if (kDeferCamH) {
+            v.x = combine<RED>(v.x + cam_h, fa->fill); v.y = combine<RED>(v.y + cam_h, fa->fill);
+            v.z = combine<RED>(v.z + cam_h, fa->fill); v.w = combine<RED>(v.w + cam_h, fa->fill);
+          }
+          if (mine) {
+            const int cell = z * fa->mw + x;
+            __builtin_amdgcn_raw_buffer_store_b128((f32x4){v.x, v.y, v.z, v.w}, rs_out, cell << 2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(
+                (uint32_t)mask_of(v.x, fa->fill) | ((uint32_t)mask_of(v.y, fa->fill) << 8) |
+                ((uint32_t)mask_of(v.z, fa->fill) << 16) | ((uint32_t)mask_of(v.w, fa->fill) << 24), rs_mask, cell, 0, 0);
+          } else {
+            *reinterpret_cast<float4*>(slab + cell0 + x) = v;
+          }
         }
-        if (strip::in_span(e.owned, x)) {
-          const int cell = z * a.mw + x;
-          __builtin_amdgcn_raw_buffer_store_b128((f32x4){v.x, v.y, v.z, v.w}, rs_out, cell << 2, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(
-              (uint32_t)mask_of(v.x, a.fill) | ((uint32_t)mask_of(v.y, a.fill) << 8) |
-              ((uint32_t)mask_of(v.z, a.fill) << 16) | ((uint32_t)mask_of(v.w, a.fill) << 24), rs_mask, cell, 0, 0);
-        } else {
-          *reinterpret_cast<float4*>(slab + cell0 + x) = v;
+        if (emit && !mine) {       // (the lanes with a group the strip does not own)
+          // the covers that hold the group; the entry is live (hits != 0) only where no lower
+          // strip's cover does -- every shared group is combined exactly once
+          const uint4 c0 = *reinterpret_cast<const uint4*>(fcovers + ur * fP2);
+          uint32_t hits = (strip::in_span(c0.x, x) ? 1u : 0u) | (strip::in_span(c0.y, x) ? 2u : 0u) |
+                          (strip::in_span(c0.z, x) ? 4u : 0u) | (strip::in_span(c0.w, x) ? 8u : 0u);
+          if (fP2 == 8) {
+            const uint4 c1 = *reinterpret_cast<const uint4*>(fcovers + ur * 8 + 4);
+            hits |= (strip::in_span(c1.x, x) ? 16u : 0u) | (strip::in_span(c1.y, x) ? 32u : 0u) |
+                    (strip::in_span(c1.z, x) ? 64u : 0u) | (strip::in_span(c1.w, x) ? 128u : 0u);
+          }
+          hits = (hits & lower) == 0u ? hits : 0u;
+          // its place: the groups of the cover left of the owned span come first, then those right of it
+          const int at = at0 + ((x < olo ? x - lo : (olo - lo) + (x - ohi)) >> 2);
+          if (at < fa->seg_cap) seg[at] = pack_shared(ur, (x - U.x0) >> 2, hits);
         }
       }
     }
+  }
+  if (emit && threadIdx.x == 0) {
+    const int n = area > 0 ? fgeom->chunk_entries[kListMaxRows / 64] : 0;
+    fa->t.counts[(size_t)b * strip::kMaxStrips + part] = n < fa->seg_cap ? n : fa->seg_cap;
+    if (n > fa->seg_cap && fa->status)       // (cannot happen: a strip lists at most the groups of its window)
+      __hip_atomic_store(fa->status, kStatusListOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   DM_STAMP(6);
   DM_STAMPS_OUT();
@@ -783,44 +968,47 @@ k_strip_scatter(StripArgs a) {
 
 struct StripCombineArgs {
   int b0, oc, ch0, oc_total, mh, mw;
-  int P, slab_stride, list_cap;
+  int P, slab_stride, seg_cap;
   float fill;
   const Win16* g_wins;
   const Win16* g_unions;
-  const int* g_counts;
-  const uint32_t* g_list;
+  const int* g_counts;        // (B, kMaxStrips)
+  const uint32_t* g_list;     // (B, P, seg_cap)
   const float* slabs;
   float* out;
   uint8_t* mask;
 };
 
 constexpr int kCombineThreads = 256;
-// A (frame, channel) gets kCombineSlots / ENTRIES blocks whose threads take ENTRIES list entries at a
-// time (their slab loads in flight together) and stride over the list.  One entry per thread for
-// height maps (a handful of blocks per frame: the kernel is one chain of round trips, 6 us at
-// cfg2), four for value maps of many channels (the chip holds 2 K blocks at a time: with one
-// entry per thread 40 channels were twenty rounds of that chain, 200 us; with four, 80 us).
+// A (frame, channel) gets kCombineSlots / ENTRIES blocks; block x works on the list segment of strip
+// x mod P (the strips list their shared groups themselves, each into its own segment), its
+// threads take ENTRIES entries at a time (their slab loads in flight together) and stride over the
+// segment with the other blocks of that strip.  One entry per thread for height maps (a handful of
+// blocks per frame: the kernel is one chain of round trips), four for value maps of many channels
+// (the chip holds 2 K blocks at a time: with one entry per thread 40 channels were twenty rounds
+// of that chain, 200 us; with four, 80 us).
 constexpr int kCombineSlots = 16;
 
-// The groups of a frame's reach spans that no strip owns (the frame's shared-group list,
-// k_strip_prepare): max / min over the slabs of the strips whose covers hold the group -- the fill
-// value where none does -- written to the map with its mask bytes.  kCombineEntries list entries per thread at a time;
-// what a block needs of the frame (count, union window, the strips' windows) is wave-uniform.
-// One list entry per thread (height maps).
+// The groups of a frame's covers that no strip owns (the strips' shared-group lists): max / min
+// over the slabs of the strips whose covers hold the group, written to the map with its mask
+// bytes.  What a block needs of the frame (count, union window, the strips' windows) is
+// wave-uniform.  One list entry per thread (height maps).
 template <int RED>
 __global__ void __launch_bounds__(kCombineThreads)
 k_strip_combine_one(StripCombineArgs a) {
-  constexpr int kCombineBlocks = kCombineSlots;
   const int fcl = blockIdx.y;                  // (frame of the launch) * oc + channel of the group
   const int bl = fcl / a.oc, b = a.b0 + bl;
   const int chl = fcl - bl * a.oc;
-  const int first = blockIdx.x * kCombineThreads + (int)threadIdx.x;
-  const uint32_t* const list = a.g_list + (size_t)b * a.list_cap;
-  // (the thread's first entry is requested before the list's length is known: one round trip
+  const int nblocks = (int)gridDim.x;
+  const int seg = (int)blockIdx.x % a.P, lane_block = (int)blockIdx.x / a.P;
+  const int seg_blocks = (nblocks - seg + a.P - 1) / a.P;      // blocks that share this segment
+  const int first = lane_block * kCombineThreads + (int)threadIdx.x;
+  const uint32_t* const list = a.g_list + ((size_t)b * a.P + seg) * a.seg_cap;
+  // (the thread's first entry is requested before the segment's length is known: one round trip
   // less in a kernel that is nothing but a chain of them)
-  uint32_t entry = first < a.list_cap ? list[first] : 0u;
-  const int listed = min(a.g_counts[b], a.list_cap);
-  if (blockIdx.x * kCombineThreads >= listed) return;
+  uint32_t entry = first < a.seg_cap ? list[first] : 0u;
+  const int listed = min(a.g_counts[(size_t)b * strip::kMaxStrips + seg], a.seg_cap);
+  if (lane_block * kCombineThreads >= listed) return;
   const int2 u_raw = *reinterpret_cast<const int2*>(a.g_unions + b);
   const int ux0 = (short)(u_raw.x & 0xffff), uz0 = (short)(u_raw.x >> 16);
   int2 wq[strip::kMaxStrips];
@@ -830,8 +1018,9 @@ k_strip_combine_one(StripCombineArgs a) {
   const float* const slabs = a.slabs + ((size_t)(b * a.oc + chl) * a.P) * a.slab_stride;
   const size_t fo = ((size_t)b * a.oc_total + a.ch0 + chl) * (size_t)a.mh * a.mw;
   const float ident = RED == kMax ? -INFINITY : INFINITY;
-  for (int i = first; i < listed; i += kCombineBlocks * kCombineThreads) {
+  for (int i = first; i < listed; i += seg_blocks * kCombineThreads) {
     if (i != first) entry = list[i];
+    if ((entry >> 24) == 0u) continue;       // (listed by a higher strip too: the lowest one's entry is the live one)
     const int z = uz0 + (int)(entry & 0xfffu), x = ux0 + (int)(((entry >> 12) & 0xfffu) << 2);
     float4 t[strip::kMaxStrips];
 #pragma unroll
@@ -860,20 +1049,22 @@ k_strip_combine_one(StripCombineArgs a) {
 template <int RED, int kCombineEntries>
 __global__ void __launch_bounds__(kCombineThreads)
 k_strip_combine(StripCombineArgs a) {
-  constexpr int kCombineBlocks = kCombineSlots / kCombineEntries;
   const int fcl = blockIdx.y;                  // (frame of the launch) * oc + channel of the group
   const int bl = fcl / a.oc, b = a.b0 + bl;
   const int chl = fcl - bl * a.oc;
-  constexpr int kStride = kCombineBlocks * kCombineThreads;
-  const int first = blockIdx.x * kCombineThreads + (int)threadIdx.x;
-  const uint32_t* const list = a.g_list + (size_t)b * a.list_cap;
-  // (the thread's first entries are requested before the list's length is known: one round trip
+  const int nblocks = (int)gridDim.x;
+  const int seg = (int)blockIdx.x % a.P, lane_block = (int)blockIdx.x / a.P;
+  const int seg_blocks = (nblocks - seg + a.P - 1) / a.P;
+  const int kStride = seg_blocks * kCombineThreads;
+  const int first = lane_block * kCombineThreads + (int)threadIdx.x;
+  const uint32_t* const list = a.g_list + ((size_t)b * a.P + seg) * a.seg_cap;
+  // (the thread's first entries are requested before the segment's length is known: one round trip
   // less in a kernel that is nothing but a chain of them)
   uint32_t ent[kCombineEntries];
 #pragma unroll
-  for (int k = 0; k < kCombineEntries; ++k) ent[k] = first + k * kStride < a.list_cap ? list[first + k * kStride] : 0u;
-  const int listed = min(a.g_counts[b], a.list_cap);
-  if (blockIdx.x * kCombineThreads >= listed) return;
+  for (int k = 0; k < kCombineEntries; ++k) ent[k] = first + k * kStride < a.seg_cap ? list[first + k * kStride] : 0u;
+  const int listed = min(a.g_counts[(size_t)b * strip::kMaxStrips + seg], a.seg_cap);
+  if (lane_block * kCombineThreads >= listed) return;
   const int2 u_raw = *reinterpret_cast<const int2*>(a.g_unions + b);
   const int ux0 = (short)(u_raw.x & 0xffff), uz0 = (short)(u_raw.x >> 16);
   int2 wq[strip::kMaxStrips];
@@ -919,7 +1110,7 @@ k_strip_combine(StripCombineArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < kCombineEntries; ++k) {
-      if (base + k * kStride >= listed) continue;
+      if (base + k * kStride >= listed || (ent[k] >> 24) == 0u) continue;       // (past the end / a dead entry)
       // (the fill value takes part: utils.py:470-477 reduces INTO the filled canvas)
       float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
       if (has_a[k]) { acc.x = combine<RED>(acc.x, ta[k].x); acc.y = combine<RED>(acc.y, ta[k].y);
@@ -940,12 +1131,32 @@ k_strip_combine(StripCombineArgs a) {
   }
 }
 
-// Test hook kernel: the geometry of every frame exactly as k_strip_scatter derives it.
+// (B, 32) dm_frame records in device memory -> StripPose records (test hook's input)
 __global__ void __launch_bounds__(64)
-k_strip_geometry_dump(const strip::Cfg* cfg, const float* frames, strip::FrameGeom* out) {
+k_pose_records(const float* frames, float* poses, int B) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const float* f = frames + (size_t)b * 32;
+  float* q = poses + (size_t)b * kPoseFloats;
+  q[0] = f[10]; q[1] = f[12]; q[2] = f[16]; q[3] = f[18]; q[4] = f[19]; q[5] = f[20]; q[6] = f[21]; q[7] = f[22];
+  q[8] = f[9]; q[9] = q[10] = q[11] = 0.0f;
+}
+
+// Test hook kernel: the geometry of every frame exactly as k_strip_scatter derives it (the same
+// device function, the rig in the kernel arguments, the poses in device memory).
+__global__ void __launch_bounds__(64)
+k_strip_geometry_dump(strip::RigArgs rig, const float* poses, strip::FrameGeom* out) {
   __shared__ strip::FrameGeom g;
-  const float* f = frames + (size_t)blockIdx.x * 32;
-  strip_geometry_wave(*cfg, f[10], f[12], f[16], f[18], f[19], f[20], f[21], f[22], (int)threadIdx.x, &g);
+  const float* f = poses + (size_t)blockIdx.x * kPoseFloats;
+  StripPose ps;
+  ps.y0 = f[0]; ps.y2 = f[1]; ps.y6 = f[2]; ps.y8 = f[3]; ps.tx = f[4]; ps.tz = f[5]; ps.wo = f[6]; ps.ho = f[7];
+  ps.cam_h = f[8]; ps.pad0 = ps.pad1 = ps.pad2 = 0.0f;
+  __shared__ GeomLds gl;
+  const int lane = (int)threadIdx.x;
+  frame_geometry_wave64(rig, ps, lane, &gl);
+  __syncthreads();
+  if (lane < strip::kMaxStrips) { g.win[lane] = gl.win[lane]; g.L[lane] = gl.L[lane]; g.R[lane] = gl.R[lane]; }
+  if (lane == 0) { g.U = gl.U; g.ok = gl.ok; g.inside = gl.inside; }
   __syncthreads();
   if (threadIdx.x == 0) out[blockIdx.x] = g;
 }

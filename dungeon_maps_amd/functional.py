@@ -264,11 +264,12 @@ def _orth_project(depth_map, value_map, valid_map, cam_pose, width_offset, heigh
     fused = torch.empty(shape[1:], dtype=torch.float32, device=call.dev)
     fmask = torch.empty(shape[1:], dtype=torch.bool, device=call.dev)
   ws, ws_bytes = call.workspace()
+  _native.check_status()
   with _on_device(call.dev):
     _native.check(_native.lib().dm_orth_project_f32(
         ctypes.byref(p), _ptr(call.frames), _ptr(call.depth), _ptr(call.value),
         _ptr(call.valid), _ptr(topdown), _ptr(mask), _ptr(height), _ptr(fused), _ptr(fmask),
-        _ptr(ws), ws_bytes, _stream_ptr(call.dev)))
+        _ptr(ws), ws_bytes, _native.status_ptr(), _stream_ptr(call.dev)))
   if call.target != call.dev:
     topdown, mask = topdown.to(call.target), mask.to(call.target)
     height = None if height is None else height.to(call.target)
@@ -341,20 +342,21 @@ def orth_project_fused(
     _native.check(_native.lib().dm_orth_project_fused_f32(
         ctypes.byref(p), _ptr(call.frames), _ptr(call.depth), _ptr(call.value),
         _ptr(call.valid), _ptr(out), _ptr(mask), int(accumulate), _ptr(ws), ws_bytes,
-        _stream_ptr(call.dev)))
+        _native.status_ptr(), _stream_ptr(call.dev)))
   if call.target != call.dev:       # outputs live on the depth map's device (maps.py:227-232)
     out, mask = out.to(call.target), mask.to(call.target)
   return out, mask
 
 
 class PreparedProjection:
-  """The camera state of a batch uploaded and analysed once (``dm_frames_prepare_f32``), then
-  projected any number of times: ``orth_project`` / ``orth_project_and_fuse`` on it enqueue the
-  kernels and nothing else -- no host-side geometry, no copy, nothing that depends on the
-  poses -- so the calls are cheap on the host and may be captured into a HIP graph
-  (``torch.cuda.graph``) and replayed.  New poses for the same shapes: ``update(cam_pose=...)``
-  re-uploads into the same buffers (stream ordered; a captured graph stays valid as long as
-  the plan does not change, which ``update`` checks).
+  """The camera state of a batch validated once and kept in a small device buffer (48 bytes per
+  frame, ``dm_frames_prepare_f32``), then projected any number of times: ``orth_project`` /
+  ``orth_project_and_fuse`` on it enqueue the kernels and nothing else -- no host-side frame
+  table, no validation -- so the calls are cheap on the host, and because the kernels read the
+  poses from that buffer (not from their arguments, as plain calls do) a launch sequence captured
+  into a HIP graph (``torch.cuda.graph``) projects whatever poses the buffer holds when it is
+  replayed.  New poses for the same shapes: ``update(cam_pose=...)`` -- the launch plan is
+  derived on the host first and the buffer is written only if the plan is unchanged.
 
   Made by ``MapProjector.prepare`` / ``prepare_orth_project``.  Applies where the library's
   strip path does (max / min, ``trunc_depth_min >= 0`` and ``trunc_depth_max`` given, map and
@@ -390,33 +392,40 @@ class PreparedProjection:
     with _on_device(self.dev):
       self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
       self.ws = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=self.dev)
-    self.plan = _native.FramesPlan()
+    self.plan = None
     self._frames = None
     self.update(cam_pose)
 
   def update(self, cam_pose=None, **camera) -> "PreparedProjection":
     """Upload other poses (and optionally ``cam_pitch`` / ``cam_height`` / offsets) for the same
-    shapes; raises if they need a different launch plan than the one already in use."""
+    shapes.  Raises -- before anything is written to the device -- if they need a different
+    launch plan than the one in use (e.g. another pitch: make a new PreparedProjection)."""
     import ctypes
-    self._camera.update({k: v for k, v in camera.items() if v is not None})
-    table = frames.build_frame_table(self.shape_in[0], cam_pose, self._camera["cam_pitch"],
-                                     self._camera["cam_height"], self._camera["width_offset"],
-                                     self._camera["height_offset"])
+    camera = {k: v for k, v in camera.items() if v is not None}
+    unknown = set(camera) - set(self._camera)
+    if unknown:
+      raise TypeError(f"update() got unexpected keyword arguments {sorted(unknown)}")
+    merged = dict(self._camera, **camera)
+    table = frames.build_frame_table(self.shape_in[0], cam_pose, merged["cam_pitch"],
+                                     merged["cam_height"], merged["width_offset"],
+                                     merged["height_offset"])
     plan = _native.FramesPlan()
     with _on_device(self.dev):
-      _native.check(_native.lib().dm_frames_prepare_f32(
+      rc = _native.lib().dm_frames_prepare_f32(
           ctypes.byref(self.params), _ptr(table), _ptr(self.buf), self.buf.numel(),
-          ctypes.byref(plan), _stream_ptr(self.dev)))
-    had = self._frames is not None
-    if had and bytes(plan) != bytes(self.plan):
-      raise _native.NativeError("the new camera state needs a different launch plan than the "
-                                "prepared one: make a new PreparedProjection")
+          None if self.plan is None else ctypes.byref(self.plan), ctypes.byref(plan),
+          _stream_ptr(self.dev))
+    _native.check(rc)       # (a mismatch leaves the buffer, the plan and the camera as they were)
+    self._camera = merged
     self.plan, self._frames = plan, table        # (the host table must outlive the async copy)
     return self
 
   def status(self) -> int:
-    """0 unless a projection found a frame whose geometry did not fit the plan (synchronises)."""
-    return int(self.buf[1024:1028].view(torch.int32).item())
+    """Bits a projection raised so far (0: none).  Synchronises the device first, so that every
+    projection enqueued before the call has reported; the same bits make the NEXT projection
+    call of the process raise ``NativeError`` without any synchronisation."""
+    torch.cuda.synchronize(self.dev)
+    return int(_native.status_word()[1][0])
 
   def _check(self, t, channels, dtype, what):
     B, _, H, W = self.shape_in
@@ -442,12 +451,13 @@ class PreparedProjection:
       out = (torch.empty(shape, dtype=torch.float32, device=self.dev),
              torch.empty(shape, dtype=torch.bool, device=self.dev))
     top, mask = out
+    _native.check_status()
     with _on_device(self.dev):
       _native.check(_native.lib().dm_orth_project_prepared_f32(
           ctypes.byref(p), ctypes.byref(self.plan), _ptr(self.buf), _ptr(depth_map), _ptr(value_map),
           _ptr(valid_map), _ptr(top), _ptr(mask), _ptr(height),
           None if fused is None else _ptr(fused[0]), None if fused is None else _ptr(fused[1]),
-          _ptr(self.ws), self.ws.numel(), _stream_ptr(self.dev)))
+          _ptr(self.ws), self.ws.numel(), _native.status_ptr(), _stream_ptr(self.dev)))
     return top, mask
 
   def orth_project(self, depth_map, value_map=None, valid_map=None, get_height_map=False, out=None):

@@ -33,15 +33,30 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 5
+#define DM_ABI_VERSION 6
 
 typedef enum dm_status {
   DM_OK = 0,
   DM_ERR_INVALID_ARGUMENT = -1,
   DM_ERR_UNSUPPORTED = -2,
   DM_ERR_WORKSPACE_TOO_SMALL = -3,
-  DM_ERR_LAUNCH = -4
+  DM_ERR_LAUNCH = -4,
+  DM_ERR_PLAN_MISMATCH = -5
 } dm_status;
+
+/*
+ * Status word: the projection entry points take `status_dev`, an int32 in memory the device can
+ * write and the caller can read without synchronising (pinned host memory; device memory works
+ * too), or NULL.  The kernels store dm_status_bits into it when they refuse work the host could
+ * not refuse up front -- today: a frame of a PREPARED batch (dm_orth_project_prepared_f32) whose
+ * pose record in the caller's device buffer no longer fits the plan it is projected with; such a
+ * frame's maps come out holding the fill value.  The word is sticky (never cleared by the
+ * library): a caller polls it before its next call and treats non-zero as a failed projection.
+ */
+typedef enum dm_status_bits {
+  DM_STATUS_FRAME_DID_NOT_FIT = 1,
+  DM_STATUS_LIST_OVERFLOW = 2
+} dm_status_bits;
 
 /* utils.Reduction (dungeon_maps/utils.py:52-76) */
 typedef enum dm_reduction {
@@ -116,7 +131,10 @@ size_t dm_orth_project_workspace_bytes(const dm_params* p);
  *              -- MapBuilder.merge / fuse_topdown_maps, maps.py:2181-2287,
  *              2471-2508, for maps sharing one frame) and its mask.
  *              The per-rank partial of the "projected+fused" metric.
- * Outputs are fully written (no pre-initialisation needed).
+ * Outputs are fully written (no pre-initialisation needed).  On the strip path (max / min with
+ * both depth truncations, the projector's axis-aligned rotations, one pitch per batch) the call
+ * enqueues kernels only: the frames' camera state travels in the scatter kernel's arguments
+ * (up to 64 frames per launch), nothing is copied to the device.
  */
 int dm_orth_project_f32(const dm_params* p, const dm_frame* frames,
                         const float* depth_dev, const float* value_dev,
@@ -124,7 +142,7 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames,
                         uint8_t* mask_dev, float* height_dev,
                         float* fused_dev, uint8_t* fused_mask_dev,
                         void* workspace_dev, size_t workspace_bytes,
-                        void* stream);
+                        int32_t* status_dev, void* stream);
 
 /*
  * Batch-fused projection: all B frames are reduced (max or min only) into ONE
@@ -141,7 +159,7 @@ int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames,
                               const uint8_t* valid_dev, float* out_dev,
                               uint8_t* mask_dev, int accumulate,
                               void* workspace_dev, size_t workspace_bytes,
-                              void* stream);
+                              int32_t* status_dev, void* stream);
 
 /*
  * camera_affine_grid (maps.py:353-460): per pixel of depth (B, dc, H, W) the
@@ -249,12 +267,12 @@ int dm_scatter_f32(const float* values_dev, const int64_t* index_dev, float* can
                    size_t workspace_bytes, void* stream);
 
 /*
- * Prepared frames: the camera state of a batch uploaded and analysed ONCE, then projected any
- * number of times with nothing pose dependent left on the host -- the launch sequence of
- * dm_orth_project_prepared_f32 depends only on `p`, `plan` and the pointers (no host-side
- * geometry, no copy), so it may be captured into a HIP graph and replayed; to project other
- * poses through a captured graph, call dm_frames_prepare_f32 again on the same buffer (stream
- * ordered) -- the replay is valid when the new plan equals the captured one.
+ * Prepared frames: the camera state of a batch kept in a device buffer of the caller's, so that a
+ * captured launch sequence (HIP graph) can project OTHER poses when replayed -- the kernels of
+ * dm_orth_project_prepared_f32 read the frames' pose records (48 bytes each) from `prepared_dev`
+ * instead of from their own arguments; everything else is dm_orth_project_f32's strip path.  To
+ * project other poses through a captured graph, call dm_frames_prepare_f32 again on the same buffer
+ * (stream ordered) with `must_match` = the captured plan.
  *
  * Applies where the strip path does (max / min, trunc_depth_min >= 0 and a finite
  * trunc_depth_max, map_width and image width multiples of 4, one camera pitch per batch, and the
@@ -263,19 +281,22 @@ int dm_scatter_f32(const float* values_dev, const int64_t* index_dev, float* can
  *
  *   dm_frames_prepared_bytes     device bytes a prepared batch of p->B frames needs (0: the strip
  *                                path never applies to `p`); the buffer must be 256-byte aligned.
- *   dm_frames_prepare_f32        validates `frames` (host, as for dm_orth_project_f32), fills
- *                                `plan_out` and enqueues ONE copy into `prepared_dev` plus one small
- *                                kernel that derives the frames' geometry there (windows, per-row
- *                                covers, the list of cells several strips share).  What it replaces
- *                                in the reference: the per-call pose handling of
- *                                MapProjector.orth_project (maps.py:1406-1465: cam_pose -> rotation
- *                                and translation tensors, utils.py:229-330) hoisted out of the
- *                                per-batch call.
- *   dm_orth_project_prepared_f32 dm_orth_project_f32 with the frames taken from `prepared_dev`.
- *                                A batch whose geometry does not fit `plan` (frames changed behind
- *                                the plan's back) projects nothing for the frames concerned and
- *                                sets the int32 at byte 1024 of `prepared_dev` non-zero.
- *                                One projection at a time per prepared buffer (stream ordered).
+ *   dm_frames_prepare_f32        validates `frames` (host, as for dm_orth_project_f32) and derives the
+ *                                launch plan ON THE HOST first; if `must_match` is given and the plan
+ *                                differs from it, returns DM_ERR_PLAN_MISMATCH and enqueues NOTHING
+ *                                (`prepared_dev` keeps the records it held).  Otherwise fills
+ *                                `plan_out` and enqueues ONE copy of p->B pose records into
+ *                                `prepared_dev`.  What it replaces in the reference: the per-call pose
+ *                                handling of MapProjector.orth_project (maps.py:1406-1465: cam_pose ->
+ *                                rotation and translation tensors, utils.py:229-330) hoisted out of
+ *                                the per-batch call.
+ *   dm_orth_project_prepared_f32 dm_orth_project_f32 with the frames taken from `prepared_dev`; `plan`
+ *                                must be the one dm_frames_prepare_f32 returned for these parameters
+ *                                (checked: strips, strip width, LDS window / table sizes, slack), else
+ *                                DM_ERR_UNSUPPORTED.  A frame whose record in `prepared_dev` does not
+ *                                fit `plan` (the buffer changed behind the plan's back) projects
+ *                                nothing and raises DM_STATUS_FRAME_DID_NOT_FIT in `status_dev`.
+ *                                One projection at a time per workspace (stream ordered).
  */
 typedef struct dm_frames_plan {
   int32_t strips;            /* column strips per frame */
@@ -284,17 +305,21 @@ typedef struct dm_frames_plan {
   int32_t max_rows;          /* rows / cells of the largest union window of a frame */
   int32_t max_union_cells;
   int32_t slack_cells;       /* float32 slack the windows carry */
-  int32_t reserved[2];
+  int32_t magnitude;         /* bound (cells, quantised) on the frames' offsets / translations the slack was derived for */
+  float pitch[4];            /* the batch's pitch rotation: Rp[4], Rp[5], Rp[7], Rp[8] */
+  int32_t reserved;
 } dm_frames_plan;
 
 size_t dm_frames_prepared_bytes(const dm_params* p);
 int dm_frames_prepare_f32(const dm_params* p, const dm_frame* frames, void* prepared_dev,
-                          size_t prepared_bytes, dm_frames_plan* plan_out, void* stream);
-int dm_orth_project_prepared_f32(const dm_params* p, const dm_frames_plan* plan, void* prepared_dev,
+                          size_t prepared_bytes, const dm_frames_plan* must_match,
+                          dm_frames_plan* plan_out, void* stream);
+int dm_orth_project_prepared_f32(const dm_params* p, const dm_frames_plan* plan, const void* prepared_dev,
                                  const float* depth_dev, const float* value_dev,
                                  const uint8_t* valid_dev, float* out_dev, uint8_t* mask_dev,
                                  float* height_dev, float* fused_dev, uint8_t* fused_mask_dev,
-                                 void* workspace_dev, size_t workspace_bytes, void* stream);
+                                 void* workspace_dev, size_t workspace_bytes, int32_t* status_dev,
+                                 void* stream);
 
 /*
  * Test hook: non-zero forces dm_orth_project_f32 onto the generic
@@ -347,6 +372,11 @@ int dm_debug_force_bands(int on);
  *                                per channel on the strip path of the calling thread, instead of
  *                                taking it from the list the index pass leaves (non-zero, the
  *                                default); returns the previous setting.  Same results.
+ *   dm_debug_strip_slab_budget   caps the bytes of slabs one channel group of the calling thread's
+ *                                strip-path projections may use (0 = no cap; returns the previous
+ *                                cap), so that value maps go through several channel groups -- the
+ *                                route a many-class object map takes when its slabs exceed the
+ *                                workspace -- at sizes the oracle finishes in seconds.
  *   dm_debug_strip_geometry      host only (no GPU needed): the strip path's geometry for `p` and
  *                                the given frames exactly as the kernels derive it.
  *                                out_geom (B, 8 + 4*8) int32 per frame: {ok | inside << 8 (bit s of
@@ -360,7 +390,7 @@ int dm_debug_force_bands(int on);
  *                                is sized with (valid for every yaw / position of the camera).
  *                                Returns P, 0 when the strip path does not apply to `p`.
  *   dm_debug_strip_geometry_dev  the same windows / edges from the device's own evaluation
- *                                (frames on the host and on the device; geom_dev: B * 336 + 1024 bytes of 8-byte
+ *                                (frames on the host and on the device; geom_dev: B * (336 + 48) bytes of 8-byte
  *                                aligned device scratch, copied back by
  *                                the caller); returns P, 0 (not applicable) or < 0.
  */
@@ -368,6 +398,7 @@ int dm_debug_last_path(void);
 int dm_debug_force_legacy_window(int on);
 int dm_debug_force_strips(int strips);
 int dm_debug_strip_value_list(int on);
+size_t dm_debug_strip_slab_budget(size_t bytes);
 int dm_debug_strip_geometry(const dm_params* p, const dm_frame* frames, int32_t* out_geom,
                             uint32_t* out_covers, int32_t* out_bound);
 int dm_debug_strip_geometry_dev(const dm_params* p, const dm_frame* frames_host,

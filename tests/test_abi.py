@@ -51,13 +51,13 @@ def test_argument_validation_without_gpu():
   lib = _native.lib()
   p = _native.Params()
   p.B, p.dc, p.vc, p.H, p.W, p.mh, p.mw = 1, 2, 3, 4, 4, 8, 8   # dc not in (1, vc)
-  rc = lib.dm_orth_project_f32(ctypes.byref(p), 1, 1, 1, None, 1, 1, None, None, None, None, 0, None)
+  rc = lib.dm_orth_project_f32(ctypes.byref(p), 1, 1, 1, None, 1, 1, None, None, None, None, 0, None, None)
   assert rc == -1 and b"depth channels" in lib.dm_last_error()
   p.dc, p.vc, p.reduction = 1, 0, 9
-  rc = lib.dm_orth_project_f32(ctypes.byref(p), 1, 1, None, None, 1, 1, None, None, None, None, 0, None)
+  rc = lib.dm_orth_project_f32(ctypes.byref(p), 1, 1, None, None, 1, 1, None, None, None, None, 0, None, None)
   assert rc == -1 and b"reduction" in lib.dm_last_error()
   p.reduction = 2
-  rc = lib.dm_orth_project_fused_f32(ctypes.byref(p), 1, 1, None, None, 1, 1, 0, None, 0, None)
+  rc = lib.dm_orth_project_fused_f32(ctypes.byref(p), 1, 1, None, None, 1, 1, 0, None, 0, None, None)
   assert rc == -2 and b"max/min" in lib.dm_last_error()
   with pytest.raises(_native.NativeError):
     _native.check(rc)

@@ -42,7 +42,7 @@ lib = _native.lib()
 stream = torch.cuda.current_stream().cuda_stream
 def native():
   lib.dm_orth_project_f32(ctypes.byref(p), call.frames.data_ptr(), depth.data_ptr(), None, None,
-                          top.data_ptr(), mask.data_ptr(), None, None, None, ws.data_ptr(), wsb, stream)
+                          top.data_ptr(), mask.data_ptr(), None, None, None, ws.data_ptr(), wsb, None, stream)
 print("native call only         %7.1f us  (window calc + memcpy + 2 launches)" % t(native))
 print("3x torch.empty           %7.1f us" % t(lambda: (torch.empty((B, 1, mh, mw), device="cuda"), torch.empty((B, 1, mh, mw), dtype=torch.bool, device="cuda"), torch.empty(wsb, dtype=torch.uint8, device="cuda"))))
 print("workspace_bytes call     %7.1f us" % t(lambda: lib.dm_orth_project_workspace_bytes(ctypes.byref(p))))

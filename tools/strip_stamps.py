@@ -53,11 +53,16 @@ def seg(name, i, j):
   print(f"  {name:44s} {np.median(dd):8.2f} {dd.max():8.2f}")
 print("workgroups: %d   per-WG phase time in us (median / max):" % len(st))
 seg("scalar loads, lds init, ray-slope table", 0, 1)
-seg("row entries -> lds, barrier", 1, 2)
+if raw[:, 7].any() and raw[:, 8].any():
+  seg("geometry (wave 0) + barrier", 1, 7)
+  seg("row tables", 7, 8)
+  seg("loop scalars reloaded + barrier", 8, 2)
+else:
+  seg("row entries -> lds, barrier", 1, 2)
 seg("second loads (head of the pipeline)", 2, 11)
 seg("pixel loop", 11, 4)
 seg("rest of the fill duty + barrier", 4, 5)
-if raw[:, 7].any():
+if False:
   seg("tail: shared groups -> slab", 5, 7)
   seg("tail: drain + barrier", 7, 8)
   seg("tail: owned groups -> map (counter in flight)", 8, 9)

@@ -3,7 +3,9 @@
 
 One step = one pass of the hot path over one batch of synthetic frames per GPU:
 
-  1. orth_project  B=64 x (640x480) depth -> (64, 1, 512, 512) height maps+masks
+  1. orth_project  B=64 x (640x480) depth -> (64, 1, 512, 512) height maps+masks, with a NEW
+     set of camera poses on every step, passed the way the reference's callers pass them
+     (MapProjector.orth_project(depth, cam_pose=...), maps.py:1406-1465)
      (BASELINE.json configs[1]; the kernel sequence the roofline is quoted on)
   2. fuse          per-rank partial global map = max over the rank's frames
   3. all-reduce    element-wise max of the partial maps over RCCL (N > 1 only)
@@ -91,9 +93,6 @@ def main():
   ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
   ap.add_argument("--depth", default="uniform", choices=["uniform", "scene"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--no-prepare", action="store_true",
-                  help="upload the poses on every call (MapProjector.orth_project_and_fuse) instead "
-                       "of once before the timed region (MapProjector.prepare)")
   ap.add_argument("--no-other-configs", action="store_true",
                   help="skip the other BASELINE.json configs (reported outside the timed region)")
   ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -136,22 +135,18 @@ def main():
   depth, pose, value = synthetic_inputs(B, H, W, C, 1234 + rank, dev, args.depth == "scene")
   depth_d = depth.to(dev)
   value_d = None if value is None else value.to(dev)
+  # the camera moves: every step gets another set of poses (host tensors, as a caller holds them)
+  gp = torch.Generator().manual_seed(4321 + rank)
+  pose_sets = [pose]
+  for _ in range(7):
+    q = torch.empty(B, 3).uniform_(-1, 1, generator=gp)
+    q[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=gp)
+    pose_sets.append(q)
   proj = dmap.MapProjector(
       width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
       width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
       trunc_depth_min=0.15, trunc_depth_max=5.05, clip_border=0, to_global=True,
       fill_value=fill, reduction="max")
-
-  # The camera state (poses, pitch, offsets) is an input like the depth maps: uploaded once,
-  # resident in HBM before the timed region (MapProjector.prepare -> dm_frames_prepare_f32).
-  # The steps then only enqueue the kernels.  (The same steps with the poses uploaded on every
-  # call are timed after the headline loop and reported as `pose_upload_per_call`.)
-  prep = None
-  if args.workload != "cfg4" and not args.no_prepare:
-    try:
-      prep = proj.prepare(B, cam_pose=pose, value_channels=C)
-    except _native.NativeError:
-      prep = None
 
   # HIP events on the launch stream (torch's current stream): before the call and,
   # through the library's measurement hook, right after the kernels that produce the
@@ -167,6 +162,8 @@ def main():
   if fused_only:     # one trajectory, shared offsets
     k = torch.arange(B, dtype=torch.float32) + rank * B
     pose = torch.stack((0.02 * k, 0.01 * k, 0.01 * k), dim=1)
+    pose_sets = [pose]
+  calls = {"n": 0}      # steps issued so far (warm-up included): picks the step's pose set
 
   # Cross-rank fuse: every step writes its partial global map into a slot of a ring;
   # once per RING steps ONE RCCL all-reduce(max) fuses the whole ring (fewer, larger
@@ -206,6 +203,8 @@ def main():
   def step(i=None):
     if i is not None and i % args.event_every != 0:
       i = None                   # untimed by events (the wall clock still covers it)
+    pose = pose_sets[calls["n"] % len(pose_sets)]
+    calls["n"] += 1
     if fused_only:
       if i is not None:
         ev_a[i].record()
@@ -224,13 +223,9 @@ def main():
       lib.dm_debug_record_before_projection(ev_a[i].cuda_event)
       lib.dm_debug_record_after_projection(ev_b[i].cuda_event)
     # per-frame maps + masks and this rank's partial global map, one launch sequence
-    if prep is not None:
-      top, mask, fused, fmask = prep.orth_project_and_fuse(
-          depth_d, value_map=value_d, fused_out=next_slot() if dist is not None else None)
-    else:
-      top, mask, fused, fmask = proj.orth_project_and_fuse(
-          depth_d, value_map=value_d, cam_pose=pose,
-          fused_out=next_slot() if dist is not None else None)
+    top, mask, fused, fmask = proj.orth_project_and_fuse(
+        depth_d, value_map=value_d, cam_pose=pose,
+        fused_out=next_slot() if dist is not None else None)
     if dist is not None and state["slot"] == RING:
       flush_ring()                                      # RCCL, element-wise max
     return top, mask, fused, fmask
@@ -266,35 +261,38 @@ def main():
   torch.cuda.synchronize()
   barrier()
   elapsed = time.perf_counter() - t0
+  rank_ms = [elapsed / args.steps * 1e3]
   if dist is not None:
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
+    elapsed = max(float(x.item()) for x in every)         # the slowest rank's clock
 
   proj_ms = np.array([ev_a[i].elapsed_time(ev_b[i]) for i in range(0, args.steps, args.event_every)])
   bracketed_s = float(np.mean(proj_ms)) * 1e-3
   kernel_s = bracketed_s
   b2b_note = None
-  if prep is not None and not fused_only:
+  last_pose = pose_sets[(calls["n"] - 1) % len(pose_sets)]      # the poses of `out`
+  if not fused_only:
     # The launch sequence's average duration without the cost of the measurement itself: a HIP
     # event between two kernels is a stream operation of its own (~1.5 us each way), so
-    # N launch sequences are enqueued back to back between ONE pair of events and the total is
-    # divided by N.  This is the figure rocprofv3's per-kernel averages add up to (profiles/).
+    # N launch sequences (each with its own set of poses) are enqueued back to back between ONE
+    # pair of events and the total is divided by N.  This is the figure rocprofv3's per-kernel
+    # averages add up to (profiles/).
     n_b2b = 64
-    outs = (torch.empty((B, C_out, mh, mw), dtype=torch.float32, device=dev),
-            torch.empty((B, C_out, mh, mw), dtype=torch.bool, device=dev))
-    for _ in range(3):
-      prep.orth_project(depth_d, value_map=value_d, out=outs)
+    for j in range(3):
+      proj.orth_project(depth_d, value_map=value_d, cam_pose=pose_sets[j % len(pose_sets)])
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(n_b2b):
-      prep.orth_project(depth_d, value_map=value_d, out=outs)
+    for j in range(n_b2b):
+      proj.orth_project(depth_d, value_map=value_d, cam_pose=pose_sets[j % len(pose_sets)])
     e1.record()
     torch.cuda.synchronize()
     kernel_s = e0.elapsed_time(e1) * 1e-3 / n_b2b
-    b2b_note = (f"{n_b2b} launch sequences back to back between one pair of HIP events on the launch "
-                f"stream, total / {n_b2b}")
+    b2b_note = (f"{n_b2b} orth_project calls (a new set of poses each) back to back between one pair of "
+                f"HIP events on the launch stream, total / {n_b2b}")
   alg = algorithmic_bytes(B, H, W, mh, mw, C, fused_only)
   achieved = alg / kernel_s / 1e9
 
@@ -317,6 +315,10 @@ def main():
       "vs_baseline": None,
       "dtype": "f32",
       "data": "synthetic",
+      "ranks": {"world_size": world,
+                "backend": (dist.get_backend() if dist is not None else None),
+                "launched_by_torch_distributed": dist is not None,
+                "ms_per_step_min": min(rank_ms), "ms_per_step_max": max(rank_ms)},
       "config": {
           "workload": f"{args.workload}: B={B}/GPU, {W}x{H} depth -> {mw}x{mh} "
                       f"{'height map' if not C else f'{C}-class object map'}, "
@@ -335,12 +337,11 @@ def main():
           "frac": achieved / HBM_PEAK_GBS,
           "traffic": traffic,
           "traffic_source": traffic_note,
-          "kernel": "orth_project launch sequence of dm_orth_project_prepared_f32: k_strip_scatter + "
-                    "k_strip_combine (everything that produces the per-frame maps and masks from "
-                    "the depth maps and the resident camera state; the batch fuse that follows "
-                    "is excluded)" if prep is not None else
-                    "orth_project launch sequence of dm_orth_project_f32 (frame-table copy + "
-                    "scatter + merge; the batch fuse that follows is excluded)",
+          "kernel": "orth_project launch sequence of dm_orth_project_f32: k_strip_scatter (the poses "
+                    "of the call in its arguments; geometry, projection, owned cells and fill) + "
+                    "k_strip_combine (cells several strips share) -- everything that produces the "
+                    "per-frame maps and masks from the depth maps and the call's poses; the batch "
+                    "fuse that follows is excluded",
           "algorithmic_bytes_per_launch": alg,
           "launch_us": kernel_s * 1e6,
           "launch_us_how": b2b_note or "HIP events around every 8th step's launch sequence",
@@ -362,38 +363,50 @@ def main():
     result["config"]["workload"] = (f"cfg4: B={B}/GPU, {W}x{H} depth fused straight into one "
                                     f"{mw}x{mh} global map (max)"
                                     f"{' + RCCL all-reduce(max)' if world > 1 else ''}")
-  result["config"]["camera_state"] = ("resident in HBM before the timed region (MapProjector.prepare)"
-                                      if prep is not None else "uploaded on every call")
-  if rank == 0 and world == 1 and prep is not None:
-    # the same step with the poses uploaded on every call (what MapBuilder.step does per frame)
-    n_p = max(20, min(100, args.steps))
-    pa = [torch.cuda.Event(enable_timing=True) for _ in range(n_p)]
-    pb = [torch.cuda.Event(enable_timing=True) for _ in range(n_p)]
-    for e in pa + pb:
-      e.record()
-    for _ in range(5):
-      proj.orth_project_and_fuse(depth_d, value_map=value_d, cam_pose=pose)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(n_p):
-      lib.dm_debug_record_before_projection(pa[i].cuda_event)
-      lib.dm_debug_record_after_projection(pb[i].cuda_event)
-      proj.orth_project_and_fuse(depth_d, value_map=value_d, cam_pose=pose)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    result["pose_upload_per_call"] = {
-        "value": B * n_p / dt, "unit": "frames/s", "steps": n_p, "ms_per_step": dt / n_p * 1e3,
-        "launch_us": float(np.mean([pa[i].elapsed_time(pb[i]) for i in range(n_p)])) * 1e3,
-        "note": "MapProjector.orth_project_and_fuse(depth, cam_pose=...): frame table built on the "
-                "host and copied to the GPU inside every call (events bracket every call here)"}
+  result["config"]["camera_state"] = (f"a new set of {B} poses on every step, passed per call "
+                                      "(MapProjector.orth_project_and_fuse(depth, cam_pose=...)): "
+                                      "they travel in the kernel arguments of the call's launches")
+  if rank == 0 and world == 1 and not fused_only:
+    # the same step on PREPARED frames: one fixed set of poses kept in a device buffer
+    # (MapProjector.prepare; what a fixed rig or a captured HIP graph uses) -- same kernels, the
+    # poses read from that buffer instead of from the kernel arguments
+    try:
+      prep = proj.prepare(B, cam_pose=pose_sets[0], value_channels=C)
+      n_p = max(20, min(100, args.steps))
+      for _ in range(5):
+        keep = prep.orth_project_and_fuse(depth_d, value_map=value_d)
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for i in range(n_p):
+        keep = prep.orth_project_and_fuse(depth_d, value_map=value_d)
+      torch.cuda.synchronize()
+      dt = time.perf_counter() - t0
+      outs = (torch.empty((B, C_out, mh, mw), dtype=torch.float32, device=dev),
+              torch.empty((B, C_out, mh, mw), dtype=torch.bool, device=dev))
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      for _ in range(64):
+        prep.orth_project(depth_d, value_map=value_d, out=outs)
+      e1.record()
+      torch.cuda.synchronize()
+      result["prepared_frames"] = {
+          "value": B * n_p / dt, "unit": "frames/s", "steps": n_p, "ms_per_step": dt / n_p * 1e3,
+          "launch_us": e0.elapsed_time(e1) * 1e3 / 64,
+          "note": "MapProjector.prepare(...).orth_project_and_fuse(depth): one fixed set of poses in a "
+                  "device buffer (64 launch sequences back to back between one pair of events)"}
+      del prep, outs, keep
+    except _native.NativeError as e:
+      result["prepared_frames"] = {"error": str(e)[:200]}
   if rank == 0 and world == 1 and args.depth == "uniform" and not fused_only and C == 0:
     # the same step on scene-like depth (floor + walls: many pixels per cell):
     # reported beside the headline number, outside its timed region
     sdepth, spose, _ = synthetic_inputs(B, H, W, C, 1234 + rank, dev, True)
     sdepth = sdepth.to(dev)
-    sprep = None if prep is None else proj.prepare(B, cam_pose=spose)
-    sstep = (lambda: sprep.orth_project_and_fuse(sdepth)) if sprep is not None else \
-            (lambda: proj.orth_project_and_fuse(sdepth, cam_pose=spose))
+    scount = {"n": 0}
+
+    def sstep():
+      scount["n"] += 1
+      return proj.orth_project_and_fuse(sdepth, cam_pose=pose_sets[scount["n"] % len(pose_sets)])
     for _ in range(10):
       sstep()
     torch.cuda.synchronize()
@@ -415,7 +428,7 @@ def main():
       and args.depth == "uniform":
     result["other_configs"] = other_configs(dmap, lib, dev)
   if rank == 0 and world == 1 and not args.no_cpu_baseline and not fused_only:
-    result["cpu_baseline"] = cpu_baseline(depth, pose, value, H, W, mh, mw, fill,
+    result["cpu_baseline"] = cpu_baseline(depth, last_pose, value, H, W, mh, mw, fill,
                                           args.cpu_seconds, out)
   if rank == 0:
     print(json.dumps(result))

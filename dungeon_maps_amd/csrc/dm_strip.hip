@@ -259,6 +259,7 @@ inline size_t pixel_list_bytes(const dm_params& p) {     // (B, P, H, wp) uint16
   return up256((size_t)p.B * p.H * ((size_t)p.W + 32 * strip::kMaxStrips) * 2);
 }
 thread_local int g_no_value_list = 0;      // dm_debug_strip_value_list(0): every channel recomputes its cells
+thread_local int g_last_info[4] = {0, 0, 0, 0};   // dm_debug_last_strip_info
 thread_local size_t g_strip_slab_budget = 0;    // dm_debug_strip_slab_budget: bytes of slabs per channel group (0: all there is)
 inline bool list_shape(const dm_params& p) { return p.vc >= kListMinChannels && p.dc == 1; }   // (sizes the workspace)
 inline bool wants_pixel_list(const dm_params& p) { return list_shape(p) && !g_no_value_list; }
@@ -412,6 +413,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const
       const float* keep_value = ia.value; float* keep_out = ia.out; uint8_t* keep_mask = ia.mask;
       ia.value = nullptr; ia.out = nullptr; ia.mask = nullptr; ia.oc = 1; ia.ch0 = 0; ia.oc_total = 1;
       e = launch(ifn, dim3(plan.P, 1, nb), dim3(kScatterThreads), lds_bytes, s, ia);
+      ++g_last_info[0];
       ia.value = keep_value; ia.out = keep_out; ia.mask = keep_mask; ia.oc_total = oc_total;
       if (e != hipSuccess) return e;
     }
@@ -421,6 +423,8 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const
       e = launch(kfn, from_list ? dim3(oc, plan.P, nb) : dim3(plan.P, oc, nb), dim3(kScatterThreads),
                  lds_bytes, s, sa);
       if (e != hipSuccess) return e;
+      ++g_last_info[1];
+      if (b0 == 0) ++g_last_info[3];
       StripCombineArgs ca;
       ca.b0 = b0; ca.oc = oc; ca.ch0 = ch0; ca.oc_total = oc_total; ca.mh = p.mh; ca.mw = p.mw;
       ca.P = plan.P; ca.slab_stride = rg.slab_stride; ca.seg_cap = sa.seg_cap; ca.fill = fill;
@@ -443,6 +447,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const
                      : launch(k_strip_combine_one<kMin>, g, dim3(kCombineThreads), 0, s, ca);
         }
         if (e != hipSuccess) return e;
+        ++g_last_info[2];
       }
     }
   }
@@ -546,6 +551,7 @@ hipError_t launch_strips(const dm_params& p, const Plan& plan, const Rig& rg, co
                          uint8_t* fused_mask, int* status, hipEvent_t after_projection, hipStream_t s) {
   const int oc_total = p.vc ? p.vc : p.dc;
   const bool is_max = p.reduction == DM_REDUCE_MAX;
+  g_last_info[0] = g_last_info[1] = g_last_info[2] = g_last_info[3] = 0;
   hipError_t e = strip_pass(p, plan, rg, poses, l, depth, value, valid, out, mask, oc_total, p.fill, is_max,
                             l.slab_bytes - hm, status, s);
   if (e != hipSuccess) return e;
@@ -693,6 +699,10 @@ extern "C" __attribute__((visibility("default"))) size_t dm_debug_strip_slab_bud
   const size_t old = dm::g_strip_slab_budget;
   dm::g_strip_slab_budget = bytes;
   return old;
+}
+
+extern "C" __attribute__((visibility("default"))) void dm_debug_last_strip_info(int32_t* out4) {
+  for (int i = 0; i < 4; ++i) out4[i] = dm::g_last_info[i];
 }
 
 extern "C" __attribute__((visibility("default"))) int dm_debug_force_legacy_window(int on) {

@@ -377,6 +377,11 @@ int dm_debug_force_bands(int on);
  *                                cap), so that value maps go through several channel groups -- the
  *                                route a many-class object map takes when its slabs exceed the
  *                                workspace -- at sizes the oracle finishes in seconds.
+ *   dm_debug_last_strip_info     what the calling thread's last strip-path projection launched (its
+ *                                value-map pass; a height pass behind it counts on top): out4 = {index-pass
+ *                                launches (value maps of many channels: the pixels' cells once for
+ *                                all channels), scatter / value-pass launches, combine launches,
+ *                                channel groups}.
  *   dm_debug_strip_geometry      host only (no GPU needed): the strip path's geometry for `p` and
  *                                the given frames exactly as the kernels derive it.
  *                                out_geom (B, 8 + 4*8) int32 per frame: {ok | inside << 8 (bit s of
@@ -399,6 +404,7 @@ int dm_debug_force_legacy_window(int on);
 int dm_debug_force_strips(int strips);
 int dm_debug_strip_value_list(int on);
 size_t dm_debug_strip_slab_budget(size_t bytes);
+void dm_debug_last_strip_info(int32_t* out4);
 int dm_debug_strip_geometry(const dm_params* p, const dm_frame* frames, int32_t* out_geom,
                             uint32_t* out_covers, int32_t* out_bound);
 int dm_debug_strip_geometry_dev(const dm_params* p, const dm_frame* frames_host,

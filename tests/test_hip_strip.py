@@ -362,3 +362,167 @@ def test_no_pixel_escapes_its_window_on_the_device(dmap, oracle):
       assert out_w == 0, (cfg, list(parts), n, out_w)
       window_cases += 1
   assert landed > 50_000 and strip_cases >= 15 and window_cases >= 60
+
+
+def test_update_with_another_plan_leaves_the_prepared_batch_untouched(dmap):
+  """PreparedProjection.update(): the launch plan is derived on the host first; poses that need
+  another plan (here: another camera pitch) raise BEFORE anything is written to the device --
+  the object keeps projecting the poses it held, bit-equal to what it gave before."""
+  from dungeon_maps_amd import _native
+  lib = _lib()
+  depth, poses, cfg = _cfg2_like()
+  proj = dmap.MapProjector(**cfg)
+  d = depth.cuda()
+  lib.dm_debug_force_strips(4)
+  try:
+    prep = proj.prepare(depth.shape[0], cam_pose=poses[0])
+    before = prep.orth_project(d)
+    plan_before = bytes(prep.plan)
+    with pytest.raises(_native.NativeError, match="different launch plan"):
+      prep.update(cam_pose=poses[1], cam_pitch=np.radians(-35.))
+    assert bytes(prep.plan) == plan_before
+    after = prep.orth_project(d)
+    assert torch.equal(after[0], before[0]) and torch.equal(after[1], before[1])
+    # ... and a matching update still goes through
+    prep.update(cam_pose=poses[1])
+    want = proj.orth_project(d, cam_pose=poses[1])
+    got = prep.orth_project(d)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    with pytest.raises(TypeError):
+      prep.update(cam_pose=poses[1], map_res=0.05)
+  finally:
+    lib.dm_debug_force_strips(0)
+  assert prep.status() == 0
+
+
+def test_frame_records_changed_behind_the_plan_are_reported(dmap):
+  """The silent path made loud: a prepared batch whose pose records in device memory no longer
+  fit its plan (here: overwritten with a translation of 1e9 m) projects nothing for the frames
+  concerned -- their maps hold the fill value -- and raises the sticky status word, which makes
+  the NEXT projection call of the process fail without any synchronisation."""
+  from dungeon_maps_amd import _native
+  lib = _lib()
+  depth, poses, cfg = _cfg2_like()
+  proj = dmap.MapProjector(**cfg)
+  d = depth.cuda()
+  lib.dm_debug_force_strips(4)
+  try:
+    prep = proj.prepare(depth.shape[0], cam_pose=poses[0])
+    good = prep.orth_project(d)
+    torch.cuda.synchronize()
+    _native.check_status()                       # nothing flagged so far
+    records = prep.buf[:depth.shape[0] * 48].view(torch.float32).view(-1, 12)
+    records[2, 4] = 1e9                          # frame 2: tx
+    bad = prep.orth_project(d)
+    assert prep.status() == _native.STATUS_FRAME_DID_NOT_FIT
+    assert bool(torch.isinf(bad[0][2]).all()) and not bool(bad[1][2].any())     # frame 2: all fill
+    for b in (0, 1, 3):
+      assert torch.equal(bad[0][b], good[0][b]) and torch.equal(bad[1][b], good[1][b])
+    with pytest.raises(_native.NativeError, match="did not fit"):
+      proj.orth_project(d, cam_pose=poses[0])
+    # the raise cleared the flag: the process carries on
+    top, mask = proj.orth_project(d, cam_pose=poses[0])
+    assert torch.equal(top, good[0]) and torch.equal(mask, good[1])
+    assert prep.status() == 0
+  finally:
+    lib.dm_debug_force_strips(0)
+
+
+def test_fifty_calls_in_flight_keep_their_own_poses(dmap, oracle):
+  """The reference-signature call (MapProjector.orth_project(depth, cam_pose=...),
+  maps.py:1406-1465) with a NEW set of poses on every call, 56 calls enqueued back to back
+  without a synchronisation: each call's poses travel in the arguments of its own kernels, so no
+  call can see another's.  Every result must equal the same call made alone (checked on the
+  generic path, which shares no code with the strips), and three of them the oracle."""
+  lib = _lib()
+  B, H, W, mh, mw = 6, 480, 640, 512, 512
+  g = torch.Generator().manual_seed(2024)
+  depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g)
+  cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
+             width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
+             trunc_depth_min=0.15, trunc_depth_max=5.05, clip_border=0, to_global=True,
+             fill_value=-np.inf)
+  proj = dmap.MapProjector(**cfg)
+  d = depth.cuda()
+  n = 56
+  poses = []
+  for _ in range(n):
+    pose = torch.empty(B, 3).uniform_(-1.5, 1.5, generator=g)
+    pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)
+    poses.append(pose)
+  lib.dm_debug_force_strips(4)
+  try:
+    torch.cuda.synchronize()
+    outs = [proj.orth_project_and_fuse(d, cam_pose=p) for p in poses]      # all in flight
+    assert lib.dm_debug_last_path() == 2
+    torch.cuda.synchronize()
+  finally:
+    lib.dm_debug_force_strips(0)
+  lib.dm_debug_force_generic_path(1)
+  try:
+    for i, p in enumerate(poses):
+      alone = proj.orth_project_and_fuse(d, cam_pose=p)
+      torch.cuda.synchronize()
+      for a_, b_ in zip(outs[i], alone):
+        assert torch.equal(a_, b_), f"call {i} differs from the same call made alone"
+  finally:
+    lib.dm_debug_force_generic_path(0)
+  for i in (0, 27, 55):
+    want = oracle.orth_project(depth.numpy(), nthreads=6,
+                               **dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=poses[i].numpy()))
+    np.testing.assert_array_equal(outs[i][1].cpu().numpy(), want[1])
+    np.testing.assert_array_equal(outs[i][0].cpu().numpy(), want[0])
+
+
+def _strip_info(lib):
+  info = (ctypes.c_int32 * 4)()
+  lib.dm_debug_last_strip_info(info)
+  return list(info)
+
+
+@pytest.mark.parametrize("groups", [1, 3])
+def test_cfg3_geometry_on_the_strip_path_index_and_value_passes(dmap, oracle, groups):
+  """BASELINE configs[2] at its geometry ON THE PATH bench.py MEASURES: 40-class one-hot values,
+  640x480 -> 512x512, four column strips -- the index pass (every pixel's cell once for all
+  channels) and the value pass (one workgroup per strip, channel and frame) -- against the oracle
+  on every frame and channel, height map included.  `groups` = 3 caps the slab space so that the
+  40 channels go through three channel groups (the route a batch takes whose slabs exceed the
+  workspace: the `ch0 > 0` launches of strip_pass)."""
+  lib = _lib()
+  B, H, W, mh, mw, C = 4, 480, 640, 512, 512, 40
+  g = torch.Generator().manual_seed(4040)
+  depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g)
+  labels = torch.randint(0, C, (B, H, W), generator=g)
+  value = torch.nn.functional.one_hot(labels, C).permute(0, 3, 1, 2).float().contiguous()
+  pose = torch.empty(B, 3).uniform_(-1, 1, generator=g)
+  pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)
+  cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
+             width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
+             trunc_depth_min=0.15, trunc_depth_max=5.05, clip_border=0, to_global=True,
+             fill_value=0.0)
+  proj = dmap.MapProjector(**cfg)
+  lib.dm_debug_force_strips(4)
+  if groups > 1:
+    # slabs of one channel: B frames x 4 strips x (20 K ... 40 K cells) x 4 bytes: room for at most 13 channels
+    lib.dm_debug_strip_slab_budget(14 * B * 4 * 20000 * 4 - 1)
+  try:
+    top, mask, height = proj.orth_project(depth.cuda(), value_map=value.cuda(), cam_pose=pose,
+                                          get_height_map=True)
+    assert lib.dm_debug_last_path() == 2
+    info = _strip_info(lib)
+  finally:
+    lib.dm_debug_force_strips(0)
+    lib.dm_debug_strip_slab_budget(0)
+  torch.cuda.synchronize()
+  # the value map's pass: one index-pass launch, then value-pass launches per channel group; the
+  # height map's pass behind it adds one scatter launch and one group
+  assert info[0] == 1, info
+  if groups == 1:
+    assert info[1] == 2 and info[3] == 2, info
+  else:
+    assert info[1] >= 1 + 3 and info[3] >= 1 + 3, info
+  want = oracle.orth_project(depth.numpy(), value_map=value.numpy(), get_height_map=True, nthreads=4,
+                             **dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose.numpy()))
+  np.testing.assert_array_equal(mask.cpu().numpy(), want[1])
+  np.testing.assert_array_equal(top.cpu().numpy(), want[0])
+  np.testing.assert_array_equal(height.cpu().numpy(), np.ascontiguousarray(want[2]))

@@ -307,10 +307,9 @@ k_strip_scatter(StripArgs a) {
   // frames travel in them) or from the caller's device buffer (prepared frames) -- one uniform
   // pointer into the constant address space either way
   typedef const __attribute__((address_space(4))) float cfloat;
-  cfloat* const pr = a.poses_dev
-      ? (cfloat*)(a.poses_dev + (size_t)b * kPoseFloats)
-      : (cfloat*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() +
-                  offsetof(StripArgs, poses)) + bl * kPoseFloats;
+  cfloat* const pr_args = (cfloat*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                    offsetof(StripArgs, poses)) + bl * kPoseFloats;
+  cfloat* const pr = a.poses_dev ? (cfloat*)(a.poses_dev + (size_t)b * kPoseFloats) : pr_args;
 #ifdef DM_STAMPS
   long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -329,10 +328,23 @@ k_strip_scatter(StripArgs a) {
     // The frame's geometry: wave 0 derives it (lane = strip x corner) into LDS, from the start of
     // the kernel, while the other fifteen waves initialise the window and the ray-slope table;
     // everybody reads it behind the barrier.
+    // (the record in the kernel arguments is requested with the arguments themselves -- its address
+    // depends on nothing that has to be loaded first; a prepared batch's record in device memory
+    // takes one more round trip)
     StripPose ps;
-    ps.y0 = pr[0]; ps.y2 = pr[1]; ps.y6 = pr[2]; ps.y8 = pr[3]; ps.tx = pr[4]; ps.tz = pr[5]; ps.wo = pr[6]; ps.ho = pr[7];
-    ps.cam_h = pr[8]; ps.pad0 = ps.pad1 = ps.pad2 = 0.0f;
+    ps.y0 = pr_args[0]; ps.y2 = pr_args[1]; ps.y6 = pr_args[2]; ps.y8 = pr_args[3]; ps.tx = pr_args[4];
+    ps.tz = pr_args[5]; ps.wo = pr_args[6]; ps.ho = pr_args[7]; ps.cam_h = pr_args[8];
+    if (a.poses_dev) {
+      ps.y0 = pr[0]; ps.y2 = pr[1]; ps.y6 = pr[2]; ps.y8 = pr[3]; ps.tx = pr[4]; ps.tz = pr[5]; ps.wo = pr[6]; ps.ho = pr[7];
+      ps.cam_h = pr[8];
+    }
+    ps.pad0 = ps.pad1 = ps.pad2 = 0.0f;
+#ifdef DM_STAMPS
+    asm volatile("" : "+s"(ps.y0), "+s"(ps.y2), "+s"(ps.cam_h));
+#endif
+    DM_STAMP(9);
     frame_geometry_wave64(a.rig, ps, lane, geom);
+    DM_STAMP(10);
   } else {
     // The whole window region of LDS gets the fill value, the ray-slope table its H entries
     // (maps.py:670-678; border rows poisoned), under the first depth rows in flight.
@@ -987,7 +999,7 @@ constexpr int kCombineThreads = 256;
 // blocks per frame: the kernel is one chain of round trips), four for value maps of many channels
 // (the chip holds 2 K blocks at a time: with one entry per thread 40 channels were twenty rounds
 // of that chain, 200 us; with four, 80 us).
-constexpr int kCombineSlots = 16;
+constexpr int kCombineSlots = 32;       // (the lists hold about as many dead entries as live ones: twice the blocks of round 2)
 
 // The groups of a frame's covers that no strip owns (the strips' shared-group lists): max / min
 // over the slabs of the strips whose covers hold the group, written to the map with its mask

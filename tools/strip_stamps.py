@@ -52,9 +52,11 @@ def seg(name, i, j):
   dd = (raw[:, j] - raw[:, i]) * 0.01
   print(f"  {name:44s} {np.median(dd):8.2f} {dd.max():8.2f}")
 print("workgroups: %d   per-WG phase time in us (median / max):" % len(st))
-seg("scalar loads, lds init, ray-slope table", 0, 1)
+seg("(thread 0 is in wave 0: start -> in front of the barrier)", 0, 1)
 if raw[:, 7].any() and raw[:, 8].any():
-  seg("geometry (wave 0) + barrier", 1, 7)
+  seg("wave 0: kernel arguments + pose record loaded", 0, 9)
+  seg("wave 0: geometry", 9, 10)
+  seg("wave 0: -> barrier passed", 10, 7)
   seg("row tables", 7, 8)
   seg("loop scalars reloaded + barrier", 8, 2)
 else:

@@ -94,6 +94,8 @@ _SIGNATURES = {
     "dm_debug_strip_value_list": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_strip_slab_budget": (ctypes.c_size_t, [ctypes.c_size_t]),
     "dm_debug_last_strip_info": (None, [ctypes.POINTER(ctypes.c_int32)]),
+    "dm_debug_force_fused_split": (None, [ctypes.c_int, ctypes.c_int]),
+    "dm_debug_last_fused_split": (None, [ctypes.POINTER(ctypes.c_int32)]),
     "dm_debug_strip_geometry": (ctypes.c_int, [
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dm_debug_strip_geometry_dev": (ctypes.c_int, [

@@ -246,7 +246,6 @@ int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames,
                               const uint8_t* valid_dev, float* out_dev, uint8_t* mask_dev,
                               int accumulate, void* workspace_dev, size_t workspace_bytes,
                               int32_t* status_dev, void* stream) {
-  (void)status_dev;
   int rc = check_params(p);
   if (rc != DM_OK) return rc;
   if (p->reduction != DM_REDUCE_MAX && p->reduction != DM_REDUCE_MIN)
@@ -266,6 +265,9 @@ int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames,
     return fail(DM_ERR_INVALID_ARGUMENT, "cannot fuse an empty batch without accumulate");
   hipError_t e = hipErrorNotSupported;
   if (p->B > 0 && dm::window_path_supported(*p) && !g_force_generic)
+    e = dm::run_strip_fused(*p, frames, depth_dev, valid_dev, out_dev, mask_dev, accumulate, workspace_dev,
+                            workspace_bytes, status_dev, static_cast<hipStream_t>(stream));
+  if (e == hipErrorNotSupported && p->B > 0 && dm::window_path_supported(*p) && !g_force_generic)
     e = dm::run_window_fused(*p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
                              accumulate, workspace_dev, workspace_bytes,
                              static_cast<hipStream_t>(stream));

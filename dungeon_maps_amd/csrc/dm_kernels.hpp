@@ -45,6 +45,11 @@ hipError_t run_strip(const dm_params& p, const dm_frame* frames_host, const floa
                      float* height, float* fused, uint8_t* fused_mask, void* ws, size_t ws_bytes,
                      int* status, hipEvent_t before_projection, hipEvent_t after_projection, hipStream_t s);
 
+// dm_orth_project_fused_f32 on column strips (heights; groups of frames per workgroup)
+hipError_t run_strip_fused(const dm_params& p, const dm_frame* frames_host, const float* depth,
+                           const uint8_t* valid, float* out, uint8_t* mask, int accumulate, void* ws,
+                           size_t ws_bytes, int* status, hipStream_t s);
+
 size_t strip_prepared_bytes(const dm_params& p);
 // hipErrorInvalidConfiguration: the plan differs from `must_match` (nothing enqueued)
 hipError_t strip_prepare(const dm_params& p, const dm_frame* frames_host, void* prepared_dev,

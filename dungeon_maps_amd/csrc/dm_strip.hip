@@ -16,6 +16,7 @@
 
 #include "dm_kernels.hpp"
 #include "dm_strip_kernels.hpp"
+#include "dm_strip_fused_kernels.hpp"
 
 #ifndef DM_X_COMBINE_ENTRIES
 #define DM_X_COMBINE_ENTRIES 4      // list entries per thread of the combine kernel for value maps of many channels
@@ -681,7 +682,308 @@ hipError_t run_strip_prepared(const dm_params& p, const dm_frames_plan& fp, cons
                        status, after_projection, s);
 }
 
+// ---------------------------------------------------------------------------------------------
+// dm_orth_project_fused_f32 on column strips (k_strip_fused + k_fuse_windows).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// Launch bound for strips of `wp` pixels (any number of them), every yaw and position of the
+// camera: the largest window a strip can have, the largest width + height of one, the slack.
+struct FusedBound {
+  dm_params key;
+  float pitch[4];
+  int wp, mag_q;
+  bool valid, ok;
+  int P, slab_cells, wh_sum, slack;
+  float inv, reach, g0, g1;
+  float res_inv, fx_inv, fy_inv;
+  bool lean;
+  float fcx[8], fcz[8];         // corners of the WHOLE image's truncated frustum in the camera's local frame, cells
+};
+
+void compute_fused_bound(const dm_params& p, int wp, const float* pitch4, int mag_q, FusedBound& fb) {
+  fb.key = p; memcpy(fb.pitch, pitch4, sizeof(fb.pitch)); fb.wp = wp; fb.mag_q = mag_q;
+  fb.valid = true; fb.ok = false;
+  if (p.reduction != DM_REDUCE_MAX && p.reduction != DM_REDUCE_MIN) return;
+  if (p.mw % 4 != 0 || p.W % 4 != 0 || wp % 4 != 0 || wp < 4) return;
+  if (p.mw > 32767 || p.mh > 32767 || (int64_t)p.mh * p.mw >= (1ll << 28)) return;
+  if (!(p.fill == p.fill)) return;
+  if (!p.has_dmin || !p.has_dmax || !(p.dmin >= 0.0f) || !(p.dmax >= p.dmin) || !isfinite(p.dmax)) return;
+  if (!exact_reciprocal(p.res, &fb.res_inv) || !exact_reciprocal(p.fx, &fb.fx_inv) ||
+      !exact_reciprocal(p.fy, &fb.fy_inv) || p.res < 1e-6f || p.res > 1e6f || p.fx < 1e-6f ||
+      p.fx > 1e6f || p.fy < 1e-6f || p.fy > 1e6f)
+    return;
+  const int clip = p.clip_border > 0 ? p.clip_border : 0;
+  const int r0 = clip, r1 = p.H - clip;
+  if (r0 >= r1) return;
+  double ay[2];
+  const int rs[2] = {r0, r1 - 1};
+  for (int i = 0; i < 2; ++i) {
+    double yr = rs[i];
+    if (p.flip_h) yr = (double)(p.H - 1) - yr;
+    ay[i] = (yr - (double)p.cy) / (double)p.fy;
+  }
+  const float ay_lo = (float)(ay[0] < ay[1] ? ay[0] : ay[1]), ay_hi = (float)(ay[0] < ay[1] ? ay[1] : ay[0]);
+  const float p5 = pitch4[1], p8 = pitch4[3];
+  fb.g0 = p5 * ay_lo + p8; fb.g1 = p5 * ay_hi + p8;        // strip::cfg_rig
+  if (!(fb.g0 > 1e-3f && fb.g1 > 1e-3f && strip::finite_f(fb.g0) && strip::finite_f(fb.g1))) return;
+  fb.inv = (float)(1.0 / (double)p.res);
+  fb.P = (p.W + wp - 1) / wp;
+  fb.lean = !p.valid_c && isfinite(p.dmin) && !p.has_hmax && p.clip_border <= 0;
+  const float gmax = strip::fmax2(strip::fabs_(fb.g0), strip::fabs_(fb.g1));
+  float amax = 0.0f;
+  std::vector<float> cx((size_t)fb.P * 8), cz((size_t)fb.P * 8);
+  std::vector<char> live(fb.P);
+  double rmax = 0.0;
+  for (int s = 0; s < fb.P; ++s) {
+    int q0 = s * wp, q1 = q0 + wp < p.W ? q0 + wp : p.W;
+    if (q0 < clip) q0 = clip;
+    if (q1 > p.W - clip) q1 = p.W - clip;
+    live[s] = q0 < q1;
+    for (int k = 0; k < 8; ++k) cx[s * 8 + k] = cz[s * 8 + k] = 0.0f;
+    if (!live[s]) continue;
+    const float ax_lo = (float)(((double)q0 - (double)p.cx) / (double)p.fx);
+    const float ax_hi = (float)(((double)(q1 - 1) - (double)p.cx) / (double)p.fx);
+    amax = strip::fmax2(amax, strip::fmax2(strip::fabs_(ax_lo), strip::fabs_(ax_hi)));
+    strip::strip_corners(ax_lo, ax_hi, fb.g0, fb.g1, p.dmin, p.dmax, fb.inv, &cx[s * 8], &cz[s * 8]);
+    for (int k = 0; k < 8; ++k) {
+      const double r = sqrt((double)cx[s * 8 + k] * cx[s * 8 + k] + (double)cz[s * 8 + k] * cz[s * 8 + k]);
+      if (r > rmax) rmax = r;
+    }
+  }
+  fb.reach = p.dmax * fb.inv * (amax + gmax);
+  {
+    const int q0 = clip, q1 = p.W - clip;       // (r0 < r1 holds; a clip that eats every column leaves no live strip)
+    const float ax_lo = (float)(((double)q0 - (double)p.cx) / (double)p.fx);
+    const float ax_hi = (float)(((double)(q1 > q0 ? q1 - 1 : q0) - (double)p.cx) / (double)p.fx);
+    strip::strip_corners(ax_lo, ax_hi, fb.g0, fb.g1, p.dmin, p.dmax, fb.inv, fb.fcx, fb.fcz);
+  }
+  const double slack_d = 2.0 + 16.0 * ((double)mag_q + 2.0 * (double)fb.reach) * (1.0 / 8388608.0) + 0.01;
+  fb.slack = slack_d > 16.0 ? -1 : (int)ceil(slack_d);
+  if (fb.slack < 0 || !isfinite(rmax)) return;
+  const int steps = 1440;
+  const double dtheta = 2.0 * M_PI / steps;
+  const double lip = rmax * dtheta;
+  const double pad_w = lip + 2.0 * fb.slack + 10.0, pad_h = lip + 2.0 * fb.slack + 4.0;
+  double area = 0.0, wh = 0.0;
+  for (int i = 0; i < steps; ++i) {
+    const double cs = cos(i * dtheta), sn = sin(i * dtheta);
+    for (int s = 0; s < fb.P; ++s) {
+      if (!live[s]) continue;
+      double lx = INFINITY, hx = -INFINITY, lz = INFINITY, hz = -INFINITY;
+      for (int k = 0; k < 8; ++k) {
+        const double x = cs * cx[s * 8 + k] + sn * cz[s * 8 + k], z = -sn * cx[s * 8 + k] + cs * cz[s * 8 + k];
+        lx = x < lx ? x : lx; hx = x > hx ? x : hx; lz = z < lz ? z : lz; hz = z > hz ? z : hz;
+      }
+      double w = hx - lx + pad_w, h = hz - lz + pad_h;
+      if (w > p.mw) w = p.mw;
+      if (h > p.mh) h = p.mh;
+      if (w * h > area) area = w * h;
+      if (w + h > wh) wh = w + h;
+    }
+  }
+  fb.slab_cells = ((int)ceil(area) + 3) & ~3;
+  fb.wh_sum = (int)ceil(wh);
+  fb.ok = true;
+}
+
+const FusedBound* fused_bound_of(const dm_params& p, int wp, const float* pitch4, int magnitude) {
+  thread_local FusedBound slots[6] = {};
+  thread_local int next = 0;
+  const int mag_q = quantised_magnitude(magnitude);
+  for (FusedBound& f : slots)
+    if (f.valid && f.wp == wp && f.mag_q == mag_q && memcmp(&f.key, &p, sizeof(dm_params)) == 0 &&
+        memcmp(f.pitch, pitch4, sizeof(f.pitch)) == 0)
+      return &f;
+  FusedBound& f = slots[next];
+  next = (next + 1) % 6;
+  f = FusedBound{};
+  compute_fused_bound(p, wp, pitch4, mag_q, f);
+  return &f;
+}
+
+using FusedKernel = void (*)(FusedArgs);
+FusedKernel pick_fused_kernel(bool is_max, bool has_valid, bool lean, bool defer) {
+#define DM_F(M) {k_strip_fused<M, false, false, false>, k_strip_fused<M, true, false, false>,   \
+                 k_strip_fused<M, false, true, false>, k_strip_fused<M, false, true, true>}
+  static const FusedKernel table[2][4] = {DM_F(kMin), DM_F(kMax)};
+#undef DM_F
+  // [min | max][plain, valid map, lean, lean + deferred camera height]   (lean implies no valid map)
+  return table[is_max ? 1 : 0][has_valid ? 1 : (lean ? (defer ? 3 : 2) : 0)];
+}
+
+thread_local int g_fused_force[2] = {0, 0};        // dm_debug_force_fused_split: {strip width, frames per group}
+thread_local int g_last_fused[4] = {0, 0, 0, 0};   // dm_debug_last_fused_split: {strip width, strips, frames per group, groups}
+
+}  // namespace
+
+// hipErrorNotSupported: does not apply (nothing enqueued) -- the caller goes on to the window path.
+hipError_t run_strip_fused(const dm_params& p, const dm_frame* frames_host, const float* depth,
+                           const uint8_t* valid, float* out, uint8_t* mask, int accumulate, void* ws,
+                           size_t ws_bytes, int* status, hipStream_t s) {
+  g_last_fused[0] = g_last_fused[1] = g_last_fused[2] = g_last_fused[3] = 0;
+  if (g_force_legacy || p.vc != 0 || p.B < 1 || p.B > 65535) return hipErrorNotSupported;
+  if (reinterpret_cast<uintptr_t>(depth) % 16 != 0 || reinterpret_cast<uintptr_t>(valid) % 4 != 0 ||
+      reinterpret_cast<uintptr_t>(out) % 16 != 0 || reinterpret_cast<uintptr_t>(mask) % 4 != 0 ||
+      reinterpret_cast<uintptr_t>(ws) % 256 != 0)
+    return hipErrorNotSupported;
+  if ((int64_t)p.H * p.W >= (1ll << 28) || (int64_t)kFusedMaxGroup * p.dc * p.H >= (1 << 23) || p.W >= (1 << 23) ||
+      (int64_t)kFusedMaxGroup * p.dc * p.H * p.W * 4 >= (1ll << 31))
+    return hipErrorNotSupported;
+  const int magnitude = validate_frames(p, frames_host, p.B);
+  if (magnitude < 0) return hipErrorNotSupported;
+  const float pitch4[4] = {frames_host[0].Rp[4], frames_host[0].Rp[5], frames_host[0].Rp[7], frames_host[0].Rp[8]};
+  const bool global = p.to_global != 0;
+  const double inv = 1.0 / (double)p.res;
+  // the frames' camera cells and yaw directions (for the groups' pose spread and the fuse kernel's bounding box)
+  thread_local std::vector<double> cam;
+  cam.resize((size_t)p.B * 4);
+  for (int b = 0; b < p.B; ++b) {
+    const dm_frame& f = frames_host[b];
+    const double xd = (global ? (double)f.tx * inv : 0.0) + (double)f.width_offset;
+    double zd = (global ? (double)f.tz * inv : 0.0) + (double)f.height_offset;
+    if (p.flip_h) zd = (double)(p.mh - 1) - zd;
+    cam[b * 4 + 0] = xd; cam[b * 4 + 1] = zd;
+    cam[b * 4 + 2] = global ? f.Ry[0] : 1.0; cam[b * 4 + 3] = global ? f.Ry[2] : 0.0;
+  }
+  // Candidates: groups of F = 8, 4, 2, 1 frames and the strip width that makes about one workgroup
+  // per CU of it; a candidate is feasible when the windows of its groups (one frame's bound widened
+  // by how far the group's poses are apart) fit in LDS and its slabs in the workspace.  Cost: the
+  // scatter's waves of workgroups + the fuse kernel's slab traffic.
+  struct Cand { int wp, F; const FusedBound* fb; int slab; double cost; };
+  Cand best = {0, 0, nullptr, 0, 1e30};
+  const int kWave = 256;
+  for (int F = kFusedMaxGroup; F >= 1; F >>= 1) {
+    if (g_fused_force[1] && F != g_fused_force[1]) continue;
+    if (F > p.B && F > 1) continue;
+    const int G = (p.B + F - 1) / F;
+    int strips = kWave / (G * p.dc) > 0 ? kWave / (G * p.dc) : 1;
+    int wp = ((p.W + strips - 1) / strips + 3) & ~3;
+    if (wp < 16) wp = 16;
+    if (wp > 256) wp = 256;
+    if (g_fused_force[0]) wp = g_fused_force[0];
+    const FusedBound* fb = fused_bound_of(p, wp, pitch4, magnitude);
+    if (!fb->ok) continue;
+    // how far a point can move between the first frame of a group and any other: camera cell + rotation chord
+    double spread = 0.0;
+    for (int g = 0; g < G && F > 1; ++g) {
+      const int b0 = g * F, b1 = b0 + F < p.B ? b0 + F : p.B;
+      for (int b = b0 + 1; b < b1; ++b) {
+        const double m = fabs(cam[b * 4] - cam[b0 * 4]) + fabs(cam[b * 4 + 1] - cam[b0 * 4 + 1]) +
+                         (double)fb->reach * hypot(cam[b * 4 + 2] - cam[b0 * 4 + 2], cam[b * 4 + 3] - cam[b0 * 4 + 3]);
+        if (m > spread) spread = m;
+      }
+    }
+    if (!(spread < 4096.0)) continue;
+    const int m = F > 1 ? (int)ceil(spread) + 2 : 0;
+    int64_t cells = (int64_t)fb->slab_cells + 2ll * m * fb->wh_sum + 4ll * m * m;
+    if (cells > (int64_t)p.mh * p.mw) cells = (int64_t)p.mh * p.mw;
+    const int slab = (int)((cells + 3) & ~3ll);
+    if (fused_lds_bytes(slab, p.H) > (size_t)kMaxLdsBytes) continue;
+    const size_t need = up256((size_t)G * fb->P * sizeof(Win16)) + (size_t)G * p.dc * fb->P * slab * 4;
+    if (need > ws_bytes) continue;
+    const int wgs = fb->P * p.dc * G;
+    const double waves = (double)((wgs + kWave - 1) / kWave);
+    const double pixels = (double)wp * p.H * F;
+    const double cost = waves * (5.0 + pixels * 2.4e-4) + 2.0 + (double)wgs * slab * 4.0 / 3.0e6;
+    if (cost < best.cost) best = Cand{wp, F, fb, slab, cost};
+  }
+  if (!best.fb) return hipErrorNotSupported;
+  const FusedBound& fb = *best.fb;
+  const int F = best.F, G = (p.B + F - 1) / F;
+  // the fuse kernel's bounding box: every window lies within the bounding box of its frame's
+  // truncated frustum (the eight corners of the whole image's, rotated by the frame's yaw as
+  // strip::strip_geometry rotates a strip's) + slack
+  int gx0, gx1, gz0, gz1;
+  {
+    double lx = INFINITY, hx = -INFINITY, lz = INFINITY, hz = -INFINITY;
+    const double fs = p.flip_h ? -1.0 : 1.0;
+    for (int b = 0; b < p.B; ++b) {
+      const dm_frame& f = frames_host[b];
+      const double y0 = global ? f.Ry[0] : 1.0, y2 = fs * (global ? f.Ry[2] : 0.0);
+      const double y6 = global ? f.Ry[6] : 0.0, y8 = fs * (global ? f.Ry[8] : 1.0);
+      for (int k = 0; k < 8; ++k) {
+        const double x = y0 * fb.fcx[k] + y6 * fb.fcz[k] + cam[b * 4], z = y2 * fb.fcx[k] + y8 * fb.fcz[k] + cam[b * 4 + 1];
+        lx = x < lx ? x : lx; hx = x > hx ? x : hx; lz = z < lz ? z : lz; hz = z > hz ? z : hz;
+      }
+    }
+    const double R = (double)fb.slack + 3.0;
+    lx = floor(lx - R); hx = ceil(hx + R) + 1.0; lz = floor(lz - R); hz = ceil(hz + R) + 1.0;
+    gx0 = lx < 0.0 ? 0 : (lx > p.mw ? p.mw : (int)lx); gx1 = hx > p.mw ? p.mw : (hx < 0.0 ? 0 : (int)hx);
+    gz0 = lz < 0.0 ? 0 : (lz > p.mh ? p.mh : (int)lz); gz1 = hz > p.mh ? p.mh : (hz < 0.0 ? 0 : (int)hz);
+    gx0 &= ~3; gx1 = (gx1 + 3) & ~3;
+    if (gx1 > p.mw) gx1 = p.mw;
+    if (gx1 <= gx0 || gz1 <= gz0) { gx0 = gx1 = gz0 = gz1 = 0; }
+  }
+  const bool is_max = p.reduction == DM_REDUCE_MAX;
+  // (the camera height deferred to the flush: only without a height truncation, which compares y1)
+  bool defer = fb.lean;
+  for (int b = 1; b < p.B; ++b) defer = defer && frames_host[b].cam_height == frames_host[0].cam_height;
+  const FusedKernel kfn = pick_fused_kernel(is_max, valid != nullptr, fb.lean, defer);
+  hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn));
+  if (e != hipSuccess) return e;
+  Win16* wins = static_cast<Win16*>(ws);
+  float* slabs = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + up256((size_t)G * fb.P * sizeof(Win16)));
+  thread_local FusedArgs fa;
+  memset(&fa, 0, offsetof(FusedArgs, poses));
+  fa.W = p.W; fa.H = p.H; fa.clip = p.clip_border > 0 ? p.clip_border : 0; fa.flip_h = p.flip_h != 0;
+  fa.cx = p.cx; fa.cy = p.cy; fa.fx = p.fx; fa.fy = p.fy; fa.res = p.res;
+  fa.fx_inv = fb.fx_inv; fa.fy_inv = fb.fy_inv; fa.res_inv = fb.res_inv;
+  fa.dmin = p.dmin; fa.dmax = p.dmax; fa.hmax = p.has_hmax ? p.hmax : INFINITY;
+  fa.Hm1 = (float)(p.H - 1); fa.mhm1 = (float)(p.mh - 1);
+  fa.p4 = pitch4[0]; fa.p5 = pitch4[1]; fa.p7 = pitch4[2]; fa.p8 = pitch4[3];
+  fa.wp = best.wp; fa.P = fb.P; fa.F = F;
+  fa.dc = p.dc; fa.valid_c = p.valid_c; fa.slab_stride = best.slab; fa.mh = p.mh; fa.mw = p.mw;
+  fa.fill = p.fill; fa.cam_h = frames_host[0].cam_height;
+  fa.inv = fb.inv; fa.reach = fb.reach; fa.g0 = fb.g0; fa.g1 = fb.g1; fa.cone_ok = 1;
+  fa.slabs = slabs; fa.wins = wins; fa.status = status;
+  const size_t lds_bytes = fused_lds_bytes(best.slab, p.H);
+  const size_t N = (size_t)p.H * p.W;
+  const int per_launch = kPoseFrames / F * F;           // whole groups per launch
+  for (int b0 = 0; b0 < p.B; b0 += per_launch) {
+    const int nb = p.B - b0 < per_launch ? p.B - b0 : per_launch;
+    fa.nb = nb; fa.group0 = b0 / F;
+    fa.depth = depth + (size_t)b0 * p.dc * N;
+    fa.valid = valid ? valid + (size_t)b0 * p.valid_c * N : nullptr;
+    for (int i = 0; i < nb; ++i) {
+      const dm_frame& f = frames_host[b0 + i];
+      StripPose& q = fa.poses[i];
+      q.y0 = global ? f.Ry[0] : 1.0f; q.y2 = global ? f.Ry[2] : 0.0f; q.y6 = global ? f.Ry[6] : 0.0f; q.y8 = global ? f.Ry[8] : 1.0f;
+      q.tx = global ? f.tx : 0.0f; q.tz = global ? f.tz : 0.0f;
+      q.wo = f.width_offset; q.ho = f.height_offset; q.cam_h = f.cam_height;
+      q.pad0 = q.pad1 = q.pad2 = 0.0f;
+    }
+    e = launch(kfn, dim3(fb.P, p.dc, (nb + F - 1) / F), dim3(kScatterThreads), lds_bytes, s, fa);
+    if (e != hipSuccess) return e;
+  }
+  FuseWinArgs fw;
+  fw.nwin = G * fb.P; fw.b0 = 0; fw.nparts = fb.P; fw.oc = p.dc; fw.ch0 = 0; fw.oc_total = p.dc;
+  fw.mh = p.mh; fw.mw = p.mw; fw.slab_stride = best.slab; fw.accumulate = accumulate; fw.fill = p.fill;
+  fw.gx0 = gx0; fw.gz0 = gz0; fw.gx1 = gx1; fw.gz1 = gz1;
+  fw.wins = wins; fw.slabs = slabs; fw.fused = out; fw.fused_mask = mask;
+  const int bw4 = (gx1 - gx0) / 4;
+  const int heavy = gx1 > gx0 ? ((bw4 + kFuseGroups - 1) / kFuseGroups) * (gz1 - gz0) : 0;
+  const int per_fill_block = kFuseGroups * kFuseLanes * 8;
+  const int fill_blocks = (int)(((size_t)p.mh * p.mw / 4 + per_fill_block - 1) / per_fill_block);
+  const dim3 g((unsigned)(heavy + fill_blocks), p.dc);
+  const dim3 blk(kFuseGroups * kFuseLanes);
+  e = is_max ? launch(k_fuse_windows<true>, g, blk, 0, s, fw) : launch(k_fuse_windows<false>, g, blk, 0, s, fw);
+  if (e != hipSuccess) return e;
+  g_last_fused[0] = best.wp; g_last_fused[1] = fb.P; g_last_fused[2] = F; g_last_fused[3] = G;
+  note_split(fb.P, 1, 1, 2);
+  return hipSuccess;
+}
+
 }  // namespace dm
+
+extern "C" __attribute__((visibility("default"))) void dm_debug_force_fused_split(int strip_width, int frames_per_group) {
+  dm::g_fused_force[0] = strip_width > 0 ? (strip_width + 3) & ~3 : 0;
+  dm::g_fused_force[1] = frames_per_group > 0 ? frames_per_group : 0;
+}
+
+extern "C" __attribute__((visibility("default"))) void dm_debug_last_fused_split(int32_t* out4) {
+  for (int i = 0; i < 4; ++i) out4[i] = dm::g_last_fused[i];
+}
 
 extern "C" __attribute__((visibility("default"))) int dm_debug_force_strips(int strips) {
   const int old = dm::g_force_strips;

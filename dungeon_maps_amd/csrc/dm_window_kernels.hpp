@@ -809,26 +809,42 @@ k_fuse_windows(FuseWinArgs a) {
   const size_t cell = (size_t)ch * M + (size_t)z * a.mw + x;
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
   if (a.accumulate && lane == 0 && live) acc = *reinterpret_cast<const float4*>(a.fused + cell);
+  const int wlane = (int)threadIdx.x & 63;
   for (int c0 = 0; c0 < a.nwin; c0 += kFuseChunk) {
-    // round 1: which windows of this chunk touch the block's cells at all?
+    // round 1: which windows of this chunk touch the block's cells at all?  One window per thread
+    // and trip; a wave compacts its hits with a ballot and takes its share of the list with ONE
+    // LDS atomic (one atomic per hit serialised the block on a single counter: on a trajectory a
+    // tile has 100-200 candidates).
     if (threadIdx.x == 0) ncand = 0;
     __syncthreads();
-    for (int r = c0 + threadIdx.x; r < a.nwin && r < c0 + kFuseChunk; r += blockDim.x) {
-      const Window w = widen(a.wins[(size_t)a.b0 * a.nparts + r]);
-      if (w.w > 0 && w.z0 <= z_hi && w.z0 + w.h > z_lo && w.x0 < x_hi && w.x0 + w.w > x_lo) {
-        const int slot = atomicAdd(&ncand, 1);
-        const int b = r / a.nparts, p = r - b * a.nparts;
-        cwin[slot] = make_int4(w.x0, w.z0, w.w, w.h);
-        cslab[slot] = ((a.b0 + b) * a.oc + chl) * a.nparts + p;
+    for (int r0 = c0; r0 < a.nwin && r0 < c0 + kFuseChunk; r0 += (int)blockDim.x) {     // (uniform trips)
+      const int r = r0 + (int)threadIdx.x;
+      bool hit = false;
+      Window w = {0, 0, 0, 0};
+      if (r < a.nwin && r < c0 + kFuseChunk) {
+        w = widen(a.wins[(size_t)a.b0 * a.nparts + r]);
+        hit = w.w > 0 && w.z0 <= z_hi && w.z0 + w.h > z_lo && w.x0 < x_hi && w.x0 + w.w > x_lo;
+      }
+      const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit);
+      if (hits != 0ull) {
+        int base = 0;
+        if (wlane == 0) base = atomicAdd(&ncand, __builtin_popcountll(hits));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (hit) {
+          const int slot = base + __builtin_popcountll(hits & ((1ull << wlane) - 1ull));
+          const int b = r / a.nparts, p = r - b * a.nparts;
+          cwin[slot] = make_int4(w.x0, w.z0, w.w, w.h);
+          cslab[slot] = ((a.b0 + b) * a.oc + chl) * a.nparts + p;
+        }
       }
     }
     __syncthreads();
-    // round 2: the 8 lanes of a group split the candidates, four slab loads in flight
+    // round 2: the 8 lanes of a group split the candidates, eight slab loads in flight
     const int n = ncand;
-    for (int i0 = lane; i0 < n; i0 += 4 * kFuseLanes) {
-      float4 v[4];
+    for (int i0 = lane; i0 < n; i0 += 8 * kFuseLanes) {
+      float4 v[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < 8; ++k) {
         const int i = i0 + k * kFuseLanes;
         v[k] = acc;
         if (i < n) {
@@ -840,7 +856,7 @@ k_fuse_windows(FuseWinArgs a) {
         }
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < 8; ++k) {
         acc.x = IS_MAX ? fmaxf(acc.x, v[k].x) : fminf(acc.x, v[k].x);
         acc.y = IS_MAX ? fmaxf(acc.y, v[k].y) : fminf(acc.y, v[k].y);
         acc.z = IS_MAX ? fmaxf(acc.z, v[k].z) : fminf(acc.z, v[k].z);

@@ -382,6 +382,12 @@ int dm_debug_force_bands(int on);
  *                                launches (value maps of many channels: the pixels' cells once for
  *                                all channels), scatter / value-pass launches, combine launches,
  *                                channel groups}.
+ *   dm_debug_force_fused_split   dm_orth_project_fused_f32 on the strip path: strips of this many
+ *                                pixels and groups of this many frames per workgroup (1, 2, 4, 8)
+ *                                whatever the cost model says (0 = back to the model).
+ *   dm_debug_last_fused_split    what the calling thread's last dm_orth_project_fused_f32 took:
+ *                                out4 = {strip width, strips, frames per group, groups}; zeros when
+ *                                it did not run on the strip path.
  *   dm_debug_strip_geometry      host only (no GPU needed): the strip path's geometry for `p` and
  *                                the given frames exactly as the kernels derive it.
  *                                out_geom (B, 8 + 4*8) int32 per frame: {ok | inside << 8 (bit s of
@@ -405,6 +411,8 @@ int dm_debug_force_strips(int strips);
 int dm_debug_strip_value_list(int on);
 size_t dm_debug_strip_slab_budget(size_t bytes);
 void dm_debug_last_strip_info(int32_t* out4);
+void dm_debug_force_fused_split(int strip_width, int frames_per_group);
+void dm_debug_last_fused_split(int32_t* out4);
 int dm_debug_strip_geometry(const dm_params* p, const dm_frame* frames, int32_t* out_geom,
                             uint32_t* out_covers, int32_t* out_bound);
 int dm_debug_strip_geometry_dev(const dm_params* p, const dm_frame* frames_host,

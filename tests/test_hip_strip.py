@@ -526,3 +526,102 @@ def test_cfg3_geometry_on_the_strip_path_index_and_value_passes(dmap, oracle, gr
   np.testing.assert_array_equal(mask.cpu().numpy(), want[1])
   np.testing.assert_array_equal(top.cpu().numpy(), want[0])
   np.testing.assert_array_equal(height.cpu().numpy(), np.ascontiguousarray(want[2]))
+
+
+def _fused_split(lib):
+  out = (ctypes.c_int32 * 4)()
+  lib.dm_debug_last_fused_split(out)
+  return list(out)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fused_projection_on_strips_equals_oracle(dmap, oracle, seed):
+  """dm_orth_project_fused_f32 on the strip path (k_strip_fused: one workgroup per strip and GROUP
+  of frames, then k_fuse_windows): the fused map of a batch must equal the oracle's, for groups
+  of 1, 2, 4 and 8 frames and several strip widths (forced), trajectories and unrelated poses,
+  valid maps, a height truncation, min, per-frame camera heights, several depth channels, and on
+  top of a running map (`accumulate`)."""
+  lib = _lib()
+  rng = np.random.default_rng(9100 + seed)
+  ran = grouped = 0
+  for it in range(10):
+    B = int(rng.choice([1, 3, 8, 13, 16]))
+    H, W = [(48, 64), (60, 80), (96, 128), (120, 160)][int(rng.integers(4))]
+    mh, mw = [(128, 128), (256, 256), (200, 300)][int(rng.integers(3))]
+    dc = 2 if it % 5 == 4 else 1
+    depth = rng.uniform(0.05, 7.0, size=(B, dc, H, W)).astype(np.float32)
+    k = np.arange(B, dtype=np.float32)
+    if it % 3 == 0:      # unrelated poses
+      pose = np.stack([rng.uniform(-1, 1, B), rng.uniform(-1, 1, B), rng.uniform(-np.pi, np.pi, B)], 1).astype(np.float32)
+    else:                # a trajectory
+      pose = np.stack([0.3 + 0.02 * k, -0.2 + 0.015 * k, 0.4 + 0.02 * k * (1 if it % 2 else -1)], 1).astype(np.float32)
+    is_min = it % 4 == 3
+    cfg = dict(width=W, height=H, hfov=float(rng.uniform(0.9, 1.6)), vfov=None,
+               cam_pitch=float(rng.uniform(-0.6, 0.1)),
+               cam_height=(rng.uniform(0.5, 1.5, B).astype(np.float32) if it % 4 == 1 else 0.88),
+               width_offset=mw / 2., height_offset=mh / 2., map_res=float(rng.choice([0.03, 0.05])),
+               map_width=mw, map_height=mh, trunc_depth_min=0.15, trunc_depth_max=float(rng.choice([2.5, 5.05])),
+               trunc_height_max=None if it % 3 else 0.9, clip_border=int(rng.choice([0, 0, 3])),
+               to_global=True, flip_h=bool(it % 5), fill_value=np.inf if is_min else -np.inf,
+               reduction="min" if is_min else "max")
+    valid = (rng.uniform(size=(B, 1, H, W)) > 0.15) if it % 4 == 2 and dc == 1 else None
+    kw = dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose)
+    want, wmask = oracle.orth_project(depth, valid_map=valid, fused=True, **kw)
+    proj = _projector(dmap, cfg)
+    d = torch.from_numpy(depth).cuda()
+    m = None if valid is None else torch.from_numpy(valid).cuda()
+    # (unrelated poses: groups of one -- their windows have nothing in common)
+    F = 1 if it % 3 == 0 else int(rng.choice([f for f in (1, 2, 4, 8) if f <= B]))
+    wp = int(rng.choice([16, 20, 32, 40, 64]))
+    lib.dm_debug_force_fused_split(wp, F)
+    try:
+      fused, fmask = proj.orth_project_fused(d, valid_map=m, cam_pose=pose)
+      split = _fused_split(lib)
+    finally:
+      lib.dm_debug_force_fused_split(0, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(fmask.cpu().numpy(), wmask, err_msg=str((cfg, F, wp, split)))
+    np.testing.assert_array_equal(fused.cpu().numpy(), want, err_msg=str((cfg, F, wp, split)))
+    if split[2]:
+      ran += 1
+      grouped += split[2] > 1
+      assert split[0] == (wp + 3) // 4 * 4 and split[2] == F
+      # on top of a running map: every cell that is better there stays
+      base = torch.from_numpy(rng.uniform(-0.5, 1.5, size=want.shape).astype(np.float32)).cuda()
+      run, rmask = proj.orth_project_fused(d, valid_map=m, cam_pose=pose, out=base.clone())
+      both = torch.minimum(base, fused) if is_min else torch.maximum(base, fused)
+      assert torch.equal(run, both)
+  assert ran >= 8 and grouped >= 2, (ran, grouped)
+
+
+def test_cfg4_runs_on_the_strip_path(dmap, oracle):
+  """BASELINE configs[3] per rank (64 frames of one trajectory -> one 1024x1024 map): the call
+  must take the strip path (one wave of workgroups), and the map must equal the oracle's with
+  the cost model's split and with groups of four frames per workgroup forced
+  (tests/test_hip_full_configs.py checks the same call end to end)."""
+  lib = _lib()
+  B, H, W, mh, mw = 64, 480, 640, 1024, 1024
+  g = torch.Generator().manual_seed(77)
+  depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g)
+  k = torch.arange(B, dtype=torch.float32)
+  pose = torch.stack((0.02 * k, 0.01 * k, 0.01 * k), dim=1)
+  cfg = dict(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
+             width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
+             trunc_depth_min=0.15, trunc_depth_max=5.05, clip_border=0, to_global=True, fill_value=-np.inf)
+  proj = dmap.MapProjector(**cfg)
+  d = depth.cuda()
+  fused, fmask = proj.orth_project_fused(d, cam_pose=pose)
+  split = _fused_split(lib)
+  torch.cuda.synchronize()
+  assert split[1] > 0 and split[1] * split[3] <= 256, split
+  want, wmask = oracle.orth_project(depth.numpy(), fused=True, nthreads=8,
+                                    **dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose.numpy()))
+  np.testing.assert_array_equal(fmask.cpu().numpy(), wmask)
+  np.testing.assert_array_equal(fused.cpu().numpy(), want)
+  lib.dm_debug_force_fused_split(40, 4)
+  try:
+    f4, m4 = proj.orth_project_fused(d, cam_pose=pose)
+    assert _fused_split(lib) == [40, 16, 4, 16]
+  finally:
+    lib.dm_debug_force_fused_split(0, 0)
+  assert torch.equal(f4, fused) and torch.equal(m4, fmask)

@@ -10,7 +10,11 @@
 //   k_map_quantize    maps.py:944-1019 (true division, round half up, int64)
 //   k_scatter_flat    utils.scatter_tensor incl. the torch_scatter call
 //                     (utils.py:389-492) on pre-ravelled indices
+#include <stdlib.h>
+#include <string.h>
+
 #include "dm_kernels.hpp"
+#include "dm_window_geometry.hpp"      // exact_reciprocal
 
 namespace dm {
 
@@ -165,46 +169,87 @@ k_camera_affine_grid(View v, int dc, const dm_frame* __restrict__ frames,
   reinterpret_cast<float2*>(grid)[k] = make_float2(u, w);
 }
 
-// The same, four pixels of a row per thread (W % 4 == 0, 16-byte aligned images): one
-// 16-byte depth load, two 16-byte grid stores, the row's ray slope computed once.
+// What the ego-motion kernel reads of a frame, passed in the kernel arguments (no staged copy
+// for batches of up to kGridFrames frames).
+struct GridFrame { float rp[9], cam_h, ry[9], tx, tz, ri[9], pad; };
+constexpr int kGridFrames = 24;          // 24 * 128 bytes of kernel arguments
+struct GridFrames { GridFrame f[kGridFrames]; };
+
+// The same, four pixels of a row per trip (W % 4 == 0, 16-byte aligned images): one 16-byte depth
+// load and two 16-byte grid stores per trip, two trips in flight, a fixed number of workgroups per
+// image that stride over it (a workgroup per 1024 pixels was twenty thousand short-lived blocks
+// for a 16-frame batch).  (x - cx) / fx by the exact reciprocal-FMA division of dm_pixel.hpp where
+// fx allows it; the two perspective divisions are IEEE divisions.
+template <bool FAST_DIV, bool FROM_ARGS>
 __global__ void __launch_bounds__(256)
-k_camera_affine_grid4(View v, int dc, const dm_frame* __restrict__ frames,
-                      const float* __restrict__ depth, float* __restrict__ grid) {
-  const int b = blockIdx.z, ch = blockIdx.y;
+k_camera_affine_grid4(View v, float fx_inv, float fy_inv, int dc, GridFrames args,
+                      const dm_frame* __restrict__ frames, int b0, const float* __restrict__ depth,
+                      float* __restrict__ grid) {
+  const int bl = blockIdx.z, b = b0 + bl, ch = blockIdx.y;
   const int W4 = v.W >> 2;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= v.H * W4) return;
-  const dm_frame* f = frames + b;
-  const float* rp = f->Rp; const float* ry = f->Ry; const float* ri = f->reserved;  // R(-pitch)
-  const int r = i / W4, q0 = (i - r * W4) << 2;
-  const size_t k = ((size_t)b * dc + ch) * ((size_t)v.H * v.W) + (size_t)r * v.W + q0;
-  const float4 zz = *reinterpret_cast<const float4*>(depth + k);
-  const float zs[4] = {zz.x, zz.y, zz.z, zz.w};
-  const float ay = ray_y(v, r);
-  float out[8];
+  const int total = v.H * W4;
+  // the frame's record: wave-uniform scalars either way
+  float rp[9], ry[9], ri[9], cam_h, tx, tz;
+  if (FROM_ARGS) {
+    const GridFrame& f = args.f[bl];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float z = zs[j];
-    const float X = ray_x(v, q0 + j) * z, Y = ay * z;
-    const float x1 = __builtin_fmaf(z, rp[6], __builtin_fmaf(Y, rp[3], X * rp[0])) + 0.0f;
-    const float y1 = __builtin_fmaf(z, rp[7], __builtin_fmaf(Y, rp[4], X * rp[1])) + f->cam_height;
-    const float z1 = __builtin_fmaf(z, rp[8], __builtin_fmaf(Y, rp[5], X * rp[2])) + 0.0f;
-    const float x2 = __builtin_fmaf(z1, ry[6], __builtin_fmaf(y1, ry[3], x1 * ry[0])) + f->tx;
-    const float y2 = __builtin_fmaf(z1, ry[7], __builtin_fmaf(y1, ry[4], x1 * ry[1])) + 0.0f;
-    const float z2 = __builtin_fmaf(z1, ry[8], __builtin_fmaf(y1, ry[5], x1 * ry[2])) + f->tz;
-    const float x3 = x2 + 0.0f, y3 = y2 + (-f->cam_height), z3 = z2 + 0.0f;
-    const float xc = __builtin_fmaf(z3, ri[6], __builtin_fmaf(y3, ri[3], x3 * ri[0]));
-    const float yc = __builtin_fmaf(z3, ri[7], __builtin_fmaf(y3, ri[4], x3 * ri[1]));
-    const float zc = __builtin_fmaf(z3, ri[8], __builtin_fmaf(y3, ri[5], x3 * ri[2]));
-    const float z_eps = zc + 1e-7f;
-    const float u = xc / z_eps * v.fx + v.cx;
-    float w = yc / z_eps * v.fy + v.cy;
-    if (v.flip_h) w = v.Hm1 - w;
-    out[2 * j] = u; out[2 * j + 1] = w;
+    for (int i = 0; i < 9; ++i) { rp[i] = f.rp[i]; ry[i] = f.ry[i]; ri[i] = f.ri[i]; }
+    cam_h = f.cam_h; tx = f.tx; tz = f.tz;
+  } else {
+    const dm_frame* f = frames + b;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { rp[i] = f->Rp[i]; ry[i] = f->Ry[i]; ri[i] = f->reserved[i]; }
+    cam_h = f->cam_height; tx = f->tx; tz = f->tz;
   }
-  float4* dst = reinterpret_cast<float4*>(grid + 2 * k);
-  dst[0] = make_float4(out[0], out[1], out[2], out[3]);
-  dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+  const size_t base = ((size_t)b * dc + ch) * ((size_t)v.H * v.W);
+  auto project4 = [&](int i, const float4 zz) {
+    const int r = i / W4, q0 = (i - r * W4) << 2;
+    const float zs[4] = {zz.x, zz.y, zz.z, zz.w};
+    float yr = (float)r;
+    if (v.flip_h) yr = v.Hm1 - yr;
+    const float ay = div_f<FAST_DIV>(yr - v.cy, v.fy, fy_inv);          // maps.py:670-678
+    float out[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float z = zs[j];
+      const float X = div_f<FAST_DIV>((float)(q0 + j) - v.cx, v.fx, fx_inv) * z, Y = ay * z;
+      // camera -> local (maps.py:753-800)
+      const float x1 = __builtin_fmaf(z, rp[6], __builtin_fmaf(Y, rp[3], X * rp[0])) + 0.0f;
+      const float y1 = __builtin_fmaf(z, rp[7], __builtin_fmaf(Y, rp[4], X * rp[1])) + cam_h;
+      const float z1 = __builtin_fmaf(z, rp[8], __builtin_fmaf(Y, rp[5], X * rp[2])) + 0.0f;
+      // the pose transition (maps.py:850-895)
+      const float x2 = __builtin_fmaf(z1, ry[6], __builtin_fmaf(y1, ry[3], x1 * ry[0])) + tx;
+      const float y2 = __builtin_fmaf(z1, ry[7], __builtin_fmaf(y1, ry[4], x1 * ry[1])) + 0.0f;
+      const float z2 = __builtin_fmaf(z1, ry[8], __builtin_fmaf(y1, ry[5], x1 * ry[2])) + tz;
+      // local -> camera: translate first, then rotate by -pitch (maps.py:802-848)
+      const float x3 = x2 + 0.0f, y3 = y2 + (-cam_h), z3 = z2 + 0.0f;
+      const float xc = __builtin_fmaf(z3, ri[6], __builtin_fmaf(y3, ri[3], x3 * ri[0]));
+      const float yc = __builtin_fmaf(z3, ri[7], __builtin_fmaf(y3, ri[4], x3 * ri[1]));
+      const float zc = __builtin_fmaf(z3, ri[8], __builtin_fmaf(y3, ri[5], x3 * ri[2]));
+      // camera -> image (maps.py:684-751)
+      const float z_eps = zc + 1e-7f;
+      const float u = xc / z_eps * v.fx + v.cx;
+      float w = yc / z_eps * v.fy + v.cy;
+      if (v.flip_h) w = v.Hm1 - w;
+      out[2 * j] = u; out[2 * j + 1] = w;
+    }
+    float4* dst = reinterpret_cast<float4*>(grid + 2 * (base + (size_t)r * v.W + q0));
+    dst[0] = make_float4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+  };
+  // a workgroup owns one contiguous piece of the image (chunked streams write faster on this chip
+  // than grid-strided ones: profiles/r01_microbench.log), its threads stride over it, two trips in flight
+  const float4* src = reinterpret_cast<const float4*>(depth + base);
+  const int per_block = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int end = min(total, ((int)blockIdx.x + 1) * per_block);
+  int i = (int)blockIdx.x * per_block + (int)threadIdx.x;
+  constexpr int kStep = 256;
+  for (; i + kStep < end; i += 2 * kStep) {
+    const float4 za = src[i], zb = src[i + kStep];
+    project4(i, za);
+    project4(i + kStep, zb);
+  }
+  if (i < end) project4(i, src[i]);
 }
 
 inline int nblocks(size_t n, int cap = 8192) {
@@ -236,16 +281,41 @@ hipError_t run_map_quantize(const float* x, const float* z, const float* woff, c
 hipError_t run_camera_affine_grid(const dm_params& p, const dm_frame* frames_host,
                                   const float* depth, float* grid, void* ws, hipStream_t s) {
   if (p.B == 0) return hipSuccess;
-  hipError_t e = hipMemcpyAsync(ws, frames_host, (size_t)p.B * sizeof(dm_frame),
-                                hipMemcpyHostToDevice, s);
-  if (e != hipSuccess) return e;
   const View v = make_view(p);
   if (p.W % 4 == 0 && reinterpret_cast<uintptr_t>(depth) % 16 == 0 &&
       reinterpret_cast<uintptr_t>(grid) % 16 == 0) {
-    dim3 g((unsigned)((p.H * (p.W / 4) + 255) / 256), p.dc, p.B);
-    hipLaunchKernelGGL(k_camera_affine_grid4, g, dim3(256), 0, s, v, p.dc,
-                       static_cast<const dm_frame*>(ws), depth, grid);
+    float fx_inv = 0.0f, fy_inv = 0.0f;
+    const bool fast = exact_reciprocal(p.fx, &fx_inv) && exact_reciprocal(p.fy, &fy_inv) && p.fx >= 1e-6f &&
+                      p.fx <= 1e6f && p.fy >= 1e-6f && p.fy <= 1e6f;
+    // about sixteen workgroups per CU over the whole launch (measured at 16 x 1280x960: 512 ... 16 K
+    // workgroups 61, 57, 52.5, 48, 53, 69 us), whole frames per launch
+    const int chunks = p.H * (p.W / 4);
+    thread_local GridFrames args;
+    for (int b0 = 0; b0 < p.B; b0 += kGridFrames) {
+      const int nb = p.B - b0 < kGridFrames ? p.B - b0 : kGridFrames;
+      static const int target = getenv("DM_X_EGO_BLOCKS") ? atoi(getenv("DM_X_EGO_BLOCKS")) : 4096;
+      int per_image = target / (nb * p.dc);
+      const int most = (chunks + 255) / 256;
+      if (per_image < 1) per_image = 1;
+      if (per_image > most) per_image = most;
+      for (int i = 0; i < nb; ++i) {
+        const dm_frame& f = frames_host[b0 + i];
+        GridFrame& g = args.f[i];
+        memcpy(g.rp, f.Rp, sizeof(g.rp)); memcpy(g.ry, f.Ry, sizeof(g.ry)); memcpy(g.ri, f.reserved, sizeof(g.ri));
+        g.cam_h = f.cam_height; g.tx = f.tx; g.tz = f.tz; g.pad = 0.0f;
+      }
+      const dim3 g((unsigned)per_image, p.dc, nb);
+      if (fast)
+        hipLaunchKernelGGL((k_camera_affine_grid4<true, true>), g, dim3(256), 0, s, v, fx_inv, fy_inv, p.dc, args,
+                           (const dm_frame*)nullptr, b0, depth, grid);
+      else
+        hipLaunchKernelGGL((k_camera_affine_grid4<false, true>), g, dim3(256), 0, s, v, fx_inv, fy_inv, p.dc, args,
+                           (const dm_frame*)nullptr, b0, depth, grid);
+    }
   } else {
+    hipError_t e = hipMemcpyAsync(ws, frames_host, (size_t)p.B * sizeof(dm_frame),
+                                  hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
     dim3 g((unsigned)((p.H * p.W + 255) / 256), p.dc, p.B);
     hipLaunchKernelGGL(k_camera_affine_grid, g, dim3(256), 0, s, v, p.dc,
                        static_cast<const dm_frame*>(ws), depth, grid);

@@ -154,6 +154,27 @@ def test_bench_rccl_leg_with_one_rank():
   assert one["fused_checksum"]["cells"] > 0
 
 
+def test_the_drivers_bench_command_has_no_stall(oracle):
+  """`python3 bench.py --gpus 1 --steps 20 --warmup 5` -- the command the harness runs -- in a
+  fresh child process: the warm-up executes the timed loop's body, so no device allocation may
+  happen inside the timed region (one cost 2 ms on a harness box in round 2), no step may take
+  the host more than a few launches' time, and the 20 steps must run at the rate of a long run."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DM_BENCH_TRACE="1")
+  cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+         "--no-other-configs", "--no-cpu-baseline"]
+  out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+  assert r["steps"] == 20 and r["warmup"] == 5
+  assert r["device_allocations_in_timed_loop"] == 0
+  assert max(r["host_step_us"]) < 400, r["host_step_us"]         # (the stall was 2 000 us)
+  assert r["ms_per_step"] < 0.075, r["ms_per_step"]              # (the stalled run: 0.145)
+  assert "new set" in r["config"]["camera_state"]                # poses change on every step
+  assert r["value"] > 850_000
+
+
 @pytest.mark.parametrize("dmin,dmax,fast", [(0.15, None, True), (None, 5.05, True), (None, None, False)])
 def test_missing_depth_truncations_at_full_geometry(dmap, oracle, dmin, dmax, fast):
   """The reference's default is no depth truncation (maps.py:1267-1268).  The call then runs

@@ -437,10 +437,10 @@ def main():
 
 
 def committed_traffic(workload, lib_path):
-  """(bytes per launch sequence, note) from profiles/r02_hbm_traffic.json if its `lib_md5`
+  """(bytes per launch sequence, note) from profiles/r03_hbm_traffic.json if its `lib_md5`
   is the md5 of the loaded library, else (None, why)."""
   import hashlib
-  tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+  tpath = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
   if workload != "cfg2" or not os.path.exists(tpath):
     return None, "no committed PMC summary for this workload"
   with open(tpath) as f:
@@ -448,10 +448,10 @@ def committed_traffic(workload, lib_path):
   with open(lib_path, "rb") as f:
     md5 = hashlib.md5(f.read()).hexdigest()
   if rec.get("lib_md5") != md5:
-    return None, (f"profiles/r02_hbm_traffic.json was measured on library build "
+    return None, (f"profiles/r03_hbm_traffic.json was measured on library build "
                   f"{rec.get('lib_md5')}, the loaded one is {md5}: not quoted")
   return rec.get("launch_sequence_bytes"), (
-      "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command on "
+      "profiles/r03_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command on "
       "this library build, gfx950 correction applied; bytes per launch sequence)")
 
 

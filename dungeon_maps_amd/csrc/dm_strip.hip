@@ -438,7 +438,10 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const
         ca.b0 = b0 + c0;
         if (oc_total >= kListMinChannels) {        // (value maps of many channels: four entries per thread)
           // (at least one block per strip's list segment)
-          const int blocks = kCombineSlots / DM_X_COMBINE_ENTRIES > plan.P ? kCombineSlots / DM_X_COMBINE_ENTRIES : plan.P;
+          // (many channels: the chip holds 2 K blocks at a time, so the fewer blocks per (frame, channel) the
+          // fewer rounds of the same chain of round trips -- 8 blocks: 131 us at cfg3, 4: 88 us)
+          const int few = kCombineSlots / DM_X_COMBINE_ENTRIES / 2;
+          const int blocks = few > plan.P ? few : plan.P;
           const dim3 g(blocks, (unsigned)(nc * oc));
           e = is_max ? launch(k_strip_combine<kMax, DM_X_COMBINE_ENTRIES>, g, dim3(kCombineThreads), 0, s, ca)
                      : launch(k_strip_combine<kMin, DM_X_COMBINE_ENTRIES>, g, dim3(kCombineThreads), 0, s, ca);

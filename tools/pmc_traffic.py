@@ -15,7 +15,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEQUENCE = ("k_strip_scatter", "k_strip_combine")          # the orth_project launch sequence
-OTHERS = ("k_fuse_unions", "k_strip_prepare")
+OTHERS = ("k_fuse_unions",)
 
 
 def per_kernel(directory, counter):
@@ -62,7 +62,7 @@ def main():
   with open(out + ".json", "w") as f:
     json.dump(rec, f, indent=1)
   with open(out + ".md", "w") as f:
-    f.write("# Round 2 -- HBM traffic of the cfg2 launch sequence (PMC, MI355X)\n\n")
+    f.write("# Round 3 -- HBM traffic of the cfg2 launch sequence (PMC, MI355X)\n\n")
     f.write("    " + rec["command"] + "\n\n")
     f.write("Library build (md5 of libdungeon_maps_amd.so): `%s`.  %s.\n\n" % (md5, rec["correction"]))
     f.write("| kernel | read (MB) | written (MB) | dispatches |\n|---|---|---|---|\n")

@@ -71,6 +71,18 @@ __device__ inline float dpp_f(float v) {
 }
 template <int CTRL>
 __device__ inline int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+// the value of lane (lane ^ M), M = 1 .. 7: quad permutes, and row_half_mirror (lane ^ 7) in front
+// of them for the upper half
+template <int M>
+__device__ inline int lane_xor(int v) {
+  static_assert(M >= 1 && M <= 7, "within aligned groups of eight lanes");
+  if (M == 1) return dpp_i<0xB1>(v);
+  if (M == 2) return dpp_i<0x4E>(v);
+  if (M == 3) return dpp_i<0x1B>(v);
+  if (M == 7) return dpp_i<0x141>(v);
+  const int h = dpp_i<0x141>(v);             // lane ^ 7, then ^ (M ^ 7)
+  return M == 4 ? dpp_i<0x1B>(h) : M == 5 ? dpp_i<0x4E>(h) : dpp_i<0xB1>(h);
+}
 // min / max over aligned groups of 8 lanes, the result in every lane of the group
 __device__ inline float min8(float v) {
   v = fminf(v, dpp_f<0xB1>(v)); v = fminf(v, dpp_f<0x4E>(v)); return fminf(v, dpp_f<0x141>(v));
@@ -495,70 +507,90 @@ k_strip_scatter(StripArgs a) {
       }
     }
   };
-  // (more than four strips -- small frames, narrow windows: the same with rolled loops over the
-  // covers in LDS, which keeps the registers of the eight-strip case out of this kernel's budget)
-  auto row_tables_rolled = [&]() {
-    for (int r0 = wave * 64; r0 < U.h; r0 += kScatterThreads) {
-      const int r = r0 + lane;
+  // More than four strips (small frames, narrow windows): eight lanes per row (lane = row x strip;
+  // all 1024 threads busy on 128 rows of the union window at a time) -- the straight-line version
+  // above with eight covers per thread does not fit the kernel's registers, and rolled loops over
+  // covers in LDS took 6.3 us at the reference demo's frame (320x240, eight strips) against 2.7 us
+  // this way (at four strips the version above is the faster one, 1.8 against 2.2 us: it needs no
+  // second pass).  Each lane computes ONE cover, sees the other strips' through lane-xor DPP moves -- in
+  // strip::row_owned's order, so every lane cuts its own cover to its owned span on the way -- and
+  // answers "does another cover continue where mine ends?" for the hole test; the lane of this
+  // workgroup's strip stores the owned span and the row's number of list entries, lane 0 of the
+  // row the reach.  Then (behind a barrier) the scan over the rows, one lane per row.
+  auto row_tables_lanes = [&](auto p2_tag) {
+    constexpr int kP2 = decltype(p2_tag)::value;
+    constexpr int kShift = kP2 == 4 ? 2 : 3;
+    constexpr int kRowsPerPass = kScatterThreads >> kShift;
+    const int q = lane & (kP2 - 1);
+    const Win16 gw = geom->win[q];
+    const strip::Line gl = geom->L[q], gr = geom->R[q];
+    for (int r0 = 0; r0 < U.h; r0 += kRowsPerPass) {       // (uniform trips: the DPP moves)
+      const int r = r0 + ((int)threadIdx.x >> kShift);
       const bool live = r < U.h;
-      uint32_t* const crow = covers + (live ? r : 0) * P2;
-      int rlo = 32767, rhi = 0;
-      uint32_t mine = 0u;
-      if (live) {
-#pragma unroll 2
-        for (int q = 0; q < P2; ++q) {
-          const Win16 gw = geom->win[q];
-          const strip::Line gl = geom->L[q], gr = geom->R[q];
-          const uint32_t c = strip::row_cover(gw, gl, gr, U.z0 + r, a.mw);
-          crow[q] = c;
-          rlo = min(rlo, c ? (int)(c & 0xffffu) : 32767); rhi = max(rhi, (int)(c >> 16));
-          mine = q == part ? c : mine;
-        }
+      const uint32_t cov = live ? strip::row_cover(gw, gl, gr, U.z0 + r, a.mw) : 0u;
+      const int end = (int)(cov >> 16);
+      int rlo = cov ? (int)(cov & 0xffffu) : 32767, rhi = end;
+      int lo = (int)(cov & 0xffffu), hi = end;
+      bool continued = cov == 0u;
+      uint32_t oth[kP2];
+      auto see = [&](int m, uint32_t other) {
+        oth[m] = other;
+        rlo = min(rlo, other ? (int)(other & 0xffffu) : 32767); rhi = max(rhi, (int)(other >> 16));
+        strip::cut_span(lo, hi, other);
+        continued = continued | (((int)(other & 0xffffu) <= end) & (end < (int)(other >> 16)));
+      };
+      oth[0] = cov;
+      see(1, (uint32_t)lane_xor<1>((int)cov)); see(2, (uint32_t)lane_xor<2>((int)cov)); see(3, (uint32_t)lane_xor<3>((int)cov));
+      if (kP2 == 8) {
+        see(4 % kP2, (uint32_t)lane_xor<4>((int)cov)); see(5 % kP2, (uint32_t)lane_xor<5>((int)cov));
+        see(6 % kP2, (uint32_t)lane_xor<6>((int)cov)); see(7 % kP2, (uint32_t)lane_xor<7>((int)cov));
       }
-      int lo = (int)(mine & 0xffffu), hi = (int)(mine >> 16);
-      bool hole = false;
-      if (live) {       // (the thread's own LDS stores read back)
-#pragma unroll 1
-        for (int m = 1; m < P2; ++m) strip::cut_span(lo, hi, crow[part ^ m]);
-#pragma unroll 1
-        for (int q = 0; q < P2; ++q) {
-          const uint32_t cq = crow[q];
-          const int end = (int)(cq >> 16);
-          bool continued = (cq == 0u) | (end >= rhi);
-#pragma unroll 1
-          for (int o = 0; o < P2; ++o) {
-            const uint32_t co = crow[o];
-            continued = continued | ((o != q) & ((int)(co & 0xffffu) <= end) & (end < (int)(co >> 16)));
-          }
-          hole = hole | !continued;
-        }
-      }
-      int entries = (int)((mine >> 16) - (mine & 0xffffu)) - (hi > lo ? hi - lo : 0);
-      entries = live ? entries >> 2 : 0;
-      const int before = wave_inclusive_scan(entries);
-      if (lane == 63) geom->chunk_entries[r0 >> 6] = before;
+      continued = continued | (end >= rhi);
+      // a hole between covers inside the hull: some cover ends inside the hull where no other continues
+      const unsigned long long open = __builtin_amdgcn_ballot_w64(!continued);
+      const bool hole = ((open >> (lane & ~(kP2 - 1))) & ((1ull << kP2) - 1ull)) != 0ull;
       if (live) {
-        owned_t[r] = hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
-        reach[r] = rhi > rlo ? make_uint2((unsigned)rlo, (unsigned)(rhi - rlo)) : make_uint2(0u, 0u);
-        list_at[r] = before - entries;
-        if (__builtin_expect(hole, 0)) {
-          if (MODE != kIndexOut && (U.z0 + r) % nparts == part) {
-            for (int x = rlo; x < rhi; x += 4) {
-              bool any = false;
-#pragma unroll 1
-              for (int q = 0; q < P2; ++q) any = any | strip::in_span(crow[q], x);
-              if (!any) {
-                const int cell = (U.z0 + r) * a.mw + x;
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, cell << 2, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, cell, 0, 0);
+        covers[r * kP2 + q] = cov;
+        if (q == part) {
+          owned_t[r] = hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
+          // entries of this strip's list on the row: the groups of its cover outside the owned span
+          list_at[r] = ((int)((cov >> 16) - (cov & 0xffffu)) - (hi > lo ? hi - lo : 0)) >> 2;
+        }
+        if (q == 0) {
+          reach[r] = rhi > rlo ? make_uint2((unsigned)rlo, (unsigned)(rhi - rlo)) : make_uint2(0u, 0u);
+          // Groups of the hull in no strip's cover (not seen in practice, but nothing rules them
+          // out) are written here, with the fill value, by the workgroup whose fill duty owns the
+          // map row.
+          if (__builtin_expect(hole, 0)) {
+            if (MODE != kIndexOut && (U.z0 + r) % nparts == part) {
+              for (int x = rlo; x < rhi; x += 4) {
+                bool any = false;
+#pragma unroll
+                for (int m = 0; m < kP2; ++m) any = any | strip::in_span(oth[m], x);
+                if (!any) {
+                  const int cell = (U.z0 + r) * a.mw + x;
+                  __builtin_amdgcn_raw_buffer_store_b128((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, cell << 2, 0, 0);
+                  __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, cell, 0, 0);
+                }
               }
             }
           }
         }
       }
     }
+    lds_barrier();
+    // where the row's entries of the strip's list go: a scan over chunks of 64 rows here, over
+    // the chunks by wave 0 behind the next barrier
+    for (int r0 = wave * 64; r0 < U.h; r0 += kScatterThreads) {       // (wave-uniform trips: the scan's shuffles)
+      const int r = r0 + lane;
+      const bool live = r < U.h;
+      const int entries = live ? list_at[r] : 0;
+      const int before = wave_inclusive_scan(entries);
+      if (lane == 63) geom->chunk_entries[r0 >> 6] = before;
+      if (live) list_at[r] = before - entries;
+    }
   };
-  if (P2 == 4) row_tables(std::integral_constant<int, 4>{}); else row_tables_rolled();
+  if (P2 == 4) row_tables(std::integral_constant<int, 4>{}); else row_tables_lanes(std::integral_constant<int, 8>{});
   DM_STAMP(8);
   // What the pixel loop reads of the kernel arguments and of the frame's pose is (re)loaded HERE,
   // through pointers the compiler cannot see through: a scalar whose live range crossed the

@@ -7,7 +7,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dungeon_maps_amd as dmap
 from dungeon_maps_amd import _native
-B, H, W, mh, mw = 64, 480, 640, 512, 512
+B, H, W, mh, mw = [int(v) for v in os.environ.get("DM_STAMPS_SHAPE", "64,480,640,512,512").split(",")]
 g = torch.Generator().manual_seed(1234)
 depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g).cuda()
 pose = torch.empty(B, 3).uniform_(-1, 1, generator=g); pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)

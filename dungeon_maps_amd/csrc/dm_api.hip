@@ -341,6 +341,48 @@ int dm_fuse_scatter_f32(const dm_fuse_src* src, float width_offset, float height
   return DM_OK;
 }
 
+static int check_fuse_sources(const dm_fuse_src* srcs, int32_t n) {
+  if (!srcs || n < 1 || n > DM_FUSE_MAX_SOURCES)
+    return fail(DM_ERR_INVALID_ARGUMENT, "1 .. %d source maps per call (got %d)", DM_FUSE_MAX_SOURCES, (int)n);
+  for (int i = 0; i < n; ++i) {
+    const int rc = check_fuse_src(srcs + i);
+    if (rc != DM_OK) return rc;
+    if (srcs[i].b != srcs[0].b || srcs[i].c != srcs[0].c)
+      return fail(DM_ERR_INVALID_ARGUMENT, "source maps of one call share b and c (%d: b=%d c=%d against b=%d c=%d)",
+                  i, srcs[i].b, srcs[i].c, srcs[0].b, srcs[0].c);
+  }
+  if (srcs[0].b == 0 || srcs[0].c == 0) return fail(DM_ERR_INVALID_ARGUMENT, "empty source maps");
+  if ((int64_t)srcs[0].b * n > 65535) return fail(DM_ERR_INVALID_ARGUMENT, "too many batch rows");
+  return DM_OK;
+}
+
+int dm_fuse_bbox_multi_f32(const dm_fuse_src* srcs, int32_t n, int32_t* stats_dev, void* stream) {
+  const int rc = check_fuse_sources(srcs, n);
+  if (rc != DM_OK) return rc;
+  if (!stats_dev) return fail(DM_ERR_INVALID_ARGUMENT, "stats is NULL");
+  const hipError_t e = dm::run_fuse_bbox_multi(srcs, n, stats_dev, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
+int dm_fuse_scatter_multi_f32(const dm_fuse_src* srcs, int32_t n, float width_offset, float height_offset,
+                              int flip_h, int64_t map_height, int64_t map_width, int reduction,
+                              float* canvas_dev, float* height_canvas_dev, void* stream) {
+  const int rc = check_fuse_sources(srcs, n);
+  if (rc != DM_OK) return rc;
+  if (reduction != DM_REDUCE_MAX && reduction != DM_REDUCE_MIN)
+    return fail(DM_ERR_UNSUPPORTED, "fused map scatter supports max/min only (got %d)", reduction);
+  if (map_height < 1 || map_width < 1 || map_height * map_width >= (1ll << 31))
+    return fail(DM_ERR_INVALID_ARGUMENT, "bad target size %lldx%lld", (long long)map_height,
+                (long long)map_width);
+  if (!canvas_dev) return fail(DM_ERR_INVALID_ARGUMENT, "canvas is NULL");
+  const hipError_t e = dm::run_fuse_scatter_multi(srcs, n, width_offset, height_offset, flip_h, (int)map_height,
+                                                  (int)map_width, reduction == DM_REDUCE_MAX, canvas_dev,
+                                                  height_canvas_dev, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
 int dm_crop_nearest_f32(const float* image_dev, const uint8_t* mask_dev, const float* center_dev,
                         int64_t B, int64_t C, int64_t h, int64_t w, int64_t crop_h, int64_t crop_w,
                         float fill, int has_fill, float* out_dev, uint8_t* out_mask_dev,

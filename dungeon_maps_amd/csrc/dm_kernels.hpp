@@ -73,6 +73,10 @@ hipError_t run_crop_nearest(const float* src, const uint8_t* src_mask, const flo
                             int C, int h, int w, int ch, int cw, float fill, int has_fill,
                             float* dst, uint8_t* dst_mask, hipStream_t s);
 hipError_t run_fuse_bbox(const dm_fuse_src& s, int* stats, int init, hipStream_t st);
+hipError_t run_fuse_bbox_multi(const dm_fuse_src* srcs, int n, int* stats, hipStream_t st);
+hipError_t run_fuse_scatter_multi(const dm_fuse_src* srcs, int n, float woff, float hoff, int flip,
+                                  int mh, int mw, int is_max, float* canvas, float* hcanvas,
+                                  hipStream_t st);
 hipError_t run_fuse_scatter(const dm_fuse_src& s, float woff, float hoff, int flip, int mh, int mw,
                             int is_max, float* canvas, float* hcanvas, hipStream_t st);
 size_t scatter_workspace_bytes(size_t rows, size_t M, int has_fill, int reduction);

@@ -522,7 +522,107 @@ k_fuse_scatter(dm_fuse_src s, float woff, float hoff, int flip, float mhm1, int 
   if (hcanvas) atomic_max_f(hcanvas + ((size_t)bi * s.c + ci) * M + cell, yy);
 }
 
+// Several source maps in one launch (MapBuilder.merge fuses two maps per frame: the launches
+// were a third of its device time).  blockIdx.z = source * b + batch row.
+struct FuseSources {
+  int n;
+  dm_fuse_src s[DM_FUSE_MAX_SOURCES];
+};
+
+// The bounding box as FIVE MAXIMA of unsigned words that start at zero (so a zero-filled stats
+// buffer needs no initialising launch): u = x ^ 0x80000000 orders like x;
+// stats = {max ~u(col), max u(col), max ~u(row), max u(row), any}.
+__global__ void __launch_bounds__(256)
+k_fuse_bbox_multi(FuseSources a, unsigned* __restrict__ stats) {
+  __shared__ unsigned sh[5];
+  if (threadIdx.x < 5) sh[threadIdx.x] = 0u;
+  __syncthreads();
+  const int si = blockIdx.z / a.s[0].b, bi = blockIdx.z - si * a.s[0].b, ci = blockIdx.y;
+  const dm_fuse_src& s = a.s[si];
+  const int n = s.h * s.w;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const size_t plane = (size_t)s.h * s.w;
+    if (s.mask_dev[((size_t)bi * s.mc + (s.mc == 1 ? 0 : ci)) * plane + i]) {
+      const int row = i / s.w, col = i - row * s.w;
+      const float y = s.height_dev[((size_t)bi * s.hc + (s.hc == 1 ? 0 : ci)) * plane + i];
+      float x, yy, z;
+      fuse_point(s, bi, row, col, y, x, yy, z);
+      // map_quantize with zero offsets, unflipped (maps.py:2146-2160)
+      const unsigned c0 = (unsigned)sat_i32(__builtin_floorf((x / s.target_res + 0.0f) + 0.5f)) ^ 0x80000000u;
+      const unsigned r0 = (unsigned)sat_i32(__builtin_floorf((z / s.target_res + 0.0f) + 0.5f)) ^ 0x80000000u;
+      atomicMax(&sh[0], ~c0); atomicMax(&sh[1], c0);
+      atomicMax(&sh[2], ~r0); atomicMax(&sh[3], r0);
+      sh[4] = 1u;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && sh[4]) {
+    atomicMax(&stats[0], sh[0]); atomicMax(&stats[1], sh[1]);
+    atomicMax(&stats[2], sh[2]); atomicMax(&stats[3], sh[3]);
+    atomicMax(&stats[4], 1u);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_fuse_scatter_multi(FuseSources a, float woff, float hoff, int flip, float mhm1, int mh, int mw,
+                     int is_max, float* __restrict__ canvas, float* __restrict__ hcanvas) {
+  const int si = blockIdx.z / a.s[0].b, bi = blockIdx.z - si * a.s[0].b, ci = blockIdx.y;
+  const dm_fuse_src& s = a.s[si];
+  const int n = s.h * s.w;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t plane = (size_t)s.h * s.w;
+  if (!s.mask_dev[((size_t)bi * s.mc + (s.mc == 1 ? 0 : ci)) * plane + i]) return;
+  const int row = i / s.w, col = i - row * s.w;
+  const float y = s.height_dev[((size_t)bi * s.hc + (s.hc == 1 ? 0 : ci)) * plane + i];
+  float x, yy, z;
+  fuse_point(s, bi, row, col, y, x, yy, z);
+  const float xf = x / s.target_res + woff;                     // maps.py:1004-1015
+  float zf = z / s.target_res + hoff;
+  if (flip) zf = mhm1 - zf;
+  const float cf = __builtin_floorf(xf + 0.5f), rf = __builtin_floorf(zf + 0.5f);
+  if (!(cf >= 0.0f && cf < (float)mw && rf >= 0.0f && rf < (float)mh)) return;   // maps.py:1150-1158
+  const size_t cell = (size_t)(int)rf * mw + (int)cf;
+  const size_t M = (size_t)mh * mw;
+  const float v = s.value_dev ? s.value_dev[((size_t)bi * s.c + ci) * plane + i] : yy;
+  float* dst = canvas + ((size_t)bi * s.c + ci) * M + cell;
+  if (is_max) atomic_max_f(dst, v); else atomic_min_f(dst, v);
+  if (hcanvas) atomic_max_f(hcanvas + ((size_t)bi * s.c + ci) * M + cell, yy);
+}
+
+inline void gather_sources(const dm_fuse_src* srcs, int n, FuseSources& a, size_t& cells) {
+  a.n = n;
+  cells = 0;
+  for (int i = 0; i < n; ++i) {
+    a.s[i] = srcs[i];
+    const size_t c = (size_t)srcs[i].h * srcs[i].w;
+    cells = c > cells ? c : cells;
+  }
+}
+
 }  // namespace
+
+hipError_t run_fuse_bbox_multi(const dm_fuse_src* srcs, int n, int* stats, hipStream_t st) {
+  FuseSources a;
+  size_t cells;
+  gather_sources(srcs, n, a, cells);
+  const dim3 g((unsigned)((cells + 255) / 256), srcs[0].c, srcs[0].b * n);
+  hipLaunchKernelGGL(k_fuse_bbox_multi, g, dim3(256), 0, st, a, reinterpret_cast<unsigned*>(stats));
+  return hipGetLastError();
+}
+
+hipError_t run_fuse_scatter_multi(const dm_fuse_src* srcs, int n, float woff, float hoff, int flip,
+                                  int mh, int mw, int is_max, float* canvas, float* hcanvas,
+                                  hipStream_t st) {
+  FuseSources a;
+  size_t cells;
+  gather_sources(srcs, n, a, cells);
+  const dim3 g((unsigned)((cells + 255) / 256), srcs[0].c, srcs[0].b * n);
+  hipLaunchKernelGGL(k_fuse_scatter_multi, g, dim3(256), 0, st, a, woff, hoff, flip, (float)(mh - 1),
+                     mh, mw, is_max, canvas, hcanvas);
+  return hipGetLastError();
+}
 
 hipError_t run_fuse_bbox(const dm_fuse_src& s, int* stats, int init, hipStream_t st) {
   if (init) hipLaunchKernelGGL(k_fuse_stats_init, dim3(1), dim3(64), 0, st, stats);

@@ -80,8 +80,21 @@ class MapProjector:
     """Shallow copy with some fields replaced (None = keep); parameter list of reference
     maps.py:1349-1372."""
     overrides = locals()
-    return MapProjector(**{name: get(overrides[name], getattr(self, name))
-                           for name in self._FIELDS})
+    # (a copy of the fields with the given ones replaced, not a trip through __init__: MapBuilder
+    # clones three projectors per frame)
+    new = object.__new__(MapProjector)
+    d = new.__dict__
+    mine = self.__dict__
+    for name in self._FIELDS:
+      v = overrides[name]
+      d[name] = mine[name] if v is None else v
+    d["_dm_defaults"] = {}
+    if width is None and height is None and hfov is None and vfov is None:
+      d["cam_params"] = mine["cam_params"]         # (never modified in place)
+    else:
+      d["cam_params"] = utils.get_camera_intrinsics(width=d["width"], height=d["height"],
+                                                    hfov=d["hfov"], vfov=d["vfov"])
+    return new
 
 
   def prepare(self, batch: int, cam_pose=None, value_channels: int = 0, valid_channels: int = 0,
@@ -334,6 +347,18 @@ def _pose_rows(pose, b: int) -> torch.Tensor:
   return p.expand(b, 3) if p.shape[0] == 1 and b > 1 else p
 
 
+def _offset_rows(v) -> list:
+  """A map offset (python number, array or tensor, one value or one per batch row) as a list of
+  float32 values held in python floats."""
+  if isinstance(v, (int, float)):
+    return [float(np.float32(v))]
+  if torch.is_tensor(v):
+    if v.device.type != "cpu" or v.dtype != torch.float32:
+      v = v.detach().to(device="cpu", dtype=torch.float32)
+    return v.reshape(-1).tolist()
+  return np.asarray(v, dtype=np.float32).reshape(-1).tolist()
+
+
 def _fuse_source(m: TopdownMap, proj: MapProjector, dev):
   """dm_fuse_src of one source map (reference maps.py:2039-2069, 2137-2144), or None if it
   cannot go through the native path."""
@@ -354,11 +379,10 @@ def _fuse_source(m: TopdownMap, proj: MapProjector, dev):
   src.b, src.c, src.hc, src.mc, src.h, src.w = b, c, hc, mk.shape[1], h, w
   src.flip_h = int(bool(sp.flip_h))
   src.res, src.target_res = float(sp.map_res), float(proj.map_res)
-  woff = utils.to_tensor(sp.width_offset).to(torch.float32).reshape(-1).cpu()
-  hoff = utils.to_tensor(sp.height_offset).to(torch.float32).reshape(-1).cpu()
+  woff, hoff = _offset_rows(sp.width_offset), _offset_rows(sp.height_offset)
   for i in range(b):
-    src.woff[i] = float(woff[i if woff.numel() > 1 else 0])
-    src.hoff[i] = float(hoff[i if hoff.numel() > 1 else 0])
+    src.woff[i] = woff[i if len(woff) > 1 else 0]
+    src.hoff[i] = hoff[i if len(hoff) > 1 else 0]
   src.has_l2g = int(sp.to_global is False)
   if src.has_l2g:       # local_to_global_space: rotate by yaw, then + (x, 0, z)
     pose = _pose_rows(sp.cam_pose, b)
@@ -376,6 +400,25 @@ def _fuse_source(m: TopdownMap, proj: MapProjector, dev):
       for k in range(12):
         src.g2l[i][k] = row[k]
   return src, (hm, mk, val)      # keep the tensors alive
+
+
+_STATS_SLOTS = 512
+_stats_rings = {}     # device -> [zero-filled (slots, 8) int32 tensor, next slot]
+
+
+def _zeroed_stats(dev) -> torch.Tensor:
+  """Five zero words on ``dev`` for dm_fuse_bbox_multi_f32 (zero is the identity of its maxima):
+  the next row of a ring that is zero-filled once per _STATS_SLOTS uses instead of once per use.
+  (A row is read back -- a host sync -- before the next one is taken, so when the ring wraps no
+  kernel is still writing into it.)"""
+  key = (dev.type, dev.index)
+  ring = _stats_rings.get(key)
+  if ring is None or ring[1] == _STATS_SLOTS:
+    ring = [torch.zeros((_STATS_SLOTS, 8), dtype=torch.int32, device=dev), 0]
+    _stats_rings[key] = ring
+  row = ring[0][ring[1]]
+  ring[1] += 1
+  return row
 
 
 def _fuse_topdown_maps_native(maps, proj: MapProjector, fill_value, reduction):
@@ -399,15 +442,24 @@ def _fuse_topdown_maps_native(maps, proj: MapProjector, fill_value, reduction):
     return None
   lib = _native.lib()
   stream = F._stream_ptr(dev)
+  code = _native.REDUCE_MAX if red == "max" else _native.REDUCE_MIN
+  # up to FUSE_MAX_SOURCES maps per launch (MapBuilder.merge: the world map and the new frame)
+  groups = [srcs[i:i + _native.FUSE_MAX_SOURCES] for i in range(0, len(srcs), _native.FUSE_MAX_SOURCES)]
+  arrays = [(_native.FuseSrc * len(g))(*[s[0] for s in g]) for g in groups]
   with F._on_device(dev):
-    stats = torch.empty(5, dtype=torch.int32, device=dev)
-    for i, (src, _) in enumerate(srcs):
-      _native.check(lib.dm_fuse_bbox_f32(ctypes.byref(src), stats.data_ptr(), int(i == 0), stream))
-    min_x, max_x, min_z, max_z, any_valid = stats.cpu().tolist()        # the one host sync
-    if not any_valid:
+    stats = _zeroed_stats(dev)
+    for arr in arrays:
+      _native.check(lib.dm_fuse_bbox_multi_f32(arr, len(arr), stats.data_ptr(), stream))
+    # the one host sync; five maxima of order-preserving unsigned words (dm_fuse_bbox_multi_f32)
+    u = stats.cpu().numpy().view(np.uint32)
+    if not u[4]:
       last = maps[-1]
       return TopdownMap(topdown_map=last.topdown_map, mask=last.mask, height_map=last.height_map,
                         map_projector=proj)
+    min_x, max_x, min_z, max_z = (int(v) for v in (
+        (~u[0]) ^ np.uint32(0x80000000), u[1] ^ np.uint32(0x80000000),
+        (~u[2]) ^ np.uint32(0x80000000), u[3] ^ np.uint32(0x80000000)))
+    min_x, max_x, min_z, max_z = (v - (1 << 32) if v >= (1 << 31) else v for v in (min_x, max_x, min_z, max_z))
     map_width = int(max_x - min_x) + 2
     map_height = int(max_z - min_z) + 2
     f32 = np.float32
@@ -418,10 +470,9 @@ def _fuse_topdown_maps_native(maps, proj: MapProjector, fill_value, reduction):
     heights = None
     if not is_height_map:
       heights = torch.full((b, c, map_height, map_width), float(NINF), dtype=torch.float32, device=dev)
-    code = _native.REDUCE_MAX if red == "max" else _native.REDUCE_MIN
-    for src, _ in srcs:
-      _native.check(lib.dm_fuse_scatter_f32(
-          ctypes.byref(src), float(woff_v), float(hoff_v), int(bool(proj.flip_h)), map_height,
+    for arr in arrays:
+      _native.check(lib.dm_fuse_scatter_multi_f32(
+          arr, len(arr), float(woff_v), float(hoff_v), int(bool(proj.flip_h)), map_height,
           map_width, code, topdown.data_ptr(), None if heights is None else heights.data_ptr(),
           stream))
     new_mask = F.mask_from_map(topdown, fill)

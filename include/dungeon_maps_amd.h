@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 6
+#define DM_ABI_VERSION 7
 
 typedef enum dm_status {
   DM_OK = 0,
@@ -189,9 +189,17 @@ int dm_camera_affine_grid_f32(const dm_params* p, const dm_frame* frames,
  *                        canvas_dev (b, c, mh, mw) and, if height_canvas_dev is given, its
  *                        height (max) into that (b, c, mh, mw) as well.  The canvases must hold
  *                        their fill values; masks follow with dm_mask_from_map_f32.
+ *   dm_fuse_bbox_multi_f32 / dm_fuse_scatter_multi_f32   the same for 1 .. DM_FUSE_MAX_SOURCES
+ *                        source maps (equal b and c) in ONE launch each -- MapBuilder.merge
+ *                        (maps.py:2357-2406) fuses two maps per frame.  The bounding box comes
+ *                        back as five MAXIMA of unsigned words, so that a zero-filled
+ *                        stats_dev[5] needs no initialising launch: with u(x) = (uint32)x ^
+ *                        0x80000000, stats = {max ~u(col), max u(col), max ~u(row), max u(row),
+ *                        any valid}; stats_dev must hold zeros on entry.
  * Rotations are row-major 3x3 as utils.py:326-327, applied as the reference's FMA chain.
  */
 #define DM_FUSE_MAX_BATCH 8
+#define DM_FUSE_MAX_SOURCES 4
 typedef struct dm_fuse_src {
   const float* height_dev;    /* (b, hc, h, w) cell heights */
   const uint8_t* mask_dev;    /* (b, mc, h, w) valid cells */
@@ -211,6 +219,11 @@ int dm_fuse_bbox_f32(const dm_fuse_src* src, int32_t* stats_dev, int init, void*
 int dm_fuse_scatter_f32(const dm_fuse_src* src, float width_offset, float height_offset,
                         int flip_h, int64_t map_height, int64_t map_width, int reduction,
                         float* canvas_dev, float* height_canvas_dev, void* stream);
+int dm_fuse_bbox_multi_f32(const dm_fuse_src* srcs, int32_t n, int32_t* stats_dev, void* stream);
+int dm_fuse_scatter_multi_f32(const dm_fuse_src* srcs, int32_t n, float width_offset,
+                              float height_offset, int flip_h, int64_t map_height,
+                              int64_t map_width, int reduction, float* canvas_dev,
+                              float* height_canvas_dev, void* stream);
 
 /*
  * crop_topdown_map / TopdownMap.select (maps.py:1959-2037): generate_crop_grid

@@ -697,7 +697,7 @@ struct FusedBound {
   float pitch[4];
   int wp, mag_q;
   bool valid, ok;
-  int P, slab_cells, wh_sum, slack;
+  int P, slab_cells, wh_sum, h_max, slack;
   float inv, reach, g0, g1;
   float res_inv, fx_inv, fy_inv;
   bool lean;
@@ -768,7 +768,7 @@ void compute_fused_bound(const dm_params& p, int wp, const float* pitch4, int ma
   const double dtheta = 2.0 * M_PI / steps;
   const double lip = rmax * dtheta;
   const double pad_w = lip + 2.0 * fb.slack + 10.0, pad_h = lip + 2.0 * fb.slack + 4.0;
-  double area = 0.0, wh = 0.0;
+  double area = 0.0, wh = 0.0, hmax = 0.0;
   for (int i = 0; i < steps; ++i) {
     const double cs = cos(i * dtheta), sn = sin(i * dtheta);
     for (int s = 0; s < fb.P; ++s) {
@@ -783,10 +783,12 @@ void compute_fused_bound(const dm_params& p, int wp, const float* pitch4, int ma
       if (h > p.mh) h = p.mh;
       if (w * h > area) area = w * h;
       if (w + h > wh) wh = w + h;
+      if (h > hmax) hmax = h;
     }
   }
   fb.slab_cells = ((int)ceil(area) + 3) & ~3;
   fb.wh_sum = (int)ceil(wh);
+  fb.h_max = (int)ceil(hmax);
   fb.ok = true;
 }
 
@@ -853,8 +855,8 @@ hipError_t run_strip_fused(const dm_params& p, const dm_frame* frames_host, cons
   // per CU of it; a candidate is feasible when the windows of its groups (one frame's bound widened
   // by how far the group's poses are apart) fit in LDS and its slabs in the workspace.  Cost: the
   // scatter's waves of workgroups + the fuse kernel's slab traffic.
-  struct Cand { int wp, F; const FusedBound* fb; int slab; double cost; };
-  Cand best = {0, 0, nullptr, 0, 1e30};
+  struct Cand { int wp, F; const FusedBound* fb; int slab, rows; double cost; };
+  Cand best = {0, 0, nullptr, 0, 0, 1e30};
   const int kWave = 256;
   for (int F = kFusedMaxGroup; F >= 1; F >>= 1) {
     if (g_fused_force[1] && F != g_fused_force[1]) continue;
@@ -882,14 +884,17 @@ hipError_t run_strip_fused(const dm_params& p, const dm_frame* frames_host, cons
     int64_t cells = (int64_t)fb->slab_cells + 2ll * m * fb->wh_sum + 4ll * m * m;
     if (cells > (int64_t)p.mh * p.mw) cells = (int64_t)p.mh * p.mw;
     const int slab = (int)((cells + 3) & ~3ll);
-    if (fused_lds_bytes(slab, p.H) > (size_t)kMaxLdsBytes) continue;
-    const size_t need = up256((size_t)G * fb->P * sizeof(Win16)) + (size_t)G * p.dc * fb->P * slab * 4;
+    int rows = fb->h_max + 2 * m;                       // the group window's height
+    rows = ((rows < p.mh ? rows : p.mh) + 3) & ~3;
+    if (fused_lds_bytes(slab, p.H, rows) > (size_t)kMaxLdsBytes) continue;
+    const size_t need = up256((size_t)G * fb->P * sizeof(Win16)) + up256((size_t)G * fb->P * rows * 4) +
+                        (size_t)G * p.dc * fb->P * slab * 4;
     if (need > ws_bytes) continue;
     const int wgs = fb->P * p.dc * G;
     const double waves = (double)((wgs + kWave - 1) / kWave);
     const double pixels = (double)wp * p.H * F;
     const double cost = waves * (5.0 + pixels * 2.4e-4) + 2.0 + (double)wgs * slab * 4.0 / 3.0e6;
-    if (cost < best.cost) best = Cand{wp, F, fb, slab, cost};
+    if (cost < best.cost) best = Cand{wp, F, fb, slab, rows, cost};
   }
   if (!best.fb) return hipErrorNotSupported;
   const FusedBound& fb = *best.fb;
@@ -926,7 +931,8 @@ hipError_t run_strip_fused(const dm_params& p, const dm_frame* frames_host, cons
   hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn));
   if (e != hipSuccess) return e;
   Win16* wins = static_cast<Win16*>(ws);
-  float* slabs = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + up256((size_t)G * fb.P * sizeof(Win16)));
+  uint32_t* spans = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(ws) + up256((size_t)G * fb.P * sizeof(Win16)));
+  float* slabs = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(spans) + up256((size_t)G * fb.P * best.rows * 4));
   thread_local FusedArgs fa;
   memset(&fa, 0, offsetof(FusedArgs, poses));
   fa.W = p.W; fa.H = p.H; fa.clip = p.clip_border > 0 ? p.clip_border : 0; fa.flip_h = p.flip_h != 0;
@@ -936,11 +942,11 @@ hipError_t run_strip_fused(const dm_params& p, const dm_frame* frames_host, cons
   fa.Hm1 = (float)(p.H - 1); fa.mhm1 = (float)(p.mh - 1);
   fa.p4 = pitch4[0]; fa.p5 = pitch4[1]; fa.p7 = pitch4[2]; fa.p8 = pitch4[3];
   fa.wp = best.wp; fa.P = fb.P; fa.F = F;
-  fa.dc = p.dc; fa.valid_c = p.valid_c; fa.slab_stride = best.slab; fa.mh = p.mh; fa.mw = p.mw;
+  fa.dc = p.dc; fa.valid_c = p.valid_c; fa.slab_stride = best.slab; fa.max_rows = best.rows; fa.mh = p.mh; fa.mw = p.mw;
   fa.fill = p.fill; fa.cam_h = frames_host[0].cam_height;
   fa.inv = fb.inv; fa.reach = fb.reach; fa.g0 = fb.g0; fa.g1 = fb.g1; fa.cone_ok = 1;
-  fa.slabs = slabs; fa.wins = wins; fa.status = status;
-  const size_t lds_bytes = fused_lds_bytes(best.slab, p.H);
+  fa.slabs = slabs; fa.wins = wins; fa.spans = spans; fa.status = status;
+  const size_t lds_bytes = fused_lds_bytes(best.slab, p.H, best.rows);
   const size_t N = (size_t)p.H * p.W;
   const int per_launch = kPoseFrames / F * F;           // whole groups per launch
   for (int b0 = 0; b0 < p.B; b0 += per_launch) {
@@ -964,6 +970,7 @@ hipError_t run_strip_fused(const dm_params& p, const dm_frame* frames_host, cons
   fw.mh = p.mh; fw.mw = p.mw; fw.slab_stride = best.slab; fw.accumulate = accumulate; fw.fill = p.fill;
   fw.gx0 = gx0; fw.gz0 = gz0; fw.gx1 = gx1; fw.gz1 = gz1;
   fw.wins = wins; fw.slabs = slabs; fw.fused = out; fw.fused_mask = mask;
+  fw.spans = spans; fw.span_rows = best.rows;
   const int bw4 = (gx1 - gx0) / 4;
   const int heavy = gx1 > gx0 ? ((bw4 + kFuseGroups - 1) / kFuseGroups) * (gz1 - gz0) : 0;
   const int per_fill_block = kFuseGroups * kFuseLanes * 8;

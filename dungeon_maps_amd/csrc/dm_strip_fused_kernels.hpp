@@ -36,6 +36,7 @@ struct FusedArgs {
   int group0;                 // index of the launch's first group among the call's
   int dc, valid_c;
   int slab_stride;            // cells of the LDS window region = of a slab
+  int max_rows;               // rows the span table holds (>= the group window's height)
   int mh, mw;
   float fill;
   float cam_h;                // DEFER: the camera height all frames share (added at the flush)
@@ -45,6 +46,7 @@ struct FusedArgs {
   const uint8_t* valid;
   float* slabs;               // ((group * dc + ch) * P + strip) * slab_stride
   Win16* wins;                // (groups, P)
+  uint32_t* spans;            // (groups, P, max_rows)   lo | hi << 16 of every window row: the cells the slab holds
   int* status;
   StripPose poses[kPoseFrames];
 };
@@ -52,9 +54,16 @@ struct FusedArgs {
 // what strip::pose_of / window_of read of a configuration
 struct FusedRig { int mw, mh, flip_h, cone_ok; float inv, reach; };
 
-// LDS, in floats: [window region: slab_stride | 64 scratch cells | ray slopes of the image rows: H | the group's window]
-__host__ __device__ inline size_t fused_lds_bytes(int slab_cells, int H) {
-  return ((size_t)slab_cells + 64 + (size_t)((H + 3) & ~3) + 16) * 4;
+// what wave 0 leaves of the group's frames for the span pass: each frame's own window and cone edges for this strip
+struct FusedFrames {
+  Win16 win[kFusedMaxGroup];
+  strip::Line L[kFusedMaxGroup], R[kFusedMaxGroup];
+};
+
+// LDS, in floats: [window region: slab_stride | 64 scratch cells | ray slopes of the image rows: H | the group's
+// window | the frames' windows and edges | the rows' spans: max_rows]
+__host__ __device__ inline size_t fused_lds_bytes(int slab_cells, int H, int max_rows) {
+  return ((size_t)slab_cells + 64 + (size_t)((H + 3) & ~3) + 16 + (size_t)max_rows) * 4 + sizeof(FusedFrames);
 }
 
 // RED: kMin / kMax.  HAS_VALID / LEAN as in k_strip_scatter.  DEFER (LEAN only: no height
@@ -116,6 +125,8 @@ k_strip_fused(FusedArgs a) {
 
   float* aytab = lds + a.slab_stride + 64;
   int* gwin = reinterpret_cast<int*>(aytab + ((a.H + 3) & ~3));     // {x0 | z0 << 16, w | h << 16, inside, ok}
+  uint32_t* rowspan = reinterpret_cast<uint32_t*>(gwin + 16);       // [max_rows]
+  FusedFrames* frames_lds = reinterpret_cast<FusedFrames*>(rowspan + a.max_rows);
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = (int)threadIdx.x & 63;
   typedef const __attribute__((address_space(4))) float cfloat;
@@ -148,6 +159,16 @@ k_strip_fused(FusedArgs a) {
     const Win16 ww = window_of(c, lx, hx, lz, hz, p.slack, in);
     const bool on = live & (p.ok != 0);
     const bool some = on & (ww.w > 0);
+    {   // the frame's cone edges for this strip (strip::cfg_rig's tmin / tmax, strip::strip_geometry's edges)
+      const float t0 = ax_lo / a.g0, t1 = ax_lo / a.g1, t2 = ax_hi / a.g0, t3 = ax_hi / a.g1;
+      const float tmin = fmin2(fmin2(t0, t1), fmin2(t2, t3)), tmax = fmax2(fmax2(t0, t1), fmax2(t2, t3));
+      const Line l = cone_edge(c, p, tmin, true), r = cone_edge(c, p, tmax, false);
+      if (k == 0 && (lane >> 3) < nf) {
+        frames_lds->win[lane >> 3] = some ? ww : Win16{0, 0, 0, 0};
+        frames_lds->L[lane >> 3] = some ? l : Line{0.0f, 0.0f, 0.0f, 0.0f};
+        frames_lds->R[lane >> 3] = some ? r : Line{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+    }
     int x0 = 32767, x1 = 0, z0 = 32767, z1 = 0, all_in = 1, all_ok = 1;
     for (int f = 0; f < nf; ++f) {           // (wave-uniform: the frames' results out of lanes 8 f)
       const int s_ = __builtin_amdgcn_readlane((int)some, 8 * f);
@@ -188,7 +209,7 @@ k_strip_fused(FusedArgs a) {
   // a group whose window does not fit what the host sized the launch for (cannot happen: the host
   // bounds the group's window from these very poses), or a frame the cone model does not hold
   // for: flagged, nothing projected
-  const bool fits = __builtin_amdgcn_readfirstlane(gwin[3]) != 0 && w.w * w.h <= a.slab_stride;
+  const bool fits = __builtin_amdgcn_readfirstlane(gwin[3]) != 0 && w.w * w.h <= a.slab_stride && w.h <= a.max_rows;
   if (!fits) {
     if (threadIdx.x == 0 && a.status && (w.w > 0 || !__builtin_amdgcn_readfirstlane(gwin[3])))
       __hip_atomic_store(a.status, kStatusFrameDidNotFit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -351,13 +372,43 @@ k_strip_fused(FusedArgs a) {
     __builtin_amdgcn_s_setprio(0);
   };
   if (inside) pipeline(std::false_type{}); else pipeline(std::true_type{});
+  // The rows' spans: on map row z the group's pixels can only land between its frames' cone edges
+  // (strip::row_cover, the cover of k_strip_scatter's strips) -- a fraction of the window's
+  // bounding box, which is all the slab has to hold and all k_fuse_windows has to visit.  Eight
+  // lanes per row, lane = frame (a group's last frame repeated), the hull over the frames by DPP
+  // moves; a wave does this as soon as it leaves the pixel loop, under the slower waves' last
+  // rows.  (Inside its frame's window by construction: the window's x range is a multiple of 4.)
+  {
+    const int fq = min(lane & 7, nf - 1);
+    const Win16 fw = frames_lds->win[fq];
+    const strip::Line fl = frames_lds->L[fq], fr = frames_lds->R[fq];
+    uint32_t* const gspans = a.spans + ((size_t)group * a.P + part) * a.max_rows;
+    for (int r0 = 0; r0 < w.h; r0 += kScatterThreads / 8) {       // (uniform trips: the DPP moves)
+      const int r = r0 + ((int)threadIdx.x >> 3);
+      const uint32_t cov = r < w.h ? strip::row_cover(fw, fl, fr, w.z0 + r, a.mw) : 0u;
+      int lo = cov ? (int)(cov & 0xffffu) : 32767, hi = (int)(cov >> 16);
+      lo = min(lo, dpp_i<0xB1>(lo)); lo = min(lo, dpp_i<0x4E>(lo)); lo = min(lo, dpp_i<0x141>(lo));
+      hi = max(hi, dpp_i<0xB1>(hi)); hi = max(hi, dpp_i<0x4E>(hi)); hi = max(hi, dpp_i<0x141>(hi));
+      if ((lane & 7) == 0 && r < w.h) {
+        const uint32_t span = hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
+        rowspan[r] = span;
+        if (ch == 0) gspans[r] = span;
+      }
+    }
+  }
   lds_barrier();
-  // flush: the whole window -> the workgroup's slab (coalesced 16-byte stores)
+  // flush: the spans of the window's rows -> the workgroup's slab, 16 lanes per row
   float* slab = a.slabs + (((size_t)group * a.dc + ch) * a.P + part) * a.slab_stride;
-  for (int i = threadIdx.x * 4; i < area; i += kScatterThreads * 4) {
-    float4 v = *reinterpret_cast<const float4*>(lds + i);
-    if (DEFER) { v.x += a.cam_h; v.y += a.cam_h; v.z += a.cam_h; v.w += a.cam_h; }
-    *reinterpret_cast<float4*>(slab + i) = v;
+  const int l16 = (int)threadIdx.x & 15;
+  for (int row = (int)threadIdx.x >> 4; row < w.h; row += kScatterThreads / 16) {
+    const uint32_t span = rowspan[row];
+    const int lo = (int)(span & 0xffffu), hi = (int)(span >> 16);
+    const int cell0 = row * w.w - w.x0;
+    for (int x = lo + (l16 << 2); x < hi; x += 64) {
+      float4 v = *reinterpret_cast<const float4*>(lds + cell0 + x);
+      if (DEFER) { v.x += a.cam_h; v.y += a.cam_h; v.z += a.cam_h; v.w += a.cam_h; }
+      *reinterpret_cast<float4*>(slab + cell0 + x) = v;
+    }
   }
 }
 

@@ -257,6 +257,7 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
       fa.accumulate = accumulate; fa.fill = fill;
       fa.gx0 = st.gx0; fa.gz0 = st.gz0; fa.gx1 = st.gx1; fa.gz1 = st.gz1;
       fa.wins = st.g_wins; fa.slabs = slabs; fa.fused = fused; fa.fused_mask = fused_mask;
+      fa.spans = nullptr; fa.span_rows = 0;        // (whole window rows in the slabs)
       const int bw4 = (st.gx1 - st.gx0) / 4;
       const int heavy = st.gx1 > st.gx0 ? ((bw4 + kFuseGroups - 1) / kFuseGroups) * (st.gz1 - st.gz0) : 0;
       const int per_fill_block = kFuseGroups * kFuseLanes * 8;

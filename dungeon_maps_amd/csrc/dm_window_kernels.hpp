@@ -753,6 +753,8 @@ struct FuseWinArgs {
   const float* slabs;         // ((b * oc + chl) * nparts + p) * slab_stride
   float* fused;               // (oc_total, mh, mw)
   uint8_t* fused_mask;
+  const uint32_t* spans;      // (windows, span_rows) lo | hi << 16: the cells of each window row that its slab holds
+  int span_rows;              //   (k_strip_fused flushes only those), or NULL: whole rows
 };
 
 constexpr int kFuseChunk = 1024;    // windows examined per candidate-list round
@@ -761,7 +763,7 @@ template <bool IS_MAX>
 __global__ void __launch_bounds__(kFuseGroups * kFuseLanes)
 k_fuse_windows(FuseWinArgs a) {
   __shared__ float4 part[kFuseLanes][kFuseGroups];
-  __shared__ int4 cwin[kFuseChunk];     // candidate windows {x0, z0, w, h} ...
+  __shared__ int4 cwin[kFuseChunk];     // candidate windows {x0, row of the window on the block's map row, w, span lo | hi << 16} ...
   __shared__ int cslab[kFuseChunk];     // ... and their slab index
   __shared__ int ncand;
   const int chl = blockIdx.y, ch = a.ch0 + chl;
@@ -821,9 +823,15 @@ k_fuse_windows(FuseWinArgs a) {
       const int r = r0 + (int)threadIdx.x;
       bool hit = false;
       Window w = {0, 0, 0, 0};
+      uint32_t span = 0u;
       if (r < a.nwin && r < c0 + kFuseChunk) {
         w = widen(a.wins[(size_t)a.b0 * a.nparts + r]);
         hit = w.w > 0 && w.z0 <= z_hi && w.z0 + w.h > z_lo && w.x0 < x_hi && w.x0 + w.w > x_lo;
+        span = (uint32_t)w.x0 | ((uint32_t)(w.x0 + w.w) << 16);
+        if (hit && a.spans) {      // (the block's cells all lie on map row z)
+          span = a.spans[((size_t)a.b0 * a.nparts + r) * a.span_rows + (z - w.z0)];
+          hit = (int)(span & 0xffffu) < x_hi && (int)(span >> 16) > x_lo;
+        }
       }
       const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit);
       if (hits != 0ull) {
@@ -833,7 +841,7 @@ k_fuse_windows(FuseWinArgs a) {
         if (hit) {
           const int slot = base + __builtin_popcountll(hits & ((1ull << wlane) - 1ull));
           const int b = r / a.nparts, p = r - b * a.nparts;
-          cwin[slot] = make_int4(w.x0, w.z0, w.w, w.h);
+          cwin[slot] = make_int4(w.x0, z - w.z0, w.w, (int)span);
           cslab[slot] = ((a.b0 + b) * a.oc + chl) * a.nparts + p;
         }
       }
@@ -849,10 +857,9 @@ k_fuse_windows(FuseWinArgs a) {
         v[k] = acc;
         if (i < n) {
           const int4 w = cwin[i];
-          const unsigned ux = (unsigned)(x - w.x), uz = (unsigned)(z - w.y);
-          if (ux < (unsigned)w.z && uz < (unsigned)w.w)
+          if (x >= (int)((unsigned)w.w & 0xffffu) && x < (int)((unsigned)w.w >> 16))
             v[k] = *reinterpret_cast<const float4*>(
-                a.slabs + (size_t)cslab[i] * a.slab_stride + (size_t)uz * w.z + ux);
+                a.slabs + (size_t)cslab[i] * a.slab_stride + (size_t)w.y * w.z + (x - w.x));
         }
       }
 #pragma unroll

@@ -638,6 +638,28 @@ hipError_t run_window_fused(const dm_params& p, const dm_frame* frames_host, con
   Staged st;
   size_t slab_bytes = 0;
   hipError_t e = stage_windows(p, frames_host, ws, ws_bytes, st, slab_bytes, s, nullptr);
+  if (e == hipErrorOutOfMemory) {
+    // The slabs of all frames do not fit the workspace (many parts of large windows): the fuse is
+    // a max / min, so the frames go through in two halves, the second one folding into the map
+    // the first one left.  (Found by the fused parity campaign: B = 65 frames of 70x50 pixels
+    // used to fail with "out of memory" here.)
+    if (p.B < 2) return hipErrorNotSupported;
+    dm_params q = p;
+    q.B = p.B / 2;
+    const size_t n = (size_t)p.H * p.W, h = q.B;
+    e = run_window_fused(q, frames_host, depth, value, valid, out, mask, accumulate, ws, ws_bytes, s);
+    if (e != hipSuccess) return e;       // (nothing was enqueued when the first half does not apply)
+    q.B = p.B - (int)h;
+    const float* depth2 = depth + h * p.dc * n;
+    const float* value2 = value ? value + h * p.vc * n : nullptr;
+    const uint8_t* valid2 = valid ? valid + h * p.valid_c * n : nullptr;
+    e = run_window_fused(q, frames_host + h, depth2, value2, valid2, out, mask, 1, ws, ws_bytes, s);
+    // (a second half this path refuses -- its split is chosen for its own frame count -- folds in
+    // through the generic path: the caller must not start over on a half-built map)
+    if (e == hipErrorNotSupported)
+      e = run_generic_fused(q, frames_host + h, depth2, value2, valid2, out, mask, 1, ws, s);
+    return e;
+  }
   if (e != hipSuccess) return e;
   return window_pass(p, st, reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + st.geom_bytes),
                      depth, value, valid, nullptr, nullptr,

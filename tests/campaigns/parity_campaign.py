@@ -37,7 +37,7 @@ def one(seed):
     depth.reshape(-1)[idx] = np.resize(np.array([np.nan, np.inf, -np.inf, 0.0, -1.0, 1e30], np.float32), 12)
   pose = np.stack([rng.uniform(-2, 2, B), rng.uniform(-2, 2, B), rng.uniform(-np.pi, np.pi, B)],
                   axis=1).astype(np.float32)
-  per_frame = bool(rng.integers(2)) and not ONE_PITCH
+  per_frame = bool(rng.integers(2)) and not ONE_PITCH and not FUSED
   pitch = rng.uniform(-0.9, 0.5, size=B if per_frame else 1).astype(np.float32)
   camh = rng.uniform(0.2, 2.0, size=B if per_frame else 1).astype(np.float32)
   is_max = bool(rng.integers(4))
@@ -62,7 +62,7 @@ def one(seed):
   if SUM:       # point counts per class: small integers, exact in float32 whatever the order
     cfg["reduction"] = "mean" if os.environ.get("DM_CAMPAIGN_SUM") == "mean" else "sum"
     cfg["fill_value"] = float(rng.choice([0.0, 1.0, 5.0]))
-  C = int(rng.choice([0, 0, 3, 9])) if SEMANTIC else 0
+  C = int(rng.choice([0, 0, 3, 9])) if SEMANTIC and not FUSED else 0
   if SUM:
     C = 3
   if C and B * C * H * W <= 6_000_000:      # value maps: one-hot labels or random reals
@@ -72,6 +72,28 @@ def one(seed):
       value = rng.normal(size=(B, C, H, W)).astype(np.float32)
   proj = dmap.MapProjector(**cfg)
   get_h = value is not None
+  if FUSED:      # dm_orth_project_fused_f32: every frame into ONE map, strips x frame groups forced at random
+    if rng.integers(2):      # a trajectory (frame groups then share a window), else unrelated poses
+      k = np.arange(B, dtype=np.float32)
+      pose = np.stack([pose[0, 0] + 0.02 * k, pose[0, 1] + 0.01 * k, pose[0, 2] + 0.01 * k], axis=1).astype(np.float32)
+    LIB.dm_debug_force_fused_split(int(rng.choice([0, 16, 20, 40, 80, 160])), int(rng.choice([0, 1, 2, 4, 8])))
+    try:
+      fo, fm = proj.orth_project_fused(torch.from_numpy(depth).cuda(),
+                                       valid_map=None if valid is None else torch.from_numpy(valid).cuda(),
+                                       cam_pose=pose)
+    finally:
+      LIB.dm_debug_force_fused_split(0, 0)
+    split = (ctypes.c_int32 * 4)()
+    LIB.dm_debug_last_fused_split(split)
+    STATS["strip"] += split[1] > 0
+    kw = dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose)
+    want = oracle.orth_project(depth, value_map=None, valid_map=valid, get_height_map=False, nthreads=16, **kw)
+    wf = want[0].max(axis=0) if cfg["reduction"] == "max" else want[0].min(axis=0)
+    wm = want[1].any(axis=0)
+    gf, gm = fo.cpu().numpy(), fm.cpu().numpy()
+    bad_m = int((gm != wm).sum())
+    bad_v = int((~((gf == wf) | (np.isnan(gf) & np.isnan(wf)))).sum())
+    return bad_m, bad_v, (B, H, W, mh, mw, res, tuple(split))
   if ONE_PITCH:      # any number of column strips, whatever the cost model says (the strip path's own hook)
     LIB.dm_debug_force_strips(int(rng.integers(0, 9)))
   outs = proj.orth_project(torch.from_numpy(depth).cuda(),
@@ -111,6 +133,7 @@ ODD = os.environ.get("DM_CAMPAIGN_ODD", "0") != "0"      # odd map widths
 SUM = os.environ.get("DM_CAMPAIGN_SUM", "0") != "0"      # reduction='sum' of one-hot values
 FINE = os.environ.get("DM_CAMPAIGN_FINE", "0") != "0"    # fine map_res: depth bands (forced)
 ONE_PITCH = os.environ.get("DM_CAMPAIGN_ONE_PITCH", "0") != "0"   # one pitch per batch + forced strips: the strip path
+FUSED = os.environ.get("DM_CAMPAIGN_FUSED", "0") != "0"    # orth_project_fused (one map for the whole batch), forced strips x frame groups
 STATS = {"banded": 0, "generic": 0, "strip": 0}
 from dungeon_maps_amd import _native
 LIB = _native.lib()
@@ -121,7 +144,11 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 bad = 0
 for s in range(first, first + count):
-  bm, bv, shape = one(s)
+  try:
+    bm, bv, shape = one(s)
+  except Exception:
+    print("EXCEPTION at seed", s, flush=True)
+    raise
   if bm or bv:
     bad += 1
     print("MISMATCH seed", s, shape, "mask cells", bm, "map cells", bv, flush=True)

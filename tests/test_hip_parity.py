@@ -236,6 +236,37 @@ def test_cpu_tensors_round_trip_through_gpu(dmap, oracle):
   np.testing.assert_array_equal(top.numpy(), want[0])
 
 
+@pytest.mark.parametrize("B", [65, 129])
+def test_fused_projection_of_more_frames_than_the_slab_workspace_holds(dmap, oracle, B):
+  """dm_orth_project_fused_f32 on the window path (70 pixel columns: no column strips) with one
+  frame more than the workspace holds slabs for: the frames go through in halves, the second
+  half folding into the map of the first.  (B = 65 used to fail with "HIP launch failed: out
+  of memory": found by tests/campaigns/parity_campaign.py in its fused mode.)"""
+  rng = np.random.default_rng(B)
+  H, W = 50, 70
+  depth = rng.uniform(0.1, 8.0, size=(B, 1, H, W)).astype(np.float32)
+  pose = np.stack([rng.uniform(-2, 2, B), rng.uniform(-2, 2, B), rng.uniform(-3, 3, B)], axis=1).astype(np.float32)
+  cfg = dict(width=W, height=H, hfov=0.947, cam_pitch=-0.3, cam_height=0.9, width_offset=128.,
+             height_offset=128., map_res=0.02, map_width=256, map_height=256, trunc_depth_min=0.5,
+             trunc_depth_max=5.05, to_global=True, flip_h=False, fill_value=-np.inf)
+  proj = dmap.MapProjector(**cfg)
+  fused, fmask = proj.orth_project_fused(torch.from_numpy(depth).cuda(), cam_pose=pose)
+  torch.cuda.synchronize()
+  want = oracle.orth_project(depth, fused=True, nthreads=8,
+                             **dict(_oracle_kwargs(oracle, cfg), cam_pose=pose))
+  np.testing.assert_array_equal(fmask.cpu().numpy(), want[1])
+  np.testing.assert_array_equal(fused.cpu().numpy(), want[0])
+  # ... and into a running map (accumulate) with min / a finite fill value
+  cfg2 = dict(cfg, fill_value=3.0, reduction="min")
+  proj2 = dmap.MapProjector(**cfg2)
+  acc, _ = proj2.orth_project_fused(torch.from_numpy(depth[:5]).cuda(), cam_pose=pose[:5])
+  acc, amask = proj2.orth_project_fused(torch.from_numpy(depth[5:]).cuda(), cam_pose=pose[5:], out=acc)
+  want2 = oracle.orth_project(depth, fused=True, nthreads=8,
+                              **dict(_oracle_kwargs(oracle, cfg2), cam_pose=pose))
+  np.testing.assert_array_equal(amask.cpu().numpy(), want2[1])
+  np.testing.assert_array_equal(acc.cpu().numpy(), want2[0])
+
+
 def test_fused_equals_max_over_frames(dmap, oracle):
   B, H, W = 6, 96, 128
   depth, pose = _synthetic(B, H, W, seed=77)

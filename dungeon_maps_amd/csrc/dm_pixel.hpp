@@ -15,6 +15,25 @@
 
 namespace dm {
 
+// buffer_store_dwordx4 with the scalar offset in an SGPR (the fill duty's addressing form).  The
+// memory pipeline reads a store's data registers for a few cycles AFTER the instruction has
+// issued; for stores of more than 8 bytes the compiler's hazard recogniser covers that with wait
+// states in front of a vector instruction that overwrites them -- except for buffer stores whose
+// scalar-offset field holds a register, which it takes to be free of the hazard.  On gfx950 they
+// are not: with the four copies of the fill value reloaded from a spill into registers that the
+// very next instruction reused (v_cvt_f32_i32 of an image row), the first dword of the store came
+// out as that row number in lanes 12-15 and 28-31 -- reduction='mean' on the window path, found
+// by the parity campaign's mean mode (tests/campaigns/parity_campaign.py).  So: the data stays an
+// input of two wait states behind the store, which keeps its registers unmodified until then.
+#ifdef __HIPCC__
+template <class V4>
+__device__ inline void buffer_store_b128_at_scalar_offset(V4 data, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+  __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voffset, soffset, 0);
+  asm volatile("s_nop 1" :: "v"(data));
+}
+#endif
+
+
 // Call-wide constants in the form the kernels consume them.
 struct View {
   int H, W, mh, mw;

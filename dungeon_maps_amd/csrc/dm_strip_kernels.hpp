@@ -659,8 +659,8 @@ k_strip_scatter(StripArgs a) {
     // (the scalar offset must be the same in every lane, skipping or not: a lane-dependent one
     // costs a waterfall loop per store)
     const int cell0 = __builtin_amdgcn_readfirstlane(live ? f_row * la->mw + (f_chunk << 8) : 0);
-    __builtin_amdgcn_raw_buffer_store_b128((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out,
-                                           skip ? 0x7ffffff0 : lane4 << 2, cell0 << 2, 0);
+    buffer_store_b128_at_scalar_offset((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out,
+                                       skip ? 0x7ffffff0 : lane4 << 2, cell0 << 2);
     __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, skip ? 0x7ffffff0 : lane4, cell0, 0);
     ++fs;
     advance(f_row, f_chunk);

@@ -248,8 +248,8 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
     const bool skip = !live | (x >= a.mw) | (in_rows & ((unsigned)(x - U.x0) < (unsigned)U.w));
     // (the scalar offset must be the same in every lane, skipping or not)
     const int cell0 = __builtin_amdgcn_readfirstlane(live ? f_row * a.mw + (f_chunk << 8) : 0);
-    __builtin_amdgcn_raw_buffer_store_b128((fill_u32x4){f_bits, f_bits, f_bits, f_bits}, rs_fill_out,
-                                           skip ? 0x7ffffff0 : f_lane4 << 2, cell0 << 2, 0);
+    buffer_store_b128_at_scalar_offset((fill_u32x4){f_bits, f_bits, f_bits, f_bits}, rs_fill_out,
+                                       skip ? 0x7ffffff0 : f_lane4 << 2, cell0 << 2);
     __builtin_amdgcn_raw_buffer_store_b32(0u, rs_fill_mask, skip ? 0x7ffffff0 : f_lane4, cell0, 0);
     ++fs;
     const bool next_row = f_chunk + 1 == f_chunks;

@@ -236,6 +236,36 @@ def test_cpu_tensors_round_trip_through_gpu(dmap, oracle):
   np.testing.assert_array_equal(top.numpy(), want[0])
 
 
+def test_mean_of_one_hot_value_maps_on_the_window_path(dmap, oracle):
+  """reduction='mean' of a 3-class one-hot value map, 9 frames, border clipped, no far truncation
+  (the window path's kernel variant that runs short of registers): equal to the oracle, cell
+  for cell, three times in a row.  This is seed 1401484 of the parity campaign's mean mode, which
+  came out with the image-row number in the first cell of some float4 groups of the FILL region:
+  a buffer_store_dwordx4 with its scalar offset in a register, followed at once by an instruction
+  that overwrites its data registers (dm_pixel.hpp buffer_store_b128_at_scalar_offset)."""
+  rng = np.random.default_rng(50_000 + 1401484)
+  B, H, W, mh, mw, C = 9, 48, 64, 96, 128, 3
+  depth = rng.uniform(0.1, 8.0, size=(B, 1, H, W)).astype(np.float32)
+  pose = np.stack([rng.uniform(-2, 2, B), rng.uniform(-2, 2, B), rng.uniform(-np.pi, np.pi, B)],
+                  axis=1).astype(np.float32)
+  value = np.eye(C, dtype=np.float32)[rng.integers(0, C, size=(B, H, W))].transpose(0, 3, 1, 2).copy()
+  cfg = dict(width=W, height=H, hfov=1.7576597295876581, vfov=None,
+             cam_pitch=rng.uniform(-0.9, 0.5, size=B).astype(np.float32),
+             cam_height=rng.uniform(0.2, 2.0, size=B).astype(np.float32),
+             width_offset=29.19671036767047, height_offset=79.95770080230739, map_res=0.0625,
+             map_width=mw, map_height=mh, trunc_depth_min=0.5, trunc_depth_max=None,
+             trunc_height_max=1.0342564776427254, clip_border=9, to_global=False, flip_h=True,
+             fill_value=1.0, reduction="mean")
+  want = oracle.orth_project(depth, value_map=value, nthreads=8,
+                             **dict(_oracle_kwargs(oracle, cfg), cam_pose=pose))
+  for _ in range(3):
+    # (what the allocator hands out next holds other numbers each time)
+    junk = torch.full((B * C * mh * mw,), 12345.0, device="cuda"); del junk
+    outs = _run(dmap, cfg, depth, value=value, cam_pose=pose)
+    np.testing.assert_array_equal(outs[1], want[1])
+    np.testing.assert_array_equal(outs[0], want[0])
+
+
 @pytest.mark.parametrize("B", [65, 129])
 def test_fused_projection_of_more_frames_than_the_slab_workspace_holds(dmap, oracle, B):
   """dm_orth_project_fused_f32 on the window path (70 pixel columns: no column strips) with one

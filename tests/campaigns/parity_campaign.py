@@ -96,10 +96,29 @@ def one(seed):
     return bad_m, bad_v, (B, H, W, mh, mw, res, tuple(split))
   if ONE_PITCH:      # any number of column strips, whatever the cost model says (the strip path's own hook)
     LIB.dm_debug_force_strips(int(rng.integers(0, 9)))
-  outs = proj.orth_project(torch.from_numpy(depth).cuda(),
-                           value_map=None if value is None else torch.from_numpy(value).cuda(),
-                           valid_map=None if valid is None else torch.from_numpy(valid).cuda(),
-                           cam_pose=pose, get_height_map=get_h)
+  d_dev = torch.from_numpy(depth).cuda()
+  v_dev = None if value is None else torch.from_numpy(value).cuda()
+  m_dev = None if valid is None else torch.from_numpy(valid).cuda()
+  how = int(rng.integers(3)) if CALLS else 0
+  fused_pair = None
+  if how == 1 and cfg["reduction"] in ("max", "min"):      # per-frame maps + the batch-fused map in one call
+    top, msk, fo, fm = proj.orth_project_and_fuse(d_dev, value_map=v_dev, valid_map=m_dev, cam_pose=pose)
+    outs = (top, msk)
+    fused_pair = (fo.cpu().numpy(), fm.cpu().numpy())
+    get_h = False
+  elif how == 2:      # prepared frames (poses in a device buffer), where the strip path takes the call
+    try:
+      prep = proj.prepare(B, cam_pose=pose, value_channels=0 if value is None else value.shape[1],
+                          valid_channels=0 if valid is None else 1)
+    except Exception:
+      prep = None
+    if prep is not None:
+      STATS["prepared"] = STATS.get("prepared", 0) + 1
+      outs = prep.orth_project(d_dev, value_map=v_dev, valid_map=m_dev, get_height_map=get_h)
+    else:
+      outs = proj.orth_project(d_dev, value_map=v_dev, valid_map=m_dev, cam_pose=pose, get_height_map=get_h)
+  else:
+    outs = proj.orth_project(d_dev, value_map=v_dev, valid_map=m_dev, cam_pose=pose, get_height_map=get_h)
   split = (ctypes.c_int32 * 4)()
   LIB.dm_debug_last_split(split)
   STATS["banded"] += split[2] > 1
@@ -111,6 +130,10 @@ def one(seed):
   got = [o.cpu().numpy() for o in outs]
   bad_m = int((got[1] != want[1]).sum())
   bad_v = 0
+  if fused_pair is not None:
+    wf = want[0].max(axis=0) if cfg["reduction"] == "max" else want[0].min(axis=0)
+    bad_m += int((fused_pair[1] != want[1].any(axis=0)).sum())
+    bad_v += int((~((fused_pair[0] == wf) | (np.isnan(fused_pair[0]) & np.isnan(wf)))).sum())
   if os.environ.get("DM_CAMPAIGN_VERBOSE"):
     d = ~((got[0] == want[0]) | (np.isnan(got[0]) & np.isnan(want[0])))
     idx = np.argwhere(d)[:12]
@@ -133,6 +156,7 @@ ODD = os.environ.get("DM_CAMPAIGN_ODD", "0") != "0"      # odd map widths
 SUM = os.environ.get("DM_CAMPAIGN_SUM", "0") != "0"      # reduction='sum' of one-hot values
 FINE = os.environ.get("DM_CAMPAIGN_FINE", "0") != "0"    # fine map_res: depth bands (forced)
 ONE_PITCH = os.environ.get("DM_CAMPAIGN_ONE_PITCH", "0") != "0"   # one pitch per batch + forced strips: the strip path
+CALLS = os.environ.get("DM_CAMPAIGN_CALLS", "0") != "0"    # a third of the calls through orth_project_and_fuse, a third through prepared frames
 FUSED = os.environ.get("DM_CAMPAIGN_FUSED", "0") != "0"    # orth_project_fused (one map for the whole batch), forced strips x frame groups
 STATS = {"banded": 0, "generic": 0, "strip": 0}
 from dungeon_maps_amd import _native
@@ -154,5 +178,6 @@ for s in range(first, first + count):
     print("MISMATCH seed", s, shape, "mask cells", bm, "map cells", bv, flush=True)
   if (s - first) % 50 == 49:
     print("  ... %d configurations, %d with mismatches" % (s - first + 1, bad), flush=True)
-print("done: %d configurations, %d with mismatches (%d took the strip path, %d depth bands, %d the generic path)"
-      % (count, bad, STATS["strip"], STATS["banded"], STATS["generic"]))
+print("done: %d configurations, %d with mismatches (%d took the strip path, %d depth bands, %d the generic path%s)"
+      % (count, bad, STATS["strip"], STATS["banded"], STATS["generic"],
+         ", %d through prepared frames" % STATS["prepared"] if "prepared" in STATS else ""))

@@ -127,10 +127,14 @@ def rotate(points, axis, angle, angle_eps: float = ANGLE_EPS) -> torch.Tensor:
   rot = rotation_matrix(to_tensor(axis, device=points.device),
                         to_tensor(angle, device=points.device), angle_eps)
   b = points.shape[0]
-  flat = points.reshape(b, -1, 3)
   if rot.shape[0] != b:
     rot = rot.expand(b, 3, 3)
-  return torch.bmm(flat, rot).reshape(points.shape)
+  # (the contraction over the FIRST index of R as ONE einsum, the call the reference makes,
+  # utils.py:329: which BLAS kernel torch's CPU matmul picks -- and with it whether the three
+  # products are summed as an FMA chain -- depends on the shape, the call and the machine, so CPU
+  # tensors get the reference's own bits only through the reference's own call.  GPU tensors go
+  # through dm_affine_points_f32, always the FMA chain.)
+  return torch.einsum("bji,b...j->b...i", rot, points)
 
 
 # ------------------------------------------------------------------- indexing

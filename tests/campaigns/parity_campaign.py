@@ -17,7 +17,14 @@ def one(seed):
     B = max(1, 3_000_000 // (H * W))
   if SUM and B * 3 * H * W > 6_000_000:      # always one-hot counts (exact), never height sums
     B = max(1, 6_000_000 // (3 * H * W))
+  if BIG:          # full-size frames: tall union windows, several passes of the row tables, 64-frame launches
+    B = int(rng.choice([1, 2, 3, 8, 16, 33, 64, 70]))
+    H, W = [(240, 320), (480, 640), (360, 480)][int(rng.integers(3))]
+    if B * H * W > 20_000_000:
+      B = max(1, 20_000_000 // (H * W))
   sizes = [(64, 64), (96, 128), (128, 96), (160, 160), (256, 256), (300, 200)]
+  if BIG:
+    sizes = [(256, 256), (512, 512), (384, 640), (640, 384), (512, 256), (768, 768)]
   if ODD:          # map widths that are not multiples of 4: padded maps + copy-out (dm_api.hip)
     sizes = [(65, 63), (97, 131), (128, 241), (255, 255), (301, 199), (100, 102)]
   mh, mw = sizes[int(rng.integers(6))]
@@ -156,6 +163,7 @@ ODD = os.environ.get("DM_CAMPAIGN_ODD", "0") != "0"      # odd map widths
 SUM = os.environ.get("DM_CAMPAIGN_SUM", "0") != "0"      # reduction='sum' of one-hot values
 FINE = os.environ.get("DM_CAMPAIGN_FINE", "0") != "0"    # fine map_res: depth bands (forced)
 ONE_PITCH = os.environ.get("DM_CAMPAIGN_ONE_PITCH", "0") != "0"   # one pitch per batch + forced strips: the strip path
+BIG = os.environ.get("DM_CAMPAIGN_BIG", "0") != "0"        # 240x320 .. 480x640 frames, maps up to 768x768, up to 70 frames
 CALLS = os.environ.get("DM_CAMPAIGN_CALLS", "0") != "0"    # a third of the calls through orth_project_and_fuse, a third through prepared frames
 FUSED = os.environ.get("DM_CAMPAIGN_FUSED", "0") != "0"    # orth_project_fused (one map for the whole batch), forced strips x frame groups
 STATS = {"banded": 0, "generic": 0, "strip": 0}

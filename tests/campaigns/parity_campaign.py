@@ -1,6 +1,22 @@
-"""One-off parity campaign (GPU box): the seeded parameter sweep of
-tests/test_hip_parity.py::test_random_configurations_vs_oracle for many more seeds, plus
-larger frames; prints every mismatch.  Usage: python tests/campaigns/parity_campaign.py [first] [count]"""
+"""Parity campaign (GPU box, builder-run: too long for the test suite): the seeded parameter sweep of
+tests/test_hip_parity.py::test_random_configurations_vs_oracle for many more seeds; the GPU result
+against the CPU oracle, cells and heights bit for bit; prints every mismatch.
+Usage: [MODE=1 ...] python tests/campaigns/parity_campaign.py [first seed] [count]
+
+Modes (environment variables, combinable where it makes sense; results of every run of the round
+in profiles/r03_parity_campaigns.log):
+  DM_CAMPAIGN_ONE_PITCH  one pitch per batch + 0..8 forced column strips: the strip path
+  DM_CAMPAIGN_CALLS      a third of the calls through orth_project_and_fuse (per-frame maps AND the
+                         batch-fused map compared), a third through MapProjector.prepare
+  DM_CAMPAIGN_FUSED      orth_project_fused: every frame into ONE map, strip width x frames per
+                         workgroup forced at random, trajectories and unrelated poses
+  DM_CAMPAIGN_BIG        240x320 .. 480x640 frames, maps up to 768x768, up to 70 frames
+  DM_CAMPAIGN_FINE       fine resolutions on large maps: depth bands (forced)
+  DM_CAMPAIGN_ODD        map widths that are not multiples of 4 (padded maps + copy-out)
+  DM_CAMPAIGN_SUM        =1: reduction 'sum', =mean: reduction 'mean' (one-hot classes: exact;
+                         heights: order-dependent float sums, rtol = atol = 1e-5)
+  DM_CAMPAIGN_SEMANTIC=0 no value maps;  DM_CAMPAIGN_EDGE=0 no NaN / inf depths, no missing truncations
+  DM_CAMPAIGN_VERBOSE    print the configuration and the first differing cells"""
 import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -712,3 +712,62 @@ def test_sum_reduction_on_the_window_path(dmap, oracle, case, red):
   want_h = oracle.orth_project(depth, valid_map=valid, **kw)   # sums of heights on top of a fill
   np.testing.assert_allclose(heights[0], want_h[0], rtol=1e-5, atol=1e-5)
   assert (heights[1] != want_h[1]).mean() < 1e-4
+
+
+def test_three_host_threads_on_their_own_streams(dmap):
+  """Three host threads, each on a stream of its own, make different projection calls at the same
+  time (64 frames of 240x320, a 3-class and a 5-class value map with its height map, a single
+  frame; plain calls and orth_project_and_fuse): every result equals the one the same call gave
+  alone.  (ctypes releases the GIL inside the native call: the library's per-thread plan and
+  bound caches, the shared status word and the per-call kernel arguments are all in play.)"""
+  import threading
+  dev = torch.device("cuda:0")
+
+  def make(seed, B, H, W, mh, mw, C):
+    rng = np.random.default_rng(seed)
+    depth = torch.from_numpy(rng.uniform(0.1, 8.0, size=(B, 1, H, W)).astype(np.float32)).to(dev)
+    pose = torch.from_numpy(np.stack([rng.uniform(-1, 1, B), rng.uniform(-1, 1, B),
+                                      rng.uniform(-3, 3, B)], axis=1).astype(np.float32))
+    value = None
+    if C:
+      value = torch.from_numpy(np.eye(C, dtype=np.float32)[rng.integers(0, C, size=(B, H, W))]
+                               .transpose(0, 3, 1, 2).copy()).to(dev)
+    proj = dmap.MapProjector(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+                             cam_height=0.88, width_offset=mw / 2., height_offset=mh / 2., map_res=0.03,
+                             map_width=mw, map_height=mh, trunc_depth_min=0.15, trunc_depth_max=5.05,
+                             to_global=True, fill_value=0.0 if C else -np.inf)
+    return proj, depth, pose, value
+
+  jobs = [make(1, 64, 240, 320, 256, 256, 0), make(2, 9, 120, 160, 128, 128, 3),
+          make(3, 1, 240, 320, 256, 256, 0), make(4, 33, 96, 128, 160, 160, 5)]
+
+  def run(job, fused):
+    proj, depth, pose, value = job
+    if fused and value is None:
+      return proj.orth_project_and_fuse(depth, cam_pose=pose)
+    return proj.orth_project(depth, value_map=value, cam_pose=pose, get_height_map=value is not None)
+
+  alone = [[t.clone() for t in run(j, f)] for j in jobs for f in (False, True)]
+  torch.cuda.synchronize()
+  errors = []
+
+  def worker(tid):
+    stream = torch.cuda.Stream()
+    try:
+      with torch.cuda.stream(stream):
+        for it in range(40):
+          k = (it * 3 + tid) % len(alone)
+          out = run(jobs[k // 2], bool(k % 2))
+          stream.synchronize()
+          if not all(torch.equal(a, b) for a, b in zip(out, alone[k])):
+            errors.append((tid, it, k))
+            return
+    except Exception as e:      # (a thread's exception would otherwise be lost)
+      errors.append((tid, repr(e)))
+
+  threads = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join()
+  assert not errors, errors

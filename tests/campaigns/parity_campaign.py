@@ -15,6 +15,7 @@ in profiles/r03_parity_campaigns.log):
   DM_CAMPAIGN_ODD        map widths that are not multiples of 4 (padded maps + copy-out)
   DM_CAMPAIGN_SUM        =1: reduction 'sum', =mean: reduction 'mean' (one-hot classes: exact;
                          heights: order-dependent float sums, rtol = atol = 1e-5)
+  DM_CAMPAIGN_DC         depth maps of two or three channels (one map channel each), valid maps shared or per channel
   DM_CAMPAIGN_SEMANTIC=0 no value maps;  DM_CAMPAIGN_EDGE=0 no NaN / inf depths, no missing truncations
   DM_CAMPAIGN_VERBOSE    print the configuration and the first differing cells"""
 import ctypes, os, sys
@@ -81,11 +82,17 @@ def one(seed):
              fill_value=(-np.inf if is_max else np.inf) if rng.integers(3) else float(rng.uniform(-1, 1)),
              reduction="max" if is_max else "min")
   valid = (rng.uniform(size=(B, 1, H, W)) > 0.1) if rng.integers(3) == 0 else None
+  if DC:         # two or three depth channels, each projected into its own map channel; valid map per channel or shared
+    dcs = int(rng.integers(2, 4))
+    depth = np.concatenate([depth] + [rng.uniform(0.1, 8.0, size=(B, 1, H, W)).astype(np.float32)
+                                      for _ in range(dcs - 1)], axis=1)
+    if valid is not None and rng.integers(2):
+      valid = rng.uniform(size=(B, dcs, H, W)) > 0.1
   value = None
   if SUM:       # point counts per class: small integers, exact in float32 whatever the order
     cfg["reduction"] = "mean" if os.environ.get("DM_CAMPAIGN_SUM") == "mean" else "sum"
     cfg["fill_value"] = float(rng.choice([0.0, 1.0, 5.0]))
-  C = int(rng.choice([0, 0, 3, 9])) if SEMANTIC and not FUSED else 0
+  C = int(rng.choice([0, 0, 3, 9])) if SEMANTIC and not FUSED and not DC else 0
   if SUM:
     C = 3
   if C and B * C * H * W <= 6_000_000:      # value maps: one-hot labels or random reals
@@ -132,7 +139,8 @@ def one(seed):
   elif how == 2:      # prepared frames (poses in a device buffer), where the strip path takes the call
     try:
       prep = proj.prepare(B, cam_pose=pose, value_channels=0 if value is None else value.shape[1],
-                          valid_channels=0 if valid is None else 1)
+                          valid_channels=0 if valid is None else valid.shape[1],
+                          depth_channels=depth.shape[1])
     except Exception:
       prep = None
     if prep is not None:
@@ -179,6 +187,7 @@ ODD = os.environ.get("DM_CAMPAIGN_ODD", "0") != "0"      # odd map widths
 SUM = os.environ.get("DM_CAMPAIGN_SUM", "0") != "0"      # reduction='sum' of one-hot values
 FINE = os.environ.get("DM_CAMPAIGN_FINE", "0") != "0"    # fine map_res: depth bands (forced)
 ONE_PITCH = os.environ.get("DM_CAMPAIGN_ONE_PITCH", "0") != "0"   # one pitch per batch + forced strips: the strip path
+DC = os.environ.get("DM_CAMPAIGN_DC", "0") != "0"          # depth maps of two or three channels
 BIG = os.environ.get("DM_CAMPAIGN_BIG", "0") != "0"        # 240x320 .. 480x640 frames, maps up to 768x768, up to 70 frames
 CALLS = os.environ.get("DM_CAMPAIGN_CALLS", "0") != "0"    # a third of the calls through orth_project_and_fuse, a third through prepared frames
 FUSED = os.environ.get("DM_CAMPAIGN_FUSED", "0") != "0"    # orth_project_fused (one map for the whole batch), forced strips x frame groups

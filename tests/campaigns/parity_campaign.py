@@ -15,6 +15,7 @@ in profiles/r03_parity_campaigns.log):
   DM_CAMPAIGN_ODD        map widths that are not multiples of 4 (padded maps + copy-out)
   DM_CAMPAIGN_SUM        =1: reduction 'sum', =mean: reduction 'mean' (one-hot classes: exact;
                          heights: order-dependent float sums, rtol = atol = 1e-5)
+  DM_CAMPAIGN_OFFSETS    one map offset and one camera height per frame
   DM_CAMPAIGN_DC         depth maps of two or three channels (one map channel each), valid maps shared or per channel
   DM_CAMPAIGN_SEMANTIC=0 no value maps;  DM_CAMPAIGN_EDGE=0 no NaN / inf depths, no missing truncations
   DM_CAMPAIGN_VERBOSE    print the configuration and the first differing cells"""
@@ -81,6 +82,10 @@ def one(seed):
              to_global=bool(rng.integers(2)), flip_h=bool(rng.integers(4)),
              fill_value=(-np.inf if is_max else np.inf) if rng.integers(3) else float(rng.uniform(-1, 1)),
              reduction="max" if is_max else "min")
+  if OFFSETS:    # one map offset per frame (what MapBuilder's centre modes produce), camera heights per frame
+    cfg["width_offset"] = (mw / 2 + rng.uniform(-40, 40, size=B)).astype(np.float32)
+    cfg["height_offset"] = (mh / 2 + rng.uniform(-40, 40, size=B)).astype(np.float32)
+    cfg["cam_height"] = rng.uniform(0.2, 2.0, size=B).astype(np.float32)
   valid = (rng.uniform(size=(B, 1, H, W)) > 0.1) if rng.integers(3) == 0 else None
   if DC:         # two or three depth channels, each projected into its own map channel; valid map per channel or shared
     dcs = int(rng.integers(2, 4))
@@ -187,6 +192,7 @@ ODD = os.environ.get("DM_CAMPAIGN_ODD", "0") != "0"      # odd map widths
 SUM = os.environ.get("DM_CAMPAIGN_SUM", "0") != "0"      # reduction='sum' of one-hot values
 FINE = os.environ.get("DM_CAMPAIGN_FINE", "0") != "0"    # fine map_res: depth bands (forced)
 ONE_PITCH = os.environ.get("DM_CAMPAIGN_ONE_PITCH", "0") != "0"   # one pitch per batch + forced strips: the strip path
+OFFSETS = os.environ.get("DM_CAMPAIGN_OFFSETS", "0") != "0"    # per-frame map offsets and camera heights
 DC = os.environ.get("DM_CAMPAIGN_DC", "0") != "0"          # depth maps of two or three channels
 BIG = os.environ.get("DM_CAMPAIGN_BIG", "0") != "0"        # 240x320 .. 480x640 frames, maps up to 768x768, up to 70 frames
 CALLS = os.environ.get("DM_CAMPAIGN_CALLS", "0") != "0"    # a third of the calls through orth_project_and_fuse, a third through prepared frames

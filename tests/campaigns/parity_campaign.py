@@ -13,7 +13,7 @@ in profiles/r03_parity_campaigns.log):
   DM_CAMPAIGN_BIG        240x320 .. 480x640 frames, maps up to 768x768, up to 70 frames
   DM_CAMPAIGN_FINE       fine resolutions on large maps: depth bands (forced)
   DM_CAMPAIGN_ODD        map widths that are not multiples of 4 (padded maps + copy-out)
-  DM_CAMPAIGN_SUM        =1: reduction 'sum', =mean: reduction 'mean' (one-hot classes: exact;
+  DM_CAMPAIGN_SUM        =1: reduction 'sum', =mean: reduction 'mean', =prod: 'prod' (one-hot classes: exact;
                          heights: order-dependent float sums, rtol = atol = 1e-5)
   DM_CAMPAIGN_OFFSETS    one map offset and one camera height per frame
   DM_CAMPAIGN_DC         depth maps of two or three channels (one map channel each), valid maps shared or per channel
@@ -95,9 +95,11 @@ def one(seed):
       valid = rng.uniform(size=(B, dcs, H, W)) > 0.1
   value = None
   if SUM:       # point counts per class: small integers, exact in float32 whatever the order
-    cfg["reduction"] = "mean" if os.environ.get("DM_CAMPAIGN_SUM") == "mean" else "sum"
+    cfg["reduction"] = os.environ["DM_CAMPAIGN_SUM"] if os.environ["DM_CAMPAIGN_SUM"] in ("mean", "prod") else "sum"
     cfg["fill_value"] = float(rng.choice([0.0, 1.0, 5.0]))
   C = int(rng.choice([0, 0, 3, 9])) if SEMANTIC and not FUSED and not DC else 0
+  if DC and SEMANTIC and not FUSED and not SUM and rng.integers(2):
+    C = depth.shape[1]           # a value channel per depth channel (dc == vc: every channel its own cells)
   if SUM:
     C = 3
   if C and B * C * H * W <= 6_000_000:      # value maps: one-hot labels or random reals

@@ -26,9 +26,20 @@ namespace dm {
 // by the parity campaign's mean mode (tests/campaigns/parity_campaign.py).  So: the data stays an
 // input of two wait states behind the store, which keeps its registers unmodified until then.
 #ifdef __HIPCC__
+// Cache policy of the fill duties' stores: nt (non-temporal, bit 1 of the cache-policy operand).  The
+// fill value is write-once data nobody reads back soon -- most of every output map -- and kept out
+// of the caches it stops evicting what IS read again: the pixel lists of the value pass, the cells
+// the batch fuse reads.  Measured (bench.py, same box, default policy -> nt): cfg2 step 55.3 ->
+// 52.8 us (1.16 -> 1.21 M frames/s), cfg3 launch 1 700 -> 1 578 us, cfg5 (335 MB of fill per
+// launch, more than the Infinity Cache holds) 105 -> 83 us; the back-to-back cfg2 launch figure,
+// whose 84 MB of output the Infinity Cache otherwise absorbs call after call, 41.5 -> 42.3 us.
+// (sc1 alone -- written through -- changes nothing; sc0 / sc1 on top of nt neither.  The mask
+// bytes that go with the fill value keep the default policy: four bytes per lane want the L2's write
+// combining -- nt on them too: cfg5 81 -> 90 us, cfg3 1 590 -> 1 610 us.)
+constexpr int kFillCachePolicy = 2;
 template <class V4>
 __device__ inline void buffer_store_b128_at_scalar_offset(V4 data, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
-  __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voffset, soffset, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voffset, soffset, kFillCachePolicy);
   asm volatile("s_nop 1" :: "v"(data));
 }
 #endif

@@ -33,13 +33,17 @@ namespace dm {
 // 52.8 us (1.16 -> 1.21 M frames/s), cfg3 launch 1 700 -> 1 578 us, cfg5 (335 MB of fill per
 // launch, more than the Infinity Cache holds) 105 -> 83 us; the back-to-back cfg2 launch figure,
 // whose 84 MB of output the Infinity Cache otherwise absorbs call after call, 41.5 -> 42.3 us.
+// So the strip path's projection kernel comes in both policies (NT_FILL) and the host picks: nt where
+// the call's own batch fuse follows (it reads the flushed cells, never the fill) or where the output
+// is larger than the Infinity Cache could keep anyway (dm_strip.hip nt_fill_pays); the default
+// policy for a plain call whose maps fit the cache, where whoever reads them next finds them there.
 // (sc1 alone -- written through -- changes nothing; sc0 / sc1 on top of nt neither.  The mask
 // bytes that go with the fill value keep the default policy: four bytes per lane want the L2's write
 // combining -- nt on them too: cfg5 81 -> 90 us, cfg3 1 590 -> 1 610 us.)
 constexpr int kFillCachePolicy = 2;
-template <class V4>
+template <int POLICY = kFillCachePolicy, class V4>
 __device__ inline void buffer_store_b128_at_scalar_offset(V4 data, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
-  __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voffset, soffset, kFillCachePolicy);
+  __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voffset, soffset, POLICY);
   asm volatile("s_nop 1" :: "v"(data));
 }
 #endif

@@ -232,15 +232,24 @@ const Rig* rig_of(const dm_params& p, const Plan& plan, const float* pitch4, int
 
 using StripKernel = void (*)(StripArgs);
 
-StripKernel pick_strip_kernel(bool is_max, bool has_valid, bool has_value, bool lean) {
-#define DM_S(M) {{{k_strip_scatter<M, false, false, false>, k_strip_scatter<M, false, false, true>},   \
-                  {k_strip_scatter<M, false, true, false>, k_strip_scatter<M, false, true, true>}},    \
-                 {{k_strip_scatter<M, true, false, false>, k_strip_scatter<M, true, false, false>},    \
-                  {k_strip_scatter<M, true, true, false>, k_strip_scatter<M, true, true, false>}}}
-  // [min | max][has_valid][has_value][lean]   (lean implies no valid map)
-  static const StripKernel table[2][2][2][2] = {DM_S(kMin), DM_S(kMax)};
+StripKernel pick_strip_kernel(bool is_max, bool has_valid, bool has_value, bool lean, bool nt_fill) {
+#define DM_K(M, VALID, VALUE, LEAN) {k_strip_scatter<M, VALID, VALUE, LEAN, kProject, false>, k_strip_scatter<M, VALID, VALUE, LEAN, kProject, true>}
+#define DM_S(M) {{{DM_K(M, false, false, false), DM_K(M, false, false, true)},   \
+                  {DM_K(M, false, true, false), DM_K(M, false, true, true)}},    \
+                 {{DM_K(M, true, false, false), DM_K(M, true, false, false)},    \
+                  {DM_K(M, true, true, false), DM_K(M, true, true, false)}}}
+  // [min | max][has_valid][has_value][lean][fill stores non-temporal]   (lean implies no valid map)
+  static const StripKernel table[2][2][2][2][2] = {DM_S(kMin), DM_S(kMax)};
 #undef DM_S
-  return table[is_max ? 1 : 0][has_valid][has_value][lean && !has_valid];
+#undef DM_K
+  return table[is_max ? 1 : 0][has_valid][has_value][lean && !has_valid][nt_fill];
+}
+
+// Whether the fill value's stores should bypass the caches (dm_pixel.hpp kFillCachePolicy): where
+// the call's own batch fuse follows -- it reads the flushed cells and never the fill -- and where
+// the maps are larger than the Infinity Cache (256 MB) could hold on to next to the depth maps.
+inline bool nt_fill_pays(const dm_params& p, int oc_total, bool fuse_follows) {
+  return fuse_follows || (size_t)p.B * oc_total * p.mh * p.mw * 5 > ((size_t)128 << 20);
 }
 
 
@@ -356,7 +365,7 @@ inline void fill_poses(StripArgs& sa, const PoseSource& src, int b0, int nb) {
 hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const PoseSource& poses,
                       const Layout& l, const float* depth, const float* value, const uint8_t* valid,
                       float* out, uint8_t* mask, int oc_total, float fill, bool is_max, size_t slab_bytes,
-                      int* status, hipStream_t s) {
+                      bool fuse_follows, int* status, hipStream_t s) {
   thread_local StripArgs sa;       // (3.5 KB: not on the stack of every caller)
   memset(&sa, 0, offsetof(StripArgs, poses));
   sa.W = p.W; sa.H = p.H;
@@ -388,7 +397,8 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const
   const bool from_list = has_value && l.pixel_list != nullptr && wants_pixel_list(p);
   sa.list = from_list ? l.pixel_list : nullptr;
   const StripKernel kfn = from_list ? pick_value_kernel(is_max)
-                                    : pick_strip_kernel(is_max, has_valid, has_value, plan.lean);
+                                    : pick_strip_kernel(is_max, has_valid, has_value, plan.lean,
+                                                        nt_fill_pays(p, oc_total, fuse_follows));
   hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn));
   if (e != hipSuccess) return e;
   const size_t lds_bytes = strip_lds_bytes(rg.slab_stride, rg.max_rows, p.H, plan.P);
@@ -557,12 +567,12 @@ hipError_t launch_strips(const dm_params& p, const Plan& plan, const Rig& rg, co
   const bool is_max = p.reduction == DM_REDUCE_MAX;
   g_last_info[0] = g_last_info[1] = g_last_info[2] = g_last_info[3] = 0;
   hipError_t e = strip_pass(p, plan, rg, poses, l, depth, value, valid, out, mask, oc_total, p.fill, is_max,
-                            l.slab_bytes - hm, status, s);
+                            l.slab_bytes - hm, fused != nullptr, status, s);
   if (e != hipSuccess) return e;
   if (height && value) {      // maps.py:332-350: second projection of the heights, NINF fill, max
     uint8_t* scratch_mask = reinterpret_cast<uint8_t*>(l.slabs) + l.slab_bytes - hm;   // (tail of the slab region)
     e = strip_pass(p, plan, rg, poses, l, depth, nullptr, valid, height, scratch_mask, p.dc, -INFINITY, true,
-                   l.slab_bytes - hm, status, s);
+                   l.slab_bytes - hm, false, status, s);
     if (e != hipSuccess) return e;
   }
   if (after_projection) {

@@ -223,11 +223,13 @@ struct StripArgs {
 //   kProject     the whole projection in one kernel (heights; value maps of few channels).
 //   kIndexOut    the index pass: no window, no fill, no flush -- every pixel's cell inside its
 //                strip's window (16 bits, 0xffff: rejected) goes to a list in the workspace.
+// NT_FILL: the fill duty's float4 stores non-temporal (dm_pixel.hpp kFillCachePolicy) or under the
+//   default cache policy (kProject only: the host decides per call, dm_strip.hip nt_fill_pays).
 //   kFromList    the value pass, one workgroup per (strip, channel, frame): cells from the list,
 //                values from the channel's image -- 8 + 16 bytes per thread and row, four
 //                instructions per pixel instead of twenty, four rows in flight.
 enum { kProject = 0, kIndexOut = 1, kFromList = 2 };
-template <int RED, bool HAS_VALID, bool HAS_VALUE, bool LEAN, int MODE = kProject>
+template <int RED, bool HAS_VALID, bool HAS_VALUE, bool LEAN, int MODE = kProject, bool NT_FILL = true>
 __global__ void __launch_bounds__(kScatterThreads)
 k_strip_scatter(StripArgs a) {
   constexpr int VEC = 4;
@@ -659,8 +661,8 @@ k_strip_scatter(StripArgs a) {
     // (the scalar offset must be the same in every lane, skipping or not: a lane-dependent one
     // costs a waterfall loop per store)
     const int cell0 = __builtin_amdgcn_readfirstlane(live ? f_row * la->mw + (f_chunk << 8) : 0);
-    buffer_store_b128_at_scalar_offset((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out,
-                                       skip ? 0x7ffffff0 : lane4 << 2, cell0 << 2);
+    buffer_store_b128_at_scalar_offset<NT_FILL ? kFillCachePolicy : 0>(
+        (u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, skip ? 0x7ffffff0 : lane4 << 2, cell0 << 2);
     __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, skip ? 0x7ffffff0 : lane4, cell0, 0);
     ++fs;
     advance(f_row, f_chunk);

@@ -15,12 +15,18 @@ N ranks each process their own 64 frames (weak scaling); `value` is the
 whole-job rate = N*B*K / max-over-ranks elapsed.  Inputs are synthetic,
 seeded, and resident in HBM before the timed region.
 
+The working set is larger than the chip's 256 MiB Infinity Cache on purpose: the steps rotate
+over ROT depth batches and ROT caller-owned output sets (4 x 79 MB in, 4 x 84 MB out at cfg2),
+so a line is touched again only after > 256 MiB of other traffic and every byte of a step is
+served by HBM -- in the timed loop and in the roofline's launch measurement alike.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
 objects: "roofline" (HBM, algorithmic bytes of step 1 / its HIP-event time on
 the launch stream) and "cpu_baseline" (the oracle timed on this box's host
 cores on a bounded sample; N=1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -43,7 +49,12 @@ WORKLOADS = {
     # per rank 64 frames of one trajectory fused straight into ONE 1024x1024 global map
     # (no per-frame maps), then the cross-rank max all-reduce: BASELINE configs[3]
     "cfg4": (64, 480, 640, 1024, 1024, 0),
+    # per rank 16 frames of 1280x960 -> 2048x2048, the ego-motion flow grid of the same depth
+    # maps and a crop of every map around its camera's cell: BASELINE configs[4]
+    "cfg5": (16, 960, 1280, 2048, 2048, 0),
 }
+CFG5_CROP = 1024          # crop side (cells) of the cfg5 workload's TopdownMap.select leg
+ROT_TARGET_BYTES = 600 << 20      # rotate until a step's buffers come around after > 2 x 256 MiB
 
 
 def algorithmic_bytes(B, H, W, mh, mw, C, fused_only=False):
@@ -99,6 +110,10 @@ def main():
   ap.add_argument("--event-every", type=int, default=8,
                   help="bracket every n-th timed step with HIP events (an event record costs "
                        "a few us of stream time, so not every step carries one)")
+  ap.add_argument("--rotate", type=int, default=0,
+                  help="depth batches / output sets the steps rotate over (0: as many as it takes for a "
+                       "step's buffers to come around after more than twice the Infinity Cache; 1: one "
+                       "set, everything cache resident -- rounds 1-3 measured that)")
   args = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,13 +143,25 @@ def main():
 
   import dungeon_maps_amd as dmap
   from dungeon_maps_amd import _native
-  _native.lib()   # the HIP library must be present: no fallback
+  lib = _native.lib()   # the HIP library must be present: no fallback
 
   B, H, W, mh, mw, C = WORKLOADS[args.workload]
+  fused_only = args.workload == "cfg4"
+  cfg5 = args.workload == "cfg5"
   fill = 0.0 if C else -np.inf
-  depth, pose, value = synthetic_inputs(B, H, W, C, 1234 + rank, dev, args.depth == "scene")
-  depth_d = depth.to(dev)
-  value_d = None if value is None else value.to(dev)
+  C_out = C if C else 1
+  alg = algorithmic_bytes(B, H, W, mh, mw, C, fused_only)
+  # How many input / output sets the steps rotate over: a set comes around again only after more
+  # than ROT_TARGET_BYTES of other traffic, so nothing of it is left in the 256 MiB Infinity Cache.
+  rot = args.rotate if args.rotate > 0 else max(1, min(8, -(-ROT_TARGET_BYTES // alg) + 1))
+  depth_sets, value_sets = [], []
+  depth = pose = value = None
+  for j in range(rot):
+    d_j, pose_j, v_j = synthetic_inputs(B, H, W, C, 1234 + rank + 1000 * j, dev, args.depth == "scene")
+    if j == 0:
+      depth, pose, value = d_j, pose_j, v_j          # (host copies: the CPU baseline's sample)
+    depth_sets.append(d_j.to(dev))
+    value_sets.append(None if v_j is None else v_j.to(dev))
   # the camera moves: every step gets another set of poses (host tensors, as a caller holds them)
   gp = torch.Generator().manual_seed(4321 + rank)
   pose_sets = [pose]
@@ -147,6 +174,22 @@ def main():
       width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
       trunc_depth_min=0.15, trunc_depth_max=5.05, clip_border=0, to_global=True,
       fill_value=fill, reduction="max")
+  # caller-owned output sets (`out=` / `fused_out=`): no allocation per call, and ROT of them so
+  # that the maps a step writes are not the cache-resident maps of the step before
+  out_sets = fused_sets = None
+  if not fused_only:
+    out_sets = [(torch.empty((B, C_out, mh, mw), dtype=torch.float32, device=dev),
+                 torch.empty((B, C_out, mh, mw), dtype=torch.bool, device=dev)) for _ in range(rot)]
+    fused_sets = [(torch.empty((C_out, mh, mw), dtype=torch.float32, device=dev),
+                   torch.empty((C_out, mh, mw), dtype=torch.bool, device=dev)) for _ in range(rot)]
+  if cfg5:
+    flow_tp = torch.tensor([0.05, 0.1, 0.02])
+    # crop centres = the cameras' cells (flip_h: the map's rows run against z), per pose set
+    centers = []
+    for q in pose_sets:
+      cxs = q[:, 0] / 0.03 + mw / 2.
+      czs = (mh - 1) - (q[:, 1] / 0.03 + mh / 2.)
+      centers.append(torch.stack((cxs, czs), dim=1).to(dev))
 
   # HIP events on the launch stream (torch's current stream): before the call and,
   # through the library's measurement hook, right after the kernels that produce the
@@ -156,26 +199,23 @@ def main():
   for e in ev_a + ev_b:
     e.record()                 # materialise the hipEvent_t handles
   torch.cuda.synchronize()
-  lib = _native.lib()
 
-  fused_only = args.workload == "cfg4"
   if fused_only:     # one trajectory, shared offsets
     k = torch.arange(B, dtype=torch.float32) + rank * B
     pose = torch.stack((0.02 * k, 0.01 * k, 0.01 * k), dim=1)
     pose_sets = [pose]
-  calls = {"n": 0}      # steps issued so far (warm-up included): picks the step's pose set
+  calls = {"n": 0}      # steps issued so far (warm-up included): picks the step's pose / buffer sets
 
   # Cross-rank fuse: every step writes its partial global map into a slot of a ring;
   # once per RING steps ONE RCCL all-reduce(max) fuses the whole ring (fewer, larger
   # collectives: xGMI rings are latency bound at 1 MiB) on RCCL's own stream while the
   # next steps project; the masks of the reduced maps are recomputed afterwards.
-  RING = int(os.environ.get("DM_BENCH_RING", "32"))
-  C_out = C if C else 1
+  RING_MAX = max(1, int(os.environ.get("DM_BENCH_RING", "32")))
   ring = ring_mask = None
   if dist is not None:
-    ring = [torch.empty((RING, C_out, mh, mw), dtype=torch.float32, device=dev) for _ in range(2)]
-    ring_mask = [torch.empty((RING, C_out, mh, mw), dtype=torch.bool, device=dev) for _ in range(2)]
-  state = {"slot": 0, "buf": 0, "pending": None}
+    ring = [torch.empty((RING_MAX, C_out, mh, mw), dtype=torch.float32, device=dev) for _ in range(2)]
+    ring_mask = [torch.empty((RING_MAX, C_out, mh, mw), dtype=torch.bool, device=dev) for _ in range(2)]
+  state = {"slot": 0, "buf": 0, "pending": None, "ring": RING_MAX}
 
   def finish_reduce():
     if state["pending"] is not None:
@@ -203,8 +243,10 @@ def main():
   def step(i=None):
     if i is not None and i % args.event_every != 0:
       i = None                   # untimed by events (the wall clock still covers it)
-    pose = pose_sets[calls["n"] % len(pose_sets)]
-    calls["n"] += 1
+    n = calls["n"]
+    calls["n"] = n + 1
+    pose = pose_sets[n % len(pose_sets)]
+    depth_d, value_d = depth_sets[n % rot], value_sets[n % rot]
     if fused_only:
       if i is not None:
         ev_a[i].record()
@@ -216,7 +258,7 @@ def main():
         fused, fmask = proj.orth_project_fused(depth_d, cam_pose=pose)
       if i is not None:
         ev_b[i].record()
-      if dist is not None and state["slot"] == RING:
+      if dist is not None and state["slot"] == state["ring"]:
         flush_ring()
       return fused, fmask, fused, fmask
     if i is not None:
@@ -224,9 +266,14 @@ def main():
       lib.dm_debug_record_after_projection(ev_b[i].cuda_event)
     # per-frame maps + masks and this rank's partial global map, one launch sequence
     top, mask, fused, fmask = proj.orth_project_and_fuse(
-        depth_d, value_map=value_d, cam_pose=pose,
-        fused_out=next_slot() if dist is not None else None)
-    if dist is not None and state["slot"] == RING:
+        depth_d, value_map=value_d, cam_pose=pose, out=out_sets[n % rot],
+        fused_out=next_slot() if dist is not None else fused_sets[n % rot])
+    if cfg5:       # the ego-motion flow grid of the same depth maps, and the crop around each camera's cell
+      grid = proj.camera_affine_grid(depth_d, flow_tp)
+      crop, crop_mask = dmap.functional.crop_nearest(top, centers[n % len(pose_sets)], CFG5_CROP, CFG5_CROP,
+                                                     fill_value=fill, mask=mask)
+      del grid, crop, crop_mask
+    if dist is not None and state["slot"] == state["ring"]:
       flush_ring()                                      # RCCL, element-wise max
     return top, mask, fused, fmask
 
@@ -235,81 +282,96 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
-  # the warm-up runs the timed loop's exact body: the steps' outputs are bound to `out` (so the
-  # caching allocator owns both sets of output blocks the loop alternates between before the clock
-  # starts -- a device allocation inside the timed region cost 50 us on one box and 2 ms on
-  # another) and every n-th step is bracketed by events
-  out = None
-  for j in range(args.warmup):
-    out = step(j % max(1, args.steps))
-  if dist is not None:
-    flush_ring()
-    finish_reduce()
-  barrier()
+  def timed_run(nsteps, nwarm, ring_steps, trace=None):
+    """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides:
+    (elapsed seconds of the slowest rank, host seconds to issue the steps, per-rank ms per step,
+    the last step's outputs, device allocations inside the timed loop)."""
+    state["ring"] = ring_steps
+    # the warm-up runs the timed loop's exact body: the steps' outputs are bound to `out` and every
+    # n-th step is bracketed by events
+    out = None
+    for j in range(nwarm):
+      out = step(j % max(1, nsteps))
+    if dist is not None:
+      flush_ring()
+      finish_reduce()
+    barrier()
+    segs0 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
+    t0 = time.perf_counter()
+    for i in range(nsteps):
+      out = step(i)
+      if trace is not None:
+        trace.append(time.perf_counter())
+    enqueue_s = time.perf_counter() - t0      # host time to issue the steps (<= elapsed)
+    segs1 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
+    if dist is not None:            # every step's all-reduce + mask is inside the timed region
+      flush_ring()
+      finish_reduce()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / nsteps * 1e3]
+    if dist is not None:
+      t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+      every = [torch.zeros_like(t) for _ in range(world)]
+      dist.all_gather(every, t)
+      rank_ms = [float(x.item()) / nsteps * 1e3 for x in every]
+      elapsed = max(float(x.item()) for x in every)         # the slowest rank's clock
+    return elapsed, enqueue_s, rank_ms, out, segs1 - segs0, t0
+
   trace = [] if os.environ.get("DM_BENCH_TRACE") else None
-  segs0 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
-  t0 = time.perf_counter()
-  for i in range(args.steps):
-    out = step(i)
-    if trace is not None:
-      trace.append(time.perf_counter())
-  enqueue_s = time.perf_counter() - t0      # host time to issue the steps (<= elapsed)
-  segs1 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
-  if dist is not None:            # every step's all-reduce + mask is inside the timed region
-    flush_ring()
-    finish_reduce()
-  torch.cuda.synchronize()
-  barrier()
-  elapsed = time.perf_counter() - t0
-  rank_ms = [elapsed / args.steps * 1e3]
-  if dist is not None:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    every = [torch.zeros_like(t) for _ in range(world)]
-    dist.all_gather(every, t)
-    rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
-    elapsed = max(float(x.item()) for x in every)         # the slowest rank's clock
+  elapsed, enqueue_s, rank_ms, out, new_segments, t0 = timed_run(args.steps, args.warmup, RING_MAX, trace)
 
   proj_ms = np.array([ev_a[i].elapsed_time(ev_b[i]) for i in range(0, args.steps, args.event_every)])
   bracketed_s = float(np.mean(proj_ms)) * 1e-3
-  kernel_s = bracketed_s
-  b2b_note = None
   last_pose = pose_sets[(calls["n"] - 1) % len(pose_sets)]      # the poses of `out`
+
+  def back_to_back(fn, n_b2b=64):
+    """fn(j) n_b2b times between ONE pair of HIP events on the launch stream, seconds per call.  (A
+    HIP event between two kernels is a stream operation of its own, ~1.5 us each way: bracketing
+    every launch sequence would time the events too.  This is the figure rocprofv3's per-kernel
+    averages add up to, profiles/.)"""
+    for j in range(4):
+      fn(j)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for j in range(n_b2b):
+      fn(4 + j)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / n_b2b
+
+  step_s = None
   if fused_only:
-    # (the bracketed figure of a fused-only step holds the host's time inside the call: the same
-    # back-to-back measurement as below, of the fused-only call)
-    n_b2b = 64
-    for j in range(3):
-      proj.orth_project_fused(depth_d, cam_pose=pose_sets[j % len(pose_sets)])
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for j in range(n_b2b):
-      proj.orth_project_fused(depth_d, cam_pose=pose_sets[j % len(pose_sets)])
-    e1.record()
-    torch.cuda.synchronize()
-    kernel_s = e0.elapsed_time(e1) * 1e-3 / n_b2b
-    b2b_note = (f"{n_b2b} orth_project_fused calls back to back between one pair of HIP events on the launch "
-                f"stream, total / {n_b2b}")
-  if not fused_only:
-    # The launch sequence's average duration without the cost of the measurement itself: a HIP
-    # event between two kernels is a stream operation of its own (~1.5 us each way), so
-    # N launch sequences (each with its own set of poses) are enqueued back to back between ONE
-    # pair of events and the total is divided by N.  This is the figure rocprofv3's per-kernel
-    # averages add up to (profiles/).
-    n_b2b = 64
-    for j in range(3):
-      proj.orth_project(depth_d, value_map=value_d, cam_pose=pose_sets[j % len(pose_sets)])
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for j in range(n_b2b):
-      proj.orth_project(depth_d, value_map=value_d, cam_pose=pose_sets[j % len(pose_sets)])
-    e1.record()
-    torch.cuda.synchronize()
-    kernel_s = e0.elapsed_time(e1) * 1e-3 / n_b2b
-    b2b_note = (f"{n_b2b} orth_project calls (a new set of poses each) back to back between one pair of "
-                f"HIP events on the launch stream, total / {n_b2b}")
-  alg = algorithmic_bytes(B, H, W, mh, mw, C, fused_only)
+    kernel_s = back_to_back(lambda j: proj.orth_project_fused(depth_sets[j % rot], cam_pose=pose_sets[j % len(pose_sets)]))
+    b2b_note = ("64 orth_project_fused calls back to back between one pair of HIP events on the launch "
+                "stream, total / 64")
+  else:
+    # The launch sequence of the per-frame maps (k_strip_scatter + k_strip_combine) exactly as the
+    # timed steps launch it: the kernel variant a call with a batch fuse takes (non-temporal fill
+    # stores, forced through the library's measurement switch), the rotating depth batches, and
+    # output blocks that rotate too -- plain orth_project allocates its outputs, so the last `rot`
+    # results are kept alive and the allocator has to hand out another block every call.
+    keep = [None] * (rot + 1)
+
+    def plain(j):
+      keep[j % len(keep)] = None
+      keep[j % len(keep)] = proj.orth_project(depth_sets[j % rot], value_map=value_sets[j % rot],
+                                              cam_pose=pose_sets[j % len(pose_sets)])
+    lib.dm_debug_force_nt_fill(1)
+    try:
+      kernel_s = back_to_back(plain, 64 if alg < (1 << 30) else 8)
+    finally:
+      lib.dm_debug_force_nt_fill(-1)
+    del keep
+    b2b_note = ("64 orth_project calls (a new set of poses, another depth batch and other output blocks "
+                "each; the kernel variant of the timed steps: non-temporal fill stores) back to back "
+                "between one pair of HIP events on the launch stream, total / 64")
+    # the whole step's device time the same way: the timed loop's own call (project + batch fuse)
+    step_s = back_to_back(lambda j: proj.orth_project_and_fuse(
+        depth_sets[j % rot], value_map=value_sets[j % rot], cam_pose=pose_sets[j % len(pose_sets)],
+        out=out_sets[j % rot], fused_out=fused_sets[j % rot]), 64 if alg < (1 << 30) else 8)
   achieved = alg / kernel_s / 1e9
 
   # HBM bytes of one launch sequence from the PMC counters: bench.py cannot run rocprofv3 on
@@ -341,8 +403,11 @@ def main():
                       f"depth={args.depth}, project + fuse(max over frames)"
                       f"{' + RCCL all-reduce(max)' if world > 1 else ''} + mask",
           "frames_per_gpu": B, "global_frames": world * B,
+          "working_set": f"{rot} depth batches and {rot} caller-owned output sets in rotation "
+                         f"({rot * alg / 2**20:.0f} MiB live: beyond the 256 MiB Infinity Cache)"
+                         if rot > 1 else "one depth batch, one output set",
           "parallelism": f"frames sharded {world}-way; fused maps all-reduced (RCCL max) "
-                         f"{RING} steps at a time, overlapped with the next steps"
+                         f"{RING_MAX} steps at a time, overlapped with the next steps"
                          if dist is not None else "single GPU",
       },
       "roofline": {
@@ -357,10 +422,10 @@ def main():
                     "of the call in its arguments; geometry, projection, owned cells and fill) + "
                     "k_strip_combine (cells several strips share) -- everything that produces the "
                     "per-frame maps and masks from the depth maps and the call's poses; the batch "
-                    "fuse that follows is excluded",
+                    "fuse that follows is excluded here and included in roofline_step",
           "algorithmic_bytes_per_launch": alg,
           "launch_us": kernel_s * 1e6,
-          "launch_us_how": b2b_note or "HIP events around every 8th step's launch sequence",
+          "launch_us_how": b2b_note,
           "launch_us_single_bracketed": bracketed_s * 1e6,
           "launch_us_single_bracketed_note": "one launch sequence between its own pair of events inside the "
                                              "timed steps (includes the events' own stream time)",
@@ -369,70 +434,97 @@ def main():
           "launch_us_p90": float(np.percentile(proj_ms, 90)) * 1e3,
       },
   }
+  if step_s is not None:
+    alg_step = alg + C_out * mh * mw * 5            # + the batch-fused map and its mask, written once
+    result["roofline_step"] = {
+        "bound": "hbm", "achieved": alg_step / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": alg_step / step_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg_step,
+        "step_us": step_s * 1e6,
+        "how": "the timed loop's own call, orth_project_and_fuse(depth, cam_pose=..., out=..., fused_out=...) "
+               "(projection launch sequence + k_fuse_unions), 64 calls back to back between one pair of HIP "
+               "events: device time per step, or the host's where the host is the slower one"}
 
   if trace is not None:      # host time of every timed step's enqueue, us (DM_BENCH_TRACE=1)
     result["host_step_us"] = [round((t - s0) * 1e6, 1) for s0, t in zip([t0] + trace[:-1], trace)]
-    result["device_allocations_in_timed_loop"] = segs1 - segs0
+    result["device_allocations_in_timed_loop"] = new_segments
   if fused_only:
-    result["roofline"]["kernel"] = ("dm_orth_project_fused_f32 launch sequence: "
-                                    "k_window_scatter + k_fuse_windows")
+    split = (ctypes.c_int32 * 4)()
+    lib.dm_debug_last_fused_split(split)
+    on_strips = lib.dm_debug_last_path() == 2
+    result["roofline"]["kernel"] = (
+        "dm_orth_project_fused_f32 launch sequence: "
+        + (f"k_strip_fused ({split[0]} strips of {split[1]} columns, groups of {split[2]} frames) + k_fuse_windows"
+           if on_strips else "k_window_scatter + k_fuse_windows (window path)"))
     result["config"]["workload"] = (f"cfg4: B={B}/GPU, {W}x{H} depth fused straight into one "
                                     f"{mw}x{mh} global map (max)"
                                     f"{' + RCCL all-reduce(max)' if world > 1 else ''}")
+  if cfg5:
+    result["metric"] = "depth frames/sec projected + ego-flow + cropped, B=16 1280x960->2048x2048"
+    result["config"]["workload"] = (
+        f"cfg5: B={B}/GPU, {W}x{H} depth -> {mw}x{mh} height map + batch fuse, camera_affine_grid of the same "
+        f"depth maps, {CFG5_CROP}x{CFG5_CROP} crop of every map + mask around its camera's cell")
+    result["legs"] = cfg5_legs(dmap, proj, depth_sets, pose_sets, out_sets, centers, flow_tp, fill, rot,
+                               back_to_back, B, H, W, mh, mw)
   result["config"]["camera_state"] = (f"a new set of {B} poses on every step, passed per call "
                                       "(MapProjector.orth_project_and_fuse(depth, cam_pose=...)): "
                                       "they travel in the kernel arguments of the call's launches")
-  if rank == 0 and world == 1 and not fused_only:
+  if dist is not None and RING_MAX != 1:
+    # the same job with ONE all-reduce per step (DM_BENCH_RING=1 semantics: every step's job-wide fused
+    # map is final before the next step is enqueued), so that an N > 1 reader sees what the batching of
+    # RING_MAX steps per collective buys and what the strict form costs
+    e1, q1, r1, _, _, _ = timed_run(args.steps, min(args.warmup, 4), 1)
+    result["ring_of_1"] = {"value": world * B * args.steps / e1, "unit": "frames/s",
+                           "ms_per_step": e1 / args.steps * 1e3,
+                           "note": "one all-reduce(max) per step instead of one per "
+                                   f"{RING_MAX} steps (`value` above): every step's job-wide map is final at once"}
+  depth_d, value_d = depth_sets[0], value_sets[0]
+  if rank == 0 and world == 1 and not fused_only and not cfg5:
     # the same step on PREPARED frames: one fixed set of poses kept in a device buffer
     # (MapProjector.prepare; what a fixed rig or a captured HIP graph uses) -- same kernels, the
     # poses read from that buffer instead of from the kernel arguments
     try:
       prep = proj.prepare(B, cam_pose=pose_sets[0], value_channels=C)
       n_p = max(20, min(100, args.steps))
-      for _ in range(5):
-        keep = prep.orth_project_and_fuse(depth_d, value_map=value_d)
+      for j in range(5):
+        prep.orth_project_and_fuse(depth_sets[j % rot], value_map=value_sets[j % rot], out=out_sets[j % rot],
+                                   fused_out=fused_sets[j % rot])
       torch.cuda.synchronize()
-      t0 = time.perf_counter()
-      for i in range(n_p):
-        keep = prep.orth_project_and_fuse(depth_d, value_map=value_d)
+      t1 = time.perf_counter()
+      for j in range(n_p):
+        prep.orth_project_and_fuse(depth_sets[j % rot], value_map=value_sets[j % rot], out=out_sets[j % rot],
+                                   fused_out=fused_sets[j % rot])
       torch.cuda.synchronize()
-      dt = time.perf_counter() - t0
-      outs = (torch.empty((B, C_out, mh, mw), dtype=torch.float32, device=dev),
-              torch.empty((B, C_out, mh, mw), dtype=torch.bool, device=dev))
-      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-      e0.record()
-      for _ in range(64):
-        prep.orth_project(depth_d, value_map=value_d, out=outs)
-      e1.record()
-      torch.cuda.synchronize()
+      dt = time.perf_counter() - t1
+      us = back_to_back(lambda j: prep.orth_project(depth_sets[j % rot], value_map=value_sets[j % rot],
+                                                    out=out_sets[j % rot])) * 1e6
       result["prepared_frames"] = {
           "value": B * n_p / dt, "unit": "frames/s", "steps": n_p, "ms_per_step": dt / n_p * 1e3,
-          "launch_us": e0.elapsed_time(e1) * 1e3 / 64,
+          "launch_us": us,
           "note": "MapProjector.prepare(...).orth_project_and_fuse(depth): one fixed set of poses in a "
-                  "device buffer (64 launch sequences back to back between one pair of events)"}
-      del prep, outs, keep
+                  "device buffer, the same rotating buffers (64 launch sequences back to back between one "
+                  "pair of events; a plain prepared call keeps the default cache policy on its fill stores)"}
+      del prep
     except _native.NativeError as e:
       result["prepared_frames"] = {"error": str(e)[:200]}
-  if rank == 0 and world == 1 and args.depth == "uniform" and not fused_only and C == 0:
+  if rank == 0 and world == 1 and args.depth == "uniform" and not fused_only and C == 0 and not cfg5:
     # the same step on scene-like depth (floor + walls: many pixels per cell):
     # reported beside the headline number, outside its timed region
-    sdepth, spose, _ = synthetic_inputs(B, H, W, C, 1234 + rank, dev, True)
-    sdepth = sdepth.to(dev)
-    scount = {"n": 0}
+    sdepths = [synthetic_inputs(B, H, W, C, 1234 + rank + 1000 * j, dev, True)[0].to(dev) for j in range(rot)]
 
-    def sstep():
-      scount["n"] += 1
-      return proj.orth_project_and_fuse(sdepth, cam_pose=pose_sets[scount["n"] % len(pose_sets)])
-    for _ in range(10):
-      sstep()
+    def sstep(j):
+      return proj.orth_project_and_fuse(sdepths[j % rot], cam_pose=pose_sets[j % len(pose_sets)],
+                                        out=out_sets[j % rot], fused_out=fused_sets[j % rot])
+    for j in range(10):
+      sstep(j)
     torch.cuda.synchronize()
     n_s = 100
-    t0 = time.perf_counter()
-    for _ in range(n_s):
-      sstep()
+    t1 = time.perf_counter()
+    for j in range(n_s):
+      sstep(j)
     torch.cuda.synchronize()
-    result["scene_like_depth"] = {"value": B * n_s / (time.perf_counter() - t0), "unit": "frames/s",
+    result["scene_like_depth"] = {"value": B * n_s / (time.perf_counter() - t1), "unit": "frames/s",
                                   "steps": n_s, "note": "same workload on floor + walls depth"}
+    del sdepths
   # checksum of the last step's fused map (a one-rank RCCL run must reproduce the plain run)
   fz, fm = out[2], out[3]
   finite = torch.isfinite(fz) & fm
@@ -440,23 +532,64 @@ def main():
       "cells": int(fm.sum().item()),
       "sum": float(torch.where(finite, fz, torch.zeros_like(fz)).double().sum().item()),
   }
-  if rank == 0 and world == 1 and not args.no_other_configs and args.workload == "cfg2" \
-      and args.depth == "uniform":
-    result["other_configs"] = other_configs(dmap, lib, dev)
   if rank == 0 and world == 1 and not args.no_cpu_baseline and not fused_only:
+    # the last timed step's poses on depth batch 0 (the host copy the oracle reads) into fresh
+    # tensors: the rotating output sets have been overwritten by the measurements above
+    out = proj.orth_project_and_fuse(depth_sets[0], value_map=value_sets[0], cam_pose=last_pose)
     result["cpu_baseline"] = cpu_baseline(depth, last_pose, value, H, W, mh, mw, fill,
                                           args.cpu_seconds, out)
+  if rank == 0 and world == 1 and not args.no_other_configs and args.workload == "cfg2" \
+      and args.depth == "uniform":
+    del depth_sets, value_sets, out_sets, fused_sets, out
+    torch.cuda.empty_cache()
+    result["other_configs"] = other_configs(dmap, lib, dev)
   if rank == 0:
     print(json.dumps(result))
   if dist is not None:
     dist.destroy_process_group()
 
 
+def cfg5_legs(dmap, proj, depth_sets, pose_sets, out_sets, centers, flow_tp, fill, rot, back_to_back,
+              B, H, W, mh, mw):
+  """The three legs of the cfg5 step on their own (64 calls back to back each, rotating buffers):
+  device time, algorithmic bytes and fraction of the HBM peak."""
+  legs = {}
+
+  def leg(name, fn, alg, note):
+    us = back_to_back(fn, 32) * 1e6
+    legs[name] = {"us": us, "algorithmic_bytes": alg, "achieved_GBps": alg / us / 1e3,
+                  "frac": alg / us / 1e3 / HBM_PEAK_GBS, "what": note}
+  keep = [None] * (rot + 1)
+
+  def plain(j):
+    keep[j % len(keep)] = None
+    keep[j % len(keep)] = proj.orth_project(depth_sets[j % rot], cam_pose=pose_sets[j % len(pose_sets)])
+  leg("orth_project", plain, algorithmic_bytes(B, H, W, mh, mw, 0),
+      "per-frame height maps + masks (maps.py:127-351)")
+  grids = [None] * 2
+
+  def flow(j):
+    grids[j % 2] = None
+    grids[j % 2] = proj.camera_affine_grid(depth_sets[j % rot], flow_tp)
+  leg("camera_affine_grid", flow, B * H * W * (4 + 8),
+      "ego-motion flow grid of the same depth maps (maps.py:353-460): depth in, two floats per pixel out")
+  crops = [None] * 2
+
+  def crop(j):
+    crops[j % 2] = None
+    crops[j % 2] = dmap.functional.crop_nearest(out_sets[j % rot][0], centers[j % len(centers)], CFG5_CROP,
+                                                CFG5_CROP, fill_value=fill, mask=out_sets[j % rot][1])
+  leg("crop_topdown_map", crop, 2 * B * CFG5_CROP * CFG5_CROP * 5,
+      f"dm_crop_nearest_f32: {CFG5_CROP}x{CFG5_CROP} crop of every height map + mask around its camera's "
+      "cell (maps.py:1959-2037, utils.py:571-652): 5 bytes per cell in, 5 out")
+  return legs
+
+
 def committed_traffic(workload, lib_path):
-  """(bytes per launch sequence, note) from profiles/r03_hbm_traffic.json if its `lib_md5`
+  """(bytes per launch sequence, note) from profiles/r04_hbm_traffic.json if its `lib_md5`
   is the md5 of the loaded library, else (None, why)."""
   import hashlib
-  tpath = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+  tpath = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
   if workload != "cfg2" or not os.path.exists(tpath):
     return None, "no committed PMC summary for this workload"
   with open(tpath) as f:
@@ -464,10 +597,10 @@ def committed_traffic(workload, lib_path):
   with open(lib_path, "rb") as f:
     md5 = hashlib.md5(f.read()).hexdigest()
   if rec.get("lib_md5") != md5:
-    return None, (f"profiles/r03_hbm_traffic.json was measured on library build "
+    return None, (f"profiles/r04_hbm_traffic.json was measured on library build "
                   f"{rec.get('lib_md5')}, the loaded one is {md5}: not quoted")
   return rec.get("launch_sequence_bytes"), (
-      "profiles/r03_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command on "
+      "profiles/r04_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command on "
       "this library build, gfx950 correction applied; bytes per launch sequence)")
 
 

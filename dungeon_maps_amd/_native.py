@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DUNGEON_MAPS_AMD_LIB") or os.path.join(
     HERE, "csrc", "libdungeon_maps_amd.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # dm_reduction
 REDUCE_MAX, REDUCE_MIN, REDUCE_SUM, REDUCE_MEAN, REDUCE_PROD = range(5)
@@ -53,7 +53,7 @@ class FramesPlan(ctypes.Structure):
 
 
 # dm_status_bits
-STATUS_FRAME_DID_NOT_FIT, STATUS_LIST_OVERFLOW = 1, 2
+STATUS_FRAME_DID_NOT_FIT, STATUS_LIST_OVERFLOW = 0x1, 0x100
 
 
 class NativeError(RuntimeError):
@@ -92,6 +92,7 @@ _SIGNATURES = {
     "dm_debug_last_path": (ctypes.c_int, []),
     "dm_debug_force_legacy_window": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_force_strips": (ctypes.c_int, [ctypes.c_int]),
+    "dm_debug_force_nt_fill": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_strip_value_list": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_strip_slab_budget": (ctypes.c_size_t, [ctypes.c_size_t]),
     "dm_debug_last_strip_info": (None, [ctypes.POINTER(ctypes.c_int32)]),

@@ -205,10 +205,12 @@ void compute_rig(const dm_params& p, const Plan& plan, const float* pitch4, int 
 // every batch whose frames stay within the same 2^17 cells (below 2^18: one rig for all), and a
 // rig is a pure function of (parameters, plan, pitch, quantised magnitude) -- what a prepared
 // batch's plan records is enough to find the same rig again.
+// Idempotent (a prepared batch's plan records the quantised value and rig_of quantises what it is
+// given): the next multiple of 2^17 at or above the magnitude, at least 2^18.
 inline int quantised_magnitude(int magnitude) {
-  if (magnitude < (1 << 18)) return 1 << 18;
-  const int64_t up = ((int64_t)magnitude + (1 << 17)) / (1 << 17) * (1 << 17);
-  return up > 0x7fffffff ? 0x7fffffff : (int)up;
+  if (magnitude <= (1 << 18)) return 1 << 18;
+  const int64_t up = (((int64_t)magnitude + (1 << 17) - 1) >> 17) << 17;
+  return up > 0x7ffe0000 ? 0x7ffe0000 : (int)up;       // (the largest multiple of 2^17 an int holds)
 }
 
 const Rig* rig_of(const dm_params& p, const Plan& plan, const float* pitch4, int magnitude) {
@@ -248,7 +250,9 @@ StripKernel pick_strip_kernel(bool is_max, bool has_valid, bool has_value, bool 
 // Whether the fill value's stores should bypass the caches (dm_pixel.hpp kFillCachePolicy): where
 // the call's own batch fuse follows -- it reads the flushed cells and never the fill -- and where
 // the maps are larger than the Infinity Cache (256 MB) could hold on to next to the depth maps.
+thread_local int g_force_nt_fill = -1;      // dm_debug_force_nt_fill: -1 the rule below, 0 never, 1 always
 inline bool nt_fill_pays(const dm_params& p, int oc_total, bool fuse_follows) {
+  if (g_force_nt_fill >= 0) return g_force_nt_fill != 0;
   return fuse_follows || (size_t)p.B * oc_total * p.mh * p.mw * 5 > ((size_t)128 << 20);
 }
 
@@ -1008,6 +1012,12 @@ extern "C" __attribute__((visibility("default"))) void dm_debug_last_fused_split
 extern "C" __attribute__((visibility("default"))) int dm_debug_force_strips(int strips) {
   const int old = dm::g_force_strips;
   dm::g_force_strips = strips > 0 && strips <= dm::strip::kMaxStrips ? strips : 0;
+  return old;
+}
+
+extern "C" __attribute__((visibility("default"))) int dm_debug_force_nt_fill(int mode) {
+  const int old = dm::g_force_nt_fill;
+  dm::g_force_nt_fill = mode < 0 ? -1 : (mode != 0);
   return old;
 }
 

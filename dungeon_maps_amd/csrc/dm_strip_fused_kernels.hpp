@@ -212,7 +212,7 @@ k_strip_fused(FusedArgs a) {
   const bool fits = __builtin_amdgcn_readfirstlane(gwin[3]) != 0 && w.w * w.h <= a.slab_stride && w.h <= a.max_rows;
   if (!fits) {
     if (threadIdx.x == 0 && a.status && (w.w > 0 || !__builtin_amdgcn_readfirstlane(gwin[3])))
-      __hip_atomic_store(a.status, kStatusFrameDidNotFit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      raise_status(a.status, kStatusFrameDidNotFit);
     w.w = 0; w.h = 0;
   }
   const int area = w.w * w.h;

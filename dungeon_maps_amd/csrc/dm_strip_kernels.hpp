@@ -172,8 +172,14 @@ struct FrameTables {
                               //                   lower strip's cover holds
 };
 
-// Status bits the kernels set (dm_status_bits in the header)
-constexpr int kStatusFrameDidNotFit = 1, kStatusListOverflow = 2;
+// Status bits the kernels set (dm_status_bits in the header).  Every bit lives in a byte of its
+// own and is raised by a plain byte store of 1: two kernels (or two workgroups) raising different
+// bits cannot overwrite each other, and no atomic has to cross PCIe to pinned host memory.
+constexpr int kStatusFrameDidNotFit = 1, kStatusListOverflow = 0x100;
+__device__ inline void raise_status(int* status, int bit) {
+  __hip_atomic_store(reinterpret_cast<unsigned char*>(status) + (bit == kStatusFrameDidNotFit ? 0 : 1), (unsigned char)1,
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 struct StripArgs {
   int W, H;
@@ -412,7 +418,7 @@ k_strip_scatter(StripArgs a) {
     if (lane < strip::kMaxStrips) a.t.wins[(size_t)b * strip::kMaxStrips + lane] = fits ? geom->win[lane] : Win16{0, 0, 0, 0};
     if (lane == 0) {
       a.t.unions[b] = narrow16(U);
-      if (!fits && a.status) __hip_atomic_store(a.status, kStatusFrameDidNotFit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (!fits && a.status) raise_status(a.status, kStatusFrameDidNotFit);
     }
   }
   // the maps of this (frame, channel) as raw buffer resources (the fill duty's and the flush's stores)
@@ -1006,7 +1012,7 @@ k_strip_scatter(StripArgs a) {
     const int n = area > 0 ? fgeom->chunk_entries[kListMaxRows / 64] : 0;
     fa->t.counts[(size_t)b * strip::kMaxStrips + part] = n < fa->seg_cap ? n : fa->seg_cap;
     if (n > fa->seg_cap && fa->status)       // (cannot happen: a strip lists at most the groups of its window)
-      __hip_atomic_store(fa->status, kStatusListOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      raise_status(fa->status, kStatusListOverflow);
   }
   DM_STAMP(6);
   DM_STAMPS_OUT();

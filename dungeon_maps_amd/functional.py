@@ -232,14 +232,14 @@ def orth_project(
                        cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
                        center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
                        clip_border, to_global, flip_h, fill_value, reduction, get_height_map,
-                       device, False, None)
+                       device, False, None, None)
 
 
 def _orth_project(depth_map, value_map, valid_map, cam_pose, width_offset, height_offset,
                   cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
                   center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
                   clip_border, to_global, flip_h, fill_value, reduction, get_height_map, device,
-                  _fuse, _fused_out):
+                  _fuse, _fused_out, _out):
   """orth_project / orth_project_and_fuse behind one native call."""
   import ctypes
   call = _Call(depth_map, value_map, valid_map, cam_pose, width_offset, height_offset,
@@ -248,8 +248,14 @@ def _orth_project(depth_map, value_map, valid_map, cam_pose, width_offset, heigh
                clip_border, to_global, flip_h, fill_value, reduction, device)
   p = call.params
   shape = (p.B, call.oc, p.mh, p.mw)
-  topdown = torch.empty(shape, dtype=torch.float32, device=call.dev)
-  mask = torch.empty(shape, dtype=torch.bool, device=call.dev)
+  if _out is not None:
+    topdown, mask = _out
+    for t, dt in ((topdown, torch.float32), (mask, torch.bool)):
+      if tuple(t.shape) != shape or t.dtype != dt or t.device != call.dev or not t.is_contiguous():
+        raise ValueError(f"`out` must be contiguous {dt} {shape} tensors on {call.dev}")
+  else:
+    topdown = torch.empty(shape, dtype=torch.float32, device=call.dev)
+    mask = torch.empty(shape, dtype=torch.bool, device=call.dev)
   height = None
   if get_height_map and p.vc:
     height = torch.empty((p.B, p.dc, p.mh, p.mw), dtype=torch.float32, device=call.dev)
@@ -289,7 +295,7 @@ def orth_project_and_fuse(depth_map, value_map, valid_map, cam_pose, width_offse
                           focal_x, focal_y, center_x, center_y, trunc_depth_min,
                           trunc_depth_max, trunc_height_max, clip_border, to_global=True,
                           flip_h=True, fill_value=NINF, reduction=None, device=None,
-                          fused_out=None
+                          fused_out=None, out=None
                           ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
   """``orth_project`` plus the batch-fused map in the same launch sequence:
   returns ``(topdown (b,C,mh,mw), mask, fused (C,mh,mw), fused_mask)`` with
@@ -299,12 +305,14 @@ def orth_project_and_fuse(depth_map, value_map, valid_map, cam_pose, width_offse
   multi-GPU job all-reduces (``parallel.all_reduce_fused``).  ``fused_out`` =
   (float32 (C,mh,mw), bool (C,mh,mw)) writes the fused map and its mask into
   caller-owned buffers, e.g. slots of a ring that is all-reduced once per several
-  steps (fewer, larger collectives)."""
+  steps (fewer, larger collectives).  ``out`` = (float32 (b,C,mh,mw), bool (b,C,mh,mw)) does
+  the same for the per-frame maps and masks (a caller that keeps a ring of output sets pays no
+  allocation per call)."""
   return _orth_project(depth_map, value_map, valid_map, cam_pose, width_offset, height_offset,
                        cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
                        center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
                        clip_border, to_global, flip_h, fill_value, reduction, False, device,
-                       True, fused_out)
+                       True, fused_out, out)
 
 
 def orth_project_fused(
@@ -338,6 +346,7 @@ def orth_project_fused(
     out = torch.empty(shape, dtype=torch.float32, device=call.dev)
   mask = torch.empty(shape, dtype=torch.bool, device=call.dev)
   ws, ws_bytes = call.workspace()
+  _native.check_status()
   with _on_device(call.dev):
     _native.check(_native.lib().dm_orth_project_fused_f32(
         ctypes.byref(p), _ptr(call.frames), _ptr(call.depth), _ptr(call.value),

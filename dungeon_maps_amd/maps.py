@@ -7,6 +7,7 @@ configuration holder: every functional API is reachable as a method whose
 """
 import ctypes
 import inspect
+import threading
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -56,6 +57,7 @@ class MapProjector:
       d[name] = values[name]
     d["_dm_defaults"] = {}                 # forwarding methods: their resolved defaults
     d["cam_params"] = utils.get_camera_intrinsics(width=width, height=height, hfov=hfov, vfov=vfov)
+    d["_cam_key"] = (width, height, hfov, vfov)      # what cam_params was built from (clone)
 
   def __setattr__(self, name, value):
     # the forwarding methods cache their resolved defaults on the instance: any assignment
@@ -89,11 +91,16 @@ class MapProjector:
       v = overrides[name]
       d[name] = mine[name] if v is None else v
     d["_dm_defaults"] = {}
-    if width is None and height is None and hfov is None and vfov is None:
+    # the intrinsics are rebuilt as the reference's clone rebuilds them (maps.py:1349-1404 goes
+    # through __init__) unless the four fields are the ones the cached cam_params came from --
+    # a projector whose width / height / hfov / vfov were reassigned must not hand on stale ones
+    key = (d["width"], d["height"], d["hfov"], d["vfov"])
+    if key == mine.get("_cam_key"):
       d["cam_params"] = mine["cam_params"]         # (never modified in place)
     else:
       d["cam_params"] = utils.get_camera_intrinsics(width=d["width"], height=d["height"],
                                                     hfov=d["hfov"], vfov=d["vfov"])
+    d["_cam_key"] = key
     return new
 
 
@@ -403,19 +410,26 @@ def _fuse_source(m: TopdownMap, proj: MapProjector, dev):
 
 
 _STATS_SLOTS = 512
-_stats_rings = {}     # device -> [zero-filled (slots, 8) int32 tensor, next slot]
+_stats_local = threading.local()     # .rings: (device, stream) -> [zero-filled (slots, 8) int32 tensor, next slot]
 
 
 def _zeroed_stats(dev) -> torch.Tensor:
   """Five zero words on ``dev`` for dm_fuse_bbox_multi_f32 (zero is the identity of its maxima):
   the next row of a ring that is zero-filled once per _STATS_SLOTS uses instead of once per use.
   (A row is read back -- a host sync -- before the next one is taken, so when the ring wraps no
-  kernel is still writing into it.)"""
-  key = (dev.type, dev.index)
-  ring = _stats_rings.get(key)
-  if ring is None or ring[1] == _STATS_SLOTS:
+  kernel is still writing into it.)  One ring per host thread and stream: the zero fill is
+  ordered in front of its rows' uses by the stream it was enqueued on, and two threads never
+  take the same row."""
+  rings = getattr(_stats_local, "rings", None)
+  if rings is None:
+    rings = _stats_local.rings = {}
+  key = (dev.type, dev.index, F._stream_ptr(dev))
+  ring = rings.get(key)
+  if ring is None or ring[1] >= _STATS_SLOTS:
+    if len(rings) > 64:
+      rings.clear()
     ring = [torch.zeros((_STATS_SLOTS, 8), dtype=torch.int32, device=dev), 0]
-    _stats_rings[key] = ring
+    rings[key] = ring
   row = ring[0][ring[1]]
   ring[1] += 1
   return row

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 7
+#define DM_ABI_VERSION 8
 
 typedef enum dm_status {
   DM_OK = 0,
@@ -52,10 +52,12 @@ typedef enum dm_status {
  * pose record in the caller's device buffer no longer fits the plan it is projected with; such a
  * frame's maps come out holding the fill value.  The word is sticky (never cleared by the
  * library): a caller polls it before its next call and treats non-zero as a failed projection.
+ * Every bit lives in a byte of its own and is raised by a byte store, so that kernels raising
+ * different bits never overwrite each other's.
  */
 typedef enum dm_status_bits {
-  DM_STATUS_FRAME_DID_NOT_FIT = 1,
-  DM_STATUS_LIST_OVERFLOW = 2
+  DM_STATUS_FRAME_DID_NOT_FIT = 0x1,
+  DM_STATUS_LIST_OVERFLOW = 0x100
 } dm_status_bits;
 
 /* utils.Reduction (dungeon_maps/utils.py:52-76) */
@@ -381,6 +383,12 @@ int dm_debug_force_bands(int on);
  *                                column strips whatever the cost model says (0 = back to the
  *                                model); returns the previous setting.  Lets the tests run the
  *                                strip path on small images.
+ *   dm_debug_force_nt_fill       which cache policy the strip path's fill stores of the calling
+ *                                thread's projections take: 1 non-temporal, 0 the default policy,
+ *                                -1 the library's own rule (non-temporal where the call's batch
+ *                                fuse follows or the maps exceed what the Infinity Cache keeps);
+ *                                returns the previous setting.  Same results; lets a measurement
+ *                                time a plain call on the kernel variant a fused call launches.
  *   dm_debug_strip_value_list    0: value maps of three channels or more recompute every pixel's cell
  *                                per channel on the strip path of the calling thread, instead of
  *                                taking it from the list the index pass leaves (non-zero, the
@@ -421,6 +429,7 @@ int dm_debug_force_bands(int on);
 int dm_debug_last_path(void);
 int dm_debug_force_legacy_window(int on);
 int dm_debug_force_strips(int strips);
+int dm_debug_force_nt_fill(int mode);
 int dm_debug_strip_value_list(int on);
 size_t dm_debug_strip_slab_budget(size_t bytes);
 void dm_debug_last_strip_info(int32_t* out4);

@@ -278,6 +278,40 @@ def test_prepared_single_small_frame_equals_oracle(dmap, oracle):
     assert torch.equal(got[0], plain[0]) and torch.equal(got[1], plain[1])
 
 
+def test_prepared_projection_far_from_the_origin(dmap, oracle):
+  """A prepared batch whose frames lie >= 2^18 cells from the origin: the plan records the QUANTISED
+  magnitude and the projection call quantises what the plan holds once more -- the quantisation
+  must be idempotent, or dm_orth_project_prepared_f32 refuses the plan dm_frames_prepare_f32 just
+  made (round-3 advisor finding: tx = 2242 m at 3 cm gives 393 216 -> 524 288)."""
+  lib = _lib()
+  rng = np.random.default_rng(2242)
+  B, H, W, mh, mw, res = 4, 120, 160, 128, 128, 0.03
+  depth = rng.uniform(0.1, 6.0, size=(B, 1, H, W)).astype(np.float32)
+  for tx in (1.0, 2242.0, 3500.0, 4300.0, 7000.0):
+    pose = np.stack([tx + rng.uniform(-1, 1, B), rng.uniform(-1, 1, B), rng.uniform(-np.pi, np.pi, B)], 1).astype(np.float32)
+    woff = float(np.float32(mw / 2. - tx / res))
+    cfg = dict(width=W, height=H, hfov=np.radians(70.), vfov=None, cam_pitch=np.radians(-20.), cam_height=0.88,
+               width_offset=woff, height_offset=mh / 2., map_res=res, map_width=mw, map_height=mh,
+               trunc_depth_min=0.15, trunc_depth_max=5.05, trunc_height_max=None, clip_border=0,
+               to_global=True, flip_h=True, fill_value=-np.inf, reduction="max")
+    proj = dmap.MapProjector(**cfg)
+    d = torch.from_numpy(depth).cuda()
+    lib.dm_debug_force_strips(4)
+    try:
+      prep = proj.prepare(B, cam_pose=pose)
+      got = prep.orth_project(d)                    # (raised DM_ERR_UNSUPPORTED for tx = 2242 before the fix)
+      assert lib.dm_debug_last_path() == 2 and prep.status() == 0
+      plain = proj.orth_project(d, cam_pose=pose)
+    finally:
+      lib.dm_debug_force_strips(0)
+    kw = dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose)
+    want = oracle.orth_project(depth, **kw)
+    np.testing.assert_array_equal(got[1].cpu().numpy(), want[1])
+    np.testing.assert_array_equal(got[0].cpu().numpy(), want[0])
+    assert torch.equal(got[0], plain[0]) and torch.equal(got[1], plain[1])
+    assert want[1].any()
+
+
 def test_prepared_projection_replays_from_a_hip_graph(dmap):
   """dm_orth_project_prepared_f32's launch sequence depends only on the parameters and the
   pointers: captured into a HIP graph it replays bit-equal, and after update() (new poses into

@@ -46,7 +46,21 @@ def _worker(rank, world, port, out_dir):
   parallel.all_reduce_fused(fused, "max")
   np.save(os.path.join(out_dir, f"fused_{rank}.npy"), fused.numpy())
   with pytest.raises(ValueError):
-    parallel.all_reduce_fused(fused, "sum")
+    parallel.all_reduce_fused(fused, "mean")
+  with pytest.raises(ValueError):
+    parallel.all_reduce_fused(fused, "sum", fill_value=-np.inf)     # a sum starts from a finite canvas
+  # reduction='sum' (ncclSum, tolerance): point counts of a one-hot value map (exact in
+  # float32) and sums of heights on top of a non-zero fill value
+  rng = np.random.default_rng(3)
+  labels = rng.integers(0, 3, size=depth.shape[:1] + depth.shape[2:])
+  onehot = np.eye(3, dtype=np.float32)[labels].transpose(0, 3, 1, 2).copy()
+  for tag, value, fill in (("counts", onehot, 0.0), ("heights", None, 1.5)):
+    kw = dict(_cfg(oracle), fill_value=fill, reduction="sum")
+    maps, _ = oracle.orth_project(depth[lo:hi], value_map=None if value is None else value[lo:hi],
+                                  cam_pose=pose[lo:hi], **kw)
+    part = parallel.partial_sum_map(torch.from_numpy(maps.copy()), fill)
+    parallel.all_reduce_fused(part, "sum", fill_value=fill)
+    np.save(os.path.join(out_dir, f"sum_{tag}_{rank}.npy"), part.numpy())
   dist.destroy_process_group()
 
 
@@ -61,6 +75,22 @@ def test_two_ranks_equal_one_rank(oracle, tmp_path):
     np.testing.assert_array_equal(got, want)
     # mask = f(map, fill): recomputed locally after the all-reduce
     np.testing.assert_array_equal(np.isfinite(got), wmask)
+  # the cross-rank sum against ONE process scatter-adding every frame's points into one canvas
+  # (the oracle's fused sum): counts exactly, heights to north_star's 1e-5
+  rng = np.random.default_rng(3)
+  labels = rng.integers(0, 3, size=depth.shape[:1] + depth.shape[2:])
+  onehot = np.eye(3, dtype=np.float32)[labels].transpose(0, 3, 1, 2).copy()
+  for tag, value, fill in (("counts", onehot, 0.0), ("heights", None, 1.5)):
+    kw = dict(_cfg(oracle), fill_value=fill, reduction="sum")
+    maps, _ = oracle.orth_project(depth, value_map=value, cam_pose=pose, **kw)
+    one = (maps.astype(np.float64) - fill).sum(0) + fill
+    for r in range(world):
+      got = np.load(tmp_path / f"sum_{tag}_{r}.npy")
+      if tag == "counts":
+        np.testing.assert_array_equal(got, one.astype(np.float32))
+        assert got.max() >= 2                       # cells several frames of both ranks hit
+      else:
+        np.testing.assert_allclose(got, one, rtol=1e-5, atol=1e-5)
 
 
 def test_shard_range_partitions_the_batch():

@@ -9,7 +9,11 @@ import dungeon_maps_amd as dmap
 from dungeon_maps_amd import _native
 B, H, W, mh, mw = [int(v) for v in os.environ.get("DM_STAMPS_SHAPE", "64,480,640,512,512").split(",")]
 g = torch.Generator().manual_seed(1234)
-depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g).cuda()
+ROT = int(os.environ.get("DM_STAMPS_ROT", "1"))     # depth batches / output blocks in rotation (> 256 MiB live: HBM-served)
+depths = [torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g).cuda() for _ in range(ROT)]
+depth = depths[0]
+if os.environ.get("DM_STAMPS_NT"):
+  _native.lib().dm_debug_force_nt_fill(int(os.environ["DM_STAMPS_NT"]))
 pose = torch.empty(B, 3).uniform_(-1, 1, generator=g); pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)
 proj = dmap.MapProjector(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
                          width_offset=mw / 2., height_offset=mh / 2., map_res=0.03, map_width=mw, map_height=mh,
@@ -31,8 +35,12 @@ if C:      # value maps: the stamps then are those of the value pass (the kernel
                            trunc_depth_min=0.15, trunc_depth_max=5.05, to_global=True, fill_value=0.0)
   buf = torch.zeros(4096 * 12 * C + 4096 * 16 * C, dtype=torch.int64, device="cuda")
   lib.dm_debug_strip_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+keep, count = [None] * (ROT + 1), [0]
 def run():
-  return proj.orth_project(depth, value_map=value, cam_pose=pose)
+  j = count[0]; count[0] += 1
+  keep[j % len(keep)] = None
+  keep[j % len(keep)] = proj.orth_project(depths[j % ROT], value_map=value, cam_pose=pose)
+  return keep[j % len(keep)]
 for _ in range(5):
   top, mask = run()
 torch.cuda.synchronize()

@@ -264,15 +264,18 @@ def main():
     if i is not None:
       lib.dm_debug_record_before_projection(ev_a[i].cuda_event)
       lib.dm_debug_record_after_projection(ev_b[i].cuda_event)
+    if cfg5:
+      # per-frame maps + masks and the ego-motion flow grid of the same depth maps from ONE native
+      # call, then the crop of every map around its camera's cell
+      top, mask, grid = proj.orth_project_and_flow(depth_d, flow_tp, cam_pose=pose, out=out_sets[n % rot])
+      crop, crop_mask = dmap.functional.crop_nearest(top, centers[n % len(pose_sets)], CFG5_CROP, CFG5_CROP,
+                                                     fill_value=fill, mask=mask)
+      del grid, crop, crop_mask
+      return top, mask, top[0], mask[0]
     # per-frame maps + masks and this rank's partial global map, one launch sequence
     top, mask, fused, fmask = proj.orth_project_and_fuse(
         depth_d, value_map=value_d, cam_pose=pose, out=out_sets[n % rot],
         fused_out=next_slot() if dist is not None else fused_sets[n % rot])
-    if cfg5:       # the ego-motion flow grid of the same depth maps, and the crop around each camera's cell
-      grid = proj.camera_affine_grid(depth_d, flow_tp)
-      crop, crop_mask = dmap.functional.crop_nearest(top, centers[n % len(pose_sets)], CFG5_CROP, CFG5_CROP,
-                                                     fill_value=fill, mask=mask)
-      del grid, crop, crop_mask
     if dist is not None and state["slot"] == state["ring"]:
       flush_ring()                                      # RCCL, element-wise max
     return top, mask, fused, fmask
@@ -322,6 +325,15 @@ def main():
   trace = [] if os.environ.get("DM_BENCH_TRACE") else None
   elapsed, enqueue_s, rank_ms, out, new_segments, t0 = timed_run(args.steps, args.warmup, RING_MAX, trace)
 
+  # checksum of the last step's fused map (a one-rank RCCL run must reproduce the plain run), taken
+  # before the measurements below write into the rotating output sets again
+  fz, fm = out[2], out[3]
+  finite = torch.isfinite(fz) & fm
+  fused_checksum = {
+      "cells": int(fm.sum().item()),
+      "sum": float(torch.where(finite, fz, torch.zeros_like(fz)).double().sum().item()),
+  }
+  del fz, fm, finite
   proj_ms = np.array([ev_a[i].elapsed_time(ev_b[i]) for i in range(0, args.steps, args.event_every)])
   bracketed_s = float(np.mean(proj_ms)) * 1e-3
   last_pose = pose_sets[(calls["n"] - 1) % len(pose_sets)]      # the poses of `out`
@@ -369,7 +381,7 @@ def main():
                 "each; the kernel variant of the timed steps: non-temporal fill stores) back to back "
                 "between one pair of HIP events on the launch stream, total / 64")
     # the whole step's device time the same way: the timed loop's own call (project + batch fuse)
-    step_s = back_to_back(lambda j: proj.orth_project_and_fuse(
+    step_s = None if cfg5 else back_to_back(lambda j: proj.orth_project_and_fuse(
         depth_sets[j % rot], value_map=value_sets[j % rot], cam_pose=pose_sets[j % len(pose_sets)],
         out=out_sets[j % rot], fused_out=fused_sets[j % rot]), 64 if alg < (1 << 30) else 8)
   achieved = alg / kernel_s / 1e9
@@ -444,6 +456,7 @@ def main():
                "(projection launch sequence + k_fuse_unions), 64 calls back to back between one pair of HIP "
                "events: device time per step, or the host's where the host is the slower one"}
 
+  result["fused_checksum"] = fused_checksum
   if trace is not None:      # host time of every timed step's enqueue, us (DM_BENCH_TRACE=1)
     result["host_step_us"] = [round((t - s0) * 1e6, 1) for s0, t in zip([t0] + trace[:-1], trace)]
     result["device_allocations_in_timed_loop"] = new_segments
@@ -461,8 +474,9 @@ def main():
   if cfg5:
     result["metric"] = "depth frames/sec projected + ego-flow + cropped, B=16 1280x960->2048x2048"
     result["config"]["workload"] = (
-        f"cfg5: B={B}/GPU, {W}x{H} depth -> {mw}x{mh} height map + batch fuse, camera_affine_grid of the same "
-        f"depth maps, {CFG5_CROP}x{CFG5_CROP} crop of every map + mask around its camera's cell")
+        f"cfg5: B={B}/GPU, {W}x{H} depth -> {mw}x{mh} height maps + the ego-motion flow grid of the same depth "
+        f"maps (orth_project_and_flow: one native call), {CFG5_CROP}x{CFG5_CROP} crop of every map + "
+        f"mask around its camera's cell")
     result["legs"] = cfg5_legs(dmap, proj, depth_sets, pose_sets, out_sets, centers, flow_tp, fill, rot,
                                back_to_back, B, H, W, mh, mw)
   result["config"]["camera_state"] = (f"a new set of {B} poses on every step, passed per call "
@@ -525,13 +539,6 @@ def main():
     result["scene_like_depth"] = {"value": B * n_s / (time.perf_counter() - t1), "unit": "frames/s",
                                   "steps": n_s, "note": "same workload on floor + walls depth"}
     del sdepths
-  # checksum of the last step's fused map (a one-rank RCCL run must reproduce the plain run)
-  fz, fm = out[2], out[3]
-  finite = torch.isfinite(fz) & fm
-  result["fused_checksum"] = {
-      "cells": int(fm.sum().item()),
-      "sum": float(torch.where(finite, fz, torch.zeros_like(fz)).double().sum().item()),
-  }
   if rank == 0 and world == 1 and not args.no_cpu_baseline and not fused_only:
     # the last timed step's poses on depth batch 0 (the host copy the oracle reads) into fresh
     # tensors: the rotating output sets have been overwritten by the measurements above
@@ -566,6 +573,24 @@ def cfg5_legs(dmap, proj, depth_sets, pose_sets, out_sets, centers, flow_tp, fil
     keep[j % len(keep)] = proj.orth_project(depth_sets[j % rot], cam_pose=pose_sets[j % len(pose_sets)])
   leg("orth_project", plain, algorithmic_bytes(B, H, W, mh, mw, 0),
       "per-frame height maps + masks (maps.py:127-351)")
+  both = [None] * 2
+
+  def fused_flow(j):
+    both[j % 2] = None
+    both[j % 2] = proj.orth_project_and_flow(depth_sets[j % rot], flow_tp, cam_pose=pose_sets[j % len(pose_sets)],
+                                            out=out_sets[j % rot])
+  leg("orth_project_and_flow", fused_flow, algorithmic_bytes(B, H, W, mh, mw, 0) + B * H * W * (4 + 8),
+      "both from one native call (dm_orth_project_flow_f32), as the timed steps make it: the projection's "
+      "launches and the flow kernel behind them (depth read twice)")
+  from dungeon_maps_amd import _native
+  _native.lib().dm_debug_flow_fused(1)
+  try:
+    leg("orth_project_and_flow_one_kernel", fused_flow, algorithmic_bytes(B, H, W, mh, mw, 0) + B * H * W * 8,
+        "the same call with the projection kernel computing the flow from the depth it has loaded (one depth "
+        "read; dm_debug_flow_fused(1)): slower than the two kernels on this chip, hence not the default")
+  finally:
+    _native.lib().dm_debug_flow_fused(0)
+  del both
   grids = [None] * 2
 
   def flow(j):

@@ -69,6 +69,8 @@ _SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
         ctypes.c_void_p]),
+    "dm_frames_fill_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p]),
     "dm_frames_prepared_bytes": (ctypes.c_size_t, [ctypes.POINTER(Params)]),
     "dm_frames_prepare_f32": (ctypes.c_int, [
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
@@ -82,6 +84,12 @@ _SIGNATURES = {
         ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "dm_orth_project_flow_f32": (ctypes.c_int, [
+        ctypes.POINTER(Params), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "dm_debug_last_flow_fused": (ctypes.c_int, []),
+    "dm_debug_flow_fused": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_force_generic_path": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_force_bands": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_slab_budget": (ctypes.c_size_t, [ctypes.c_size_t]),
@@ -92,6 +100,7 @@ _SIGNATURES = {
     "dm_debug_last_path": (ctypes.c_int, []),
     "dm_debug_force_legacy_window": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_force_strips": (ctypes.c_int, [ctypes.c_int]),
+    "dm_debug_fill_split": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_force_nt_fill": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_strip_value_list": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_strip_slab_budget": (ctypes.c_size_t, [ctypes.c_size_t]),

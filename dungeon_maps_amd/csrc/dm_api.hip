@@ -2,6 +2,7 @@
 // validation, path selection, error reporting.  No torch types, no allocation.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "dm_kernels.hpp"
 
@@ -91,11 +92,18 @@ size_t dm_orth_project_workspace_bytes(const dm_params* p) {
   return n;
 }
 
-int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float* depth_dev,
-                        const float* value_dev, const uint8_t* valid_dev, float* out_dev,
-                        uint8_t* mask_dev, float* height_dev, float* fused_dev,
-                        uint8_t* fused_mask_dev, void* workspace_dev, size_t workspace_bytes,
-                        int32_t* status_dev, void* stream) {
+}  // extern "C"
+
+// dm_orth_project_f32, and -- with `flow_frames` / `grid_dev` -- dm_orth_project_flow_f32: the same
+// projection plus the ego-motion flow grid of the same depth maps, computed by the projection
+// kernel itself where the window path's lean height kernel runs (one depth read for both), by the
+// stand-alone kernel behind the projection otherwise.
+static int orth_project_impl(const dm_params* p, const dm_frame* frames, const float* depth_dev,
+                             const float* value_dev, const uint8_t* valid_dev, float* out_dev,
+                             uint8_t* mask_dev, float* height_dev, float* fused_dev,
+                             uint8_t* fused_mask_dev, void* workspace_dev, size_t workspace_bytes,
+                             int32_t* status_dev, void* stream, const dm_frame* flow_frames,
+                             float* grid_dev) {
   int rc = check_params(p);
   if (rc != DM_OK) return rc;
   if (p->B == 0) return DM_OK;
@@ -119,6 +127,7 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
   const hipEvent_t mid = g_mid_event, pre = g_pre_event;
   g_mid_event = nullptr;
   g_pre_event = nullptr;
+  bool flowed = false;        // the projection kernel wrote the flow grid
   if (dm::window_path_supported(*p) && !g_force_generic) {
     // the reference's default is no depth truncation at all (maps.py:1267-1268): the fast paths
     // then run with bounds beyond which no ray can still be inside the map (same cells)
@@ -130,7 +139,7 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
     if (e == hipErrorNotSupported)
       e = dm::run_window(pp, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev,
                          p->vc ? height_dev : nullptr, fused_dev, fused_mask_dev, workspace_dev,
-                         workspace_bytes, pre, mid, s);
+                         workspace_bytes, pre, mid, s, flow_frames, grid_dev, &flowed);
   } else if (padded_route(*p) && !g_force_generic &&
            reinterpret_cast<uintptr_t>(workspace_dev) % 256 == 0) {
     // project into padded maps at the head of the workspace, then copy the real columns out
@@ -178,7 +187,53 @@ int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float*
       if (e == hipSuccess) e = dm::run_mask_from_map(fused_dev, p->fill, fused_mask_dev, n, s);
     }
   }
+  if (e == hipSuccess && grid_dev && !flowed)       // (no fused kernel for this call: the stand-alone one)
+    e = dm::run_camera_affine_grid(*p, flow_frames, depth_dev, grid_dev, workspace_dev, s);
   if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
+extern "C" {
+
+int dm_orth_project_f32(const dm_params* p, const dm_frame* frames, const float* depth_dev,
+                        const float* value_dev, const uint8_t* valid_dev, float* out_dev,
+                        uint8_t* mask_dev, float* height_dev, float* fused_dev,
+                        uint8_t* fused_mask_dev, void* workspace_dev, size_t workspace_bytes,
+                        int32_t* status_dev, void* stream) {
+  return orth_project_impl(p, frames, depth_dev, value_dev, valid_dev, out_dev, mask_dev, height_dev, fused_dev,
+                           fused_mask_dev, workspace_dev, workspace_bytes, status_dev, stream, nullptr, nullptr);
+}
+
+int dm_orth_project_flow_f32(const dm_params* p, const dm_frame* frames, const dm_frame* flow_frames,
+                             const float* depth_dev, const uint8_t* valid_dev, float* out_dev,
+                             uint8_t* mask_dev, float* fused_dev, uint8_t* fused_mask_dev, float* grid_dev,
+                             void* workspace_dev, size_t workspace_bytes, int32_t* status_dev, void* stream) {
+  if (!p || p->vc != 0)
+    return fail(DM_ERR_INVALID_ARGUMENT, "dm_orth_project_flow_f32 projects heights (vc = 0)");
+  if (!flow_frames || !grid_dev)
+    return fail(DM_ERR_INVALID_ARGUMENT, "flow_frames / grid must not be NULL");
+  if (p->B == 0) return DM_OK;
+  return orth_project_impl(p, frames, depth_dev, nullptr, valid_dev, out_dev, mask_dev, nullptr, fused_dev,
+                           fused_mask_dev, workspace_dev, workspace_bytes, status_dev, stream, flow_frames, grid_dev);
+}
+
+int dm_frames_fill_f32(const float* static_table, int32_t B, const float* pose, const float* sin_yaw,
+                       const float* cos_yaw, float* out_table) {
+  if (!static_table || !pose || !sin_yaw || !cos_yaw || !out_table || B < 0)
+    return fail(DM_ERR_INVALID_ARGUMENT, "dm_frames_fill_f32: NULL argument or negative B");
+  static_assert(sizeof(dm_frame) == 32 * sizeof(float), "dm_frame is 32 floats");
+  memcpy(out_table, static_table, (size_t)B * sizeof(dm_frame));
+  dm_frame* f = reinterpret_cast<dm_frame*>(out_table);
+  for (int32_t b = 0; b < B; ++b) {
+    const float yaw = pose[3 * b + 2];
+    // utils.py:323-324: |angle| <= 1e-3 -> 0, i.e. sin = 0 and cos = 1 exactly
+    const bool small = (yaw < 0.0f ? -yaw : yaw) <= 0.001f;
+    const float s = small ? 0.0f : sin_yaw[b];
+    const float c = small ? 1.0f : cos_yaw[b];
+    const float d = 1.0f - (1.0f - c);          // (1 + sin * 0) + (1 - cos) * (-1), float32 (utils.py:326)
+    f[b].Ry[0] = d; f[b].Ry[2] = s; f[b].Ry[6] = -s; f[b].Ry[8] = d;
+    f[b].tx = pose[3 * b]; f[b].tz = pose[3 * b + 1];
+  }
   return DM_OK;
 }
 

@@ -31,7 +31,8 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
                       const float* value, const uint8_t* valid, float* out, uint8_t* mask,
                       float* height, float* fused, uint8_t* fused_mask, void* ws,
                       size_t ws_bytes, hipEvent_t before_projection, hipEvent_t after_projection,
-                      hipStream_t s);
+                      hipStream_t s, const dm_frame* flow_frames_host = nullptr, float* flow_grid = nullptr,
+                      bool* flow_done = nullptr);
 
 hipError_t run_window_fused(const dm_params& p, const dm_frame* frames_host, const float* depth,
                             const float* value, const uint8_t* valid, float* out, uint8_t* mask,

@@ -228,6 +228,35 @@ __device__ inline void project_point(const FastView& fv, const Cam& c, float z, 
   zf = __builtin_floorf(zf + 0.5f);
 }
 
+// camera_affine_grid of one pixel (maps.py:353-460): where a pixel with depth z and camera-space
+// coordinates (X, Y) = (ray_x * z, ray_y * z) lands in the image after the camera moved.  Chain,
+// all float32 in the reference's op order: camera_to_local_space (753-800: rp, cam_h) ->
+// local_to_global_space(trans_pose) (850-895: ry, tx, tz) -> local_to_camera_space (802-848:
+// translate by (0, -cam_h, 0), rotate by -pitch: ri) -> camera_to_image_space (684-751: z_eps =
+// z + 1e-7, x / z_eps * fx + cx, flip).  The FULL FMA chains (zero entries included): a non-finite
+// depth must give the reference's NaN / inf, which reach the output here.  One definition for the
+// stand-alone kernel (dm_points.hip) and the projection kernel that computes the flow from the
+// depth it has loaded anyway (dm_window_kernels.hpp, HAS_FLOW).
+__device__ inline void flow_pixel(float z, float X, float Y, const float (&rp)[9], float cam_h,
+                                  const float (&ry)[9], float tx, float tz, const float (&ri)[9],
+                                  float fx, float cx, float fy, float cy, bool flip_h, float Hm1,
+                                  float& u, float& w) {
+  const float x1 = __builtin_fmaf(z, rp[6], __builtin_fmaf(Y, rp[3], X * rp[0])) + 0.0f;
+  const float y1 = __builtin_fmaf(z, rp[7], __builtin_fmaf(Y, rp[4], X * rp[1])) + cam_h;
+  const float z1 = __builtin_fmaf(z, rp[8], __builtin_fmaf(Y, rp[5], X * rp[2])) + 0.0f;
+  const float x2 = __builtin_fmaf(z1, ry[6], __builtin_fmaf(y1, ry[3], x1 * ry[0])) + tx;
+  const float y2 = __builtin_fmaf(z1, ry[7], __builtin_fmaf(y1, ry[4], x1 * ry[1])) + 0.0f;
+  const float z2 = __builtin_fmaf(z1, ry[8], __builtin_fmaf(y1, ry[5], x1 * ry[2])) + tz;
+  const float x3 = x2 + 0.0f, y3 = y2 + (-cam_h), z3 = z2 + 0.0f;
+  const float xc = __builtin_fmaf(z3, ri[6], __builtin_fmaf(y3, ri[3], x3 * ri[0]));
+  const float yc = __builtin_fmaf(z3, ri[7], __builtin_fmaf(y3, ri[4], x3 * ri[1]));
+  const float zc = __builtin_fmaf(z3, ri[8], __builtin_fmaf(y3, ri[5], x3 * ri[2]));
+  const float z_eps = zc + 1e-7f;
+  u = xc / z_eps * fx + cx;
+  w = yc / z_eps * fy + cy;
+  if (flip_h) w = Hm1 - w;
+}
+
 // ---------------------------------------------------------------------------
 // order-preserving float <-> uint key: k(a) < k(b)  <=>  a < b (with -0 < +0)
 __device__ inline uint32_t f2key(float f) {

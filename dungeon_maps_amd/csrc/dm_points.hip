@@ -213,24 +213,8 @@ k_camera_affine_grid4(View v, float fx_inv, float fy_inv, int dc, GridFrames arg
     for (int j = 0; j < 4; ++j) {
       const float z = zs[j];
       const float X = div_f<FAST_DIV>((float)(q0 + j) - v.cx, v.fx, fx_inv) * z, Y = ay * z;
-      // camera -> local (maps.py:753-800)
-      const float x1 = __builtin_fmaf(z, rp[6], __builtin_fmaf(Y, rp[3], X * rp[0])) + 0.0f;
-      const float y1 = __builtin_fmaf(z, rp[7], __builtin_fmaf(Y, rp[4], X * rp[1])) + cam_h;
-      const float z1 = __builtin_fmaf(z, rp[8], __builtin_fmaf(Y, rp[5], X * rp[2])) + 0.0f;
-      // the pose transition (maps.py:850-895)
-      const float x2 = __builtin_fmaf(z1, ry[6], __builtin_fmaf(y1, ry[3], x1 * ry[0])) + tx;
-      const float y2 = __builtin_fmaf(z1, ry[7], __builtin_fmaf(y1, ry[4], x1 * ry[1])) + 0.0f;
-      const float z2 = __builtin_fmaf(z1, ry[8], __builtin_fmaf(y1, ry[5], x1 * ry[2])) + tz;
-      // local -> camera: translate first, then rotate by -pitch (maps.py:802-848)
-      const float x3 = x2 + 0.0f, y3 = y2 + (-cam_h), z3 = z2 + 0.0f;
-      const float xc = __builtin_fmaf(z3, ri[6], __builtin_fmaf(y3, ri[3], x3 * ri[0]));
-      const float yc = __builtin_fmaf(z3, ri[7], __builtin_fmaf(y3, ri[4], x3 * ri[1]));
-      const float zc = __builtin_fmaf(z3, ri[8], __builtin_fmaf(y3, ri[5], x3 * ri[2]));
-      // camera -> image (maps.py:684-751)
-      const float z_eps = zc + 1e-7f;
-      const float u = xc / z_eps * v.fx + v.cx;
-      float w = yc / z_eps * v.fy + v.cy;
-      if (v.flip_h) w = v.Hm1 - w;
+      float u, w;
+      flow_pixel(z, X, Y, rp, cam_h, ry, tx, tz, ri, v.fx, v.cx, v.fy, v.cy, v.flip_h != 0, v.Hm1, u, w);
       out[2 * j] = u; out[2 * j + 1] = w;
     }
     float4* dst = reinterpret_cast<float4*>(grid + 2 * (base + (size_t)r * v.W + q0));

@@ -250,6 +250,12 @@ StripKernel pick_strip_kernel(bool is_max, bool has_valid, bool has_value, bool 
 // Whether the fill value's stores should bypass the caches (dm_pixel.hpp kFillCachePolicy): where
 // the call's own batch fuse follows -- it reads the flushed cells and never the fill -- and where
 // the maps are larger than the Infinity Cache (256 MB) could hold on to next to the depth maps.
+// dm_debug_fill_split: where the fill duty of the map rows outside a frame's union window runs
+// (StripArgs::defer_outer / head_share).  -1: under the pixel loop with the rest (rounds 2-3);
+// 0..8: out of the loop -- that many of every eight such rows of a wave in the kernel's head, the
+// others in the combine kernel.
+constexpr int kFillSplitDefault = -1;     // (measured: no gain in the head, a loss in the combine kernel -- DESIGN)
+thread_local int g_fill_split = kFillSplitDefault;
 thread_local int g_force_nt_fill = -1;      // dm_debug_force_nt_fill: -1 the rule below, 0 never, 1 always
 inline bool nt_fill_pays(const dm_params& p, int oc_total, bool fuse_follows) {
   if (g_force_nt_fill >= 0) return g_force_nt_fill != 0;
@@ -393,6 +399,10 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const
   sa.out = out; sa.mask = mask; sa.mh = p.mh; sa.mw = p.mw;
   sa.t = l.t;
   sa.status = status;
+  // (height maps and value maps of few channels: the launch pairs whose combine kernel is
+  // k_strip_combine_one, which takes its share of the fill duty)
+  sa.defer_outer = g_fill_split >= 0 && oc_total < kListMinChannels;
+  sa.head_share = sa.defer_outer ? g_fill_split : 0;
   sa.rig = rg.args;
 #ifdef DM_STAMPS
   sa.stamps = g_stamp_buffer;
@@ -445,6 +455,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const
       ca.P = plan.P; ca.slab_stride = rg.slab_stride; ca.seg_cap = sa.seg_cap; ca.fill = fill;
       ca.g_wins = l.t.wins; ca.g_unions = l.t.unions; ca.g_counts = l.t.counts; ca.g_list = l.t.list;
       ca.slabs = l.slabs; ca.out = out; ca.mask = mask;
+      ca.defer_outer = sa.defer_outer; ca.head_share = sa.head_share;
       // grid.y = frames * channels <= 65535 per launch
       const int per_launch = 65535 / oc > 0 ? 65535 / oc : 1;
       for (int c0 = 0; c0 < nb; c0 += per_launch) {
@@ -1012,6 +1023,12 @@ extern "C" __attribute__((visibility("default"))) void dm_debug_last_fused_split
 extern "C" __attribute__((visibility("default"))) int dm_debug_force_strips(int strips) {
   const int old = dm::g_force_strips;
   dm::g_force_strips = strips > 0 && strips <= dm::strip::kMaxStrips ? strips : 0;
+  return old;
+}
+
+extern "C" __attribute__((visibility("default"))) int dm_debug_fill_split(int head_share) {
+  const int old = dm::g_fill_split;
+  dm::g_fill_split = head_share < 0 ? -1 : (head_share > 8 ? 8 : head_share);
   return old;
 }
 

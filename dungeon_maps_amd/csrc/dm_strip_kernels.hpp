@@ -197,6 +197,13 @@ struct StripArgs {
   int seg_cap;                // entries a strip's shared-group list holds
   float fill;
   int b0;                     // first frame of this launch
+  // Where the fill duty of the map rows OUTSIDE the frame's union window (whole rows of fill value:
+  // about 60 % of a 512-row map) runs.  0: with everything else under the pixel loop (rounds 2-3).
+  // 1: out of the loop, which a working set beyond the Infinity Cache makes bandwidth bound --
+  // of every eight such rows of a wave the first `head_share` are stored in the kernel's head
+  // (HBM idles there while the row tables are derived), the others by the combine kernel (a chain
+  // of dependent round trips under which HBM idles too): kFillSplit* below.
+  int defer_outer, head_share;
   const float* poses_dev;     // (B, kPoseFloats) in device memory (prepared frames), or NULL: `poses`
   const float* depth;
   const float* value;         // (B, oc_total, H, W) or NULL: project the heights
@@ -599,6 +606,27 @@ k_strip_scatter(StripArgs a) {
     }
   };
   if (P2 == 4) row_tables(std::integral_constant<int, 4>{}); else row_tables_lanes(std::integral_constant<int, 8>{});
+  // Fill duty, head share: of this wave's map rows (part + (wave + 16 j) P) those outside the union
+  // window's rows hold nothing but the fill value -- known from the geometry alone -- and those
+  // with (j & 7) < head_share are stored right here: the waves that derive no row tables have
+  // nothing to do until the barrier, and HBM has nothing to do either.  Whole rows, wave-level
+  // stores with scalar addressing (as the loop's fill steps).
+  if (MODE != kIndexOut && a.out != nullptr && a.defer_outer && a.head_share > 0) {
+    const int rows_mine = (a.mh - part + nparts - 1) / nparts;
+    const int nj = wave < rows_mine ? (rows_mine - wave + 15) >> 4 : 0;
+    const int chunks_h = (a.mw + 255) >> 8;
+    for (int j = 0; j < nj; ++j) {
+      const int z = part + (wave + 16 * j) * nparts;
+      if ((unsigned)(z - U.z0) < (unsigned)U.h || (j & 7) >= a.head_share) continue;      // (scalar)
+      for (int c = 0; c < chunks_h; ++c) {
+        const int x = (c << 8) + (lane << 2);
+        const int cell0 = z * a.mw + (c << 8);
+        buffer_store_b128_at_scalar_offset<NT_FILL ? kFillCachePolicy : 0>(
+            (u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, x < a.mw ? lane << 4 : 0x7ffffff0, cell0 << 2);
+        __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, x < a.mw ? lane << 2 : 0x7ffffff0, cell0, 0);
+      }
+    }
+  }
   DM_STAMP(8);
   // What the pixel loop reads of the kernel arguments and of the frame's pose is (re)loaded HERE,
   // through pointers the compiler cannot see through: a scalar whose live range crossed the
@@ -634,13 +662,23 @@ k_strip_scatter(StripArgs a) {
   const int fparts = nparts;
   const int fill_rows = (la->mh - part + fparts - 1) / fparts;
   const int chunks = (la->mw + 255) >> 8;
+  // this wave's rows part + (wave + 16 j) P, j in [j_lo, j_hi): all of them, or -- when the rows
+  // outside the union window are stored elsewhere (defer_outer) -- those inside its z range
+  int j_lo = 0, j_hi = wave < fill_rows ? (fill_rows - wave + 15) >> 4 : 0;
+  if (la->defer_outer) {
+    const int z_base = part + wave * fparts, stride = 16 * fparts;
+    const int a0 = U.z0 - z_base + stride - 1, a1 = U.z0 + U.h - z_base + stride - 1;
+    const int lo = a0 > 0 ? a0 / stride : 0, hi = a1 > 0 ? a1 / stride : 0;
+    j_lo = __builtin_amdgcn_readfirstlane(U.h > 0 ? min(lo, j_hi) : 0);
+    j_hi = __builtin_amdgcn_readfirstlane(U.h > 0 ? min(hi, j_hi) : 0);
+  }
 #ifdef DM_X_NOFILL2
   const int fill_steps = 0;
 #else
-  const int fill_steps = la->out != nullptr && wave < fill_rows ? ((fill_rows - wave + 15) >> 4) * chunks : 0;
+  const int fill_steps = la->out != nullptr && j_hi > j_lo ? (j_hi - j_lo) * chunks : 0;
 #endif
   const int lane4 = lane << 2;
-  int fs = 0, f_row = part + wave * fparts, f_chunk = 0;       // (wave-uniform)
+  int fs = 0, f_row = part + (wave + 16 * j_lo) * fparts, f_chunk = 0;       // (wave-uniform)
   // the reach of a map row ({0, 0} outside U's rows), read from LDS TWO steps ahead: the steps
   // come in pairs, and a value read one step ahead would make the second step of a pair wait
   // for every LDS operation in flight (one counter), the pixel loop's atomics among them
@@ -1021,6 +1059,7 @@ k_strip_scatter(StripArgs a) {
 struct StripCombineArgs {
   int b0, oc, ch0, oc_total, mh, mw;
   int P, slab_stride, seg_cap;
+  int defer_outer, head_share;      // StripArgs': the rows outside the union window this kernel fills
   float fill;
   const Win16* g_wins;
   const Win16* g_unions;
@@ -1041,6 +1080,35 @@ constexpr int kCombineThreads = 256;
 // of that chain, 200 us; with four, 80 us).
 constexpr int kCombineSlots = 32;       // (the lists hold about as many dead entries as live ones: twice the blocks of round 2)
 
+// The combine kernel's share of the fill duty (StripArgs::defer_outer): the map rows z of (frame b,
+// channel chl) outside the union window's rows [uz0, uz0 + uh) whose index among their wave's rows
+// in the scatter kernel, j = z / (16 P), has (j & 7) >= head_share.  Block x of the frame's
+// blocks takes the rows x, x + nblocks, ...; a row is stored by the block's threads as float4
+// groups + their four mask bytes.  Issued in front of the chain of round trips the combine step
+// is: the stores drain while it waits.
+__device__ inline void combine_fill_outer(const StripCombineArgs& a, int b, int chl, int uz0, int uh) {
+  const size_t fo = ((size_t)b * a.oc_total + a.ch0 + chl) * (size_t)a.mh * a.mw;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const f32x4 fv = {a.fill, a.fill, a.fill, a.fill};
+  const int groups = a.mw >> 2;
+  // (rows in flight per step: 256 threads cover 1024 cells)
+  const int rows_per_step = groups >= kCombineThreads ? 1 : kCombineThreads / groups;
+  const int sub = (int)threadIdx.x / groups, g0 = (int)threadIdx.x - sub * groups;
+  const int stride = (int)gridDim.x * rows_per_step;
+  for (int z0 = (int)blockIdx.x * rows_per_step; z0 < a.mh; z0 += stride) {
+    const int z = z0 + (rows_per_step > 1 ? sub : 0);
+    if (rows_per_step > 1 && sub >= rows_per_step) continue;
+    if (z >= a.mh || (unsigned)(z - uz0) < (unsigned)uh) continue;
+    if (((z / (16 * a.P)) & 7) < a.head_share) continue;
+    float* const row = a.out + fo + (size_t)z * a.mw;
+    uint8_t* const mrow = a.mask + fo + (size_t)z * a.mw;
+    for (int g = rows_per_step > 1 ? g0 : (int)threadIdx.x; g < groups; g += kCombineThreads) {
+      __builtin_nontemporal_store(fv, reinterpret_cast<f32x4*>(row) + g);
+      reinterpret_cast<uint32_t*>(mrow)[g] = 0u;
+    }
+  }
+}
+
 // The groups of a frame's covers that no strip owns (the strips' shared-group lists): max / min
 // over the slabs of the strips whose covers hold the group, written to the map with its mask
 // bytes.  What a block needs of the frame (count, union window, the strips' windows) is
@@ -1059,10 +1127,12 @@ k_strip_combine_one(StripCombineArgs a) {
   // (the thread's first entry is requested before the segment's length is known: one round trip
   // less in a kernel that is nothing but a chain of them)
   uint32_t entry = first < a.seg_cap ? list[first] : 0u;
-  const int listed = min(a.g_counts[(size_t)b * strip::kMaxStrips + seg], a.seg_cap);
-  if (lane_block * kCombineThreads >= listed) return;
   const int2 u_raw = *reinterpret_cast<const int2*>(a.g_unions + b);
+  const int listed = min(a.g_counts[(size_t)b * strip::kMaxStrips + seg], a.seg_cap);
   const int ux0 = (short)(u_raw.x & 0xffff), uz0 = (short)(u_raw.x >> 16);
+  if (a.defer_outer)      // this kernel's share of the map rows outside the union window: fill value, mask 0
+    combine_fill_outer(a, b, chl, uz0, (short)(u_raw.y >> 16));
+  if (lane_block * kCombineThreads >= listed) return;
   int2 wq[strip::kMaxStrips];
 #pragma unroll
   for (int q = 0; q < strip::kMaxStrips; ++q)

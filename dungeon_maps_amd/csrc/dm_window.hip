@@ -69,7 +69,8 @@ static int frames_per_chunk(int nparts) {
 static size_t geometry_bytes(int B, int nparts) {
   const int chunk = frames_per_chunk(nparts);
   return align_up((size_t)B * nparts * sizeof(Win16), 256) + align_up((size_t)B * sizeof(Win16), 256) +
-         align_up((size_t)((B + chunk - 1) / chunk) * sizeof(ScatterTables), 256);
+         align_up((size_t)((B + chunk - 1) / chunk) * sizeof(ScatterTables), 256) +
+         align_up((size_t)B * sizeof(FlowRec), 256);       // (fused ego-motion flow: dm_orth_project_flow_f32)
 }
 
 static constexpr size_t kSlabBudget = (size_t)256 << 20;   // slab bytes per channel group
@@ -103,6 +104,7 @@ struct Staged {                 // what run_window keeps between its passes
   Win16* g_wins;                // device copies (workspace head)
   Win16* g_unions;
   const ScatterTables* d_tables;  // one per chunk of frames: workspace, filled by ONE stream-ordered copy
+  FlowRec* d_flow;              // (B) flow records, behind the tables (written only by a fused flow call)
   int chunk;                    // frames per chunk
   size_t geom_bytes;
   bool fast, fast_div;
@@ -144,6 +146,20 @@ Kernel pick_kernel(int red, bool fast, bool has_valid, bool has_value, bool vec4
   return lean ? lean_table[red][has_value] : table[red][fast][has_valid][has_value][vec4];
 }
 
+Kernel pick_flow_kernel(bool is_max) {
+  return is_max ? k_window_scatter<kMax, true, false, false, 4, true, true>
+                : k_window_scatter<kMin, true, false, false, 4, true, true>;
+}
+
+thread_local int g_last_flow_fused = 0;       // dm_debug_last_flow_fused
+// dm_debug_flow_fused: whether dm_orth_project_flow_f32 lets the projection kernel compute the flow.
+// Measured at BASELINE configs[4]'s frames (16 x 1280x960 -> 2048x2048, working set beyond the
+// Infinity Cache): 213.6 us fused against 100.8 + 62.0 us for the two kernels -- the flow's two
+// IEEE divisions per pixel are dependent chains, and the projection kernel has four waves per
+// SIMD (its LDS window) to hide them where the stand-alone kernel has sixteen; the second depth
+// read the fusion saves is 79 MB, about 13 us.  So the default is the two kernels.
+thread_local int g_flow_fused = 0;
+
 // One pass: scatter `value` (or the heights when NULL) of channels [0, oc_total)
 // into out/mask, channel group by channel group, chunk of frames by chunk of frames.
 // With `fused` set, the per-frame maps are skipped (out/mask NULL) and every channel
@@ -152,8 +168,9 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
                        const float* depth, const float* value, const uint8_t* valid, float* out,
                        uint8_t* mask, int oc_total, float fill, int red, size_t slab_bytes,
                        hipStream_t s, float* fused = nullptr, uint8_t* fused_mask = nullptr,
-                       int accumulate = 0) {
+                       int accumulate = 0, float* flow_grid = nullptr, bool* flow_done = nullptr) {
   ScatterArgs sa;
+  sa.flow = nullptr; sa.flow_grid = nullptr;
   sa.W = p.W; sa.H = p.H;
   sa.clip = p.clip_border > 0 ? p.clip_border : 0;
   sa.flip_h = p.flip_h != 0;
@@ -185,7 +202,14 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
   const bool lean = st.fast && vec4 && !has_valid && p.has_dmin && p.has_dmax &&
                     isfinite(p.dmin) && isfinite(p.dmax) && !p.has_hmax && p.clip_border <= 0;
   const bool is_max = red == kMax;             // (the fuse kernels: max / min only)
-  const Kernel kfn = pick_kernel(red, st.fast, has_valid, has_value, vec4, lean);
+  // the ego-motion flow rides on the lean height projection (every pixel is visited exactly once
+  // per launch: no depth bands, one depth channel group)
+  const bool with_flow = flow_grid != nullptr && g_flow_fused && lean && !has_value && (red == kMax || red == kMin) &&
+                         st.parts.pd == 1 && reinterpret_cast<uintptr_t>(flow_grid) % 16 == 0;
+  if (flow_done) *flow_done = with_flow;
+  if (with_flow) { sa.flow = st.d_flow; sa.flow_grid = flow_grid; }
+  const Kernel kfn = with_flow ? pick_flow_kernel(is_max)
+                               : pick_kernel(red, st.fast, has_valid, has_value, vec4, lean);
   hipError_t e = hipSuccess;
   {   // raise the dynamic-LDS limit once per kernel variant and device
     static thread_local const void* done[64][8] = {};
@@ -465,6 +489,9 @@ hipError_t stage_windows(const dm_params& p, const dm_frame* frames_host, void* 
     st.g_unions = reinterpret_cast<Win16*>(base);
     base += align_up((size_t)p.B * sizeof(Win16), 256);
     st.d_tables = reinterpret_cast<const ScatterTables*>(base);
+    const int chunk_now = frames_per_chunk(st.nparts);
+    base += align_up((size_t)((p.B + chunk_now - 1) / chunk_now) * sizeof(ScatterTables), 256);
+    st.d_flow = reinterpret_cast<FlowRec*>(base);
   }
 
   recs.resize(p.B);
@@ -526,8 +553,11 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
                       const float* value, const uint8_t* valid, float* out, uint8_t* mask,
                       float* height, float* fused, uint8_t* fused_mask, void* ws,
                       size_t ws_bytes, hipEvent_t before_projection, hipEvent_t after_projection,
-                      hipStream_t s) {
+                      hipStream_t s, const dm_frame* flow_frames_host, float* flow_grid,
+                      bool* flow_done) {
   const int oc_total = p.vc ? p.vc : p.dc;
+  if (flow_done) *flow_done = false;
+  g_last_flow_fused = 0;
   if (reinterpret_cast<uintptr_t>(out) % 16 != 0 || reinterpret_cast<uintptr_t>(mask) % 4 != 0 ||
       reinterpret_cast<uintptr_t>(fused) % 16 != 0 ||
       reinterpret_cast<uintptr_t>(fused_mask) % 4 != 0 ||
@@ -560,15 +590,16 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     dm_params q = p;
     q.B = p.B / 2;
     const size_t n = (size_t)p.H * p.W, m = (size_t)p.mh * p.mw, h = q.B;
+    // (a fused ego-motion flow is not carried through the halves: the caller runs the stand-alone kernel)
     e = run_window(q, frames_host, depth, value, valid, out, mask, height, nullptr, nullptr, ws,
-                   ws_bytes, before_projection, nullptr, s);
+                   ws_bytes, before_projection, nullptr, s, nullptr, nullptr, nullptr);
     if (e == hipErrorNotSupported) shape.hopeless = 63;     // a half that does not fit or pay
     if (e != hipSuccess) return e;
     q.B = p.B - (int)h;
     e = run_window(q, frames_host + h, depth + h * p.dc * n, value ? value + h * p.vc * n : nullptr,
                       valid ? valid + h * p.valid_c * n : nullptr, out + h * oc_total * m,
                       mask + h * oc_total * m, height ? height + h * p.dc * m : nullptr, nullptr,
-                      nullptr, ws, ws_bytes, nullptr, after_projection, s);
+                      nullptr, ws, ws_bytes, nullptr, after_projection, s, nullptr, nullptr, nullptr);
     if (e == hipErrorNotSupported) shape.hopeless = 63;
     return e;
   }
@@ -584,9 +615,28 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
                   : p.reduction == DM_REDUCE_MIN ? kMin
                   : p.reduction == DM_REDUCE_SUM ? kSum
                                                  : kMean;
+  if (flow_grid && flow_frames_host && !value) {
+    // the frames' flow records (rotation and translation of the pose transition, rotate(X, -pitch)):
+    // one more stream-ordered copy, behind the tables
+    thread_local std::vector<FlowRec> frecs;
+    frecs.resize(p.B);
+    for (int b = 0; b < p.B; ++b) {
+      const dm_frame& f = flow_frames_host[b];
+      FlowRec& r = frecs[b];
+      memcpy(r.ry, f.Ry, sizeof(r.ry)); memcpy(r.ri, f.reserved, sizeof(r.ri));
+      r.tx = f.tx; r.tz = f.tz; r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = 0.0f;
+    }
+    e = hipMemcpyAsync(st.d_flow, frecs.data(), (size_t)p.B * sizeof(FlowRec), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+  } else {
+    flow_grid = nullptr;
+  }
+  bool flowed = false;
   e = window_pass(p, st, slabs, depth, value, valid, out, mask, oc_total, p.fill, red,
-                  slab_bytes, s);
+                  slab_bytes, s, nullptr, nullptr, 0, flow_grid, &flowed);
   if (e != hipSuccess) return e;
+  if (flow_done) *flow_done = flowed;
+  g_last_flow_fused = flowed ? 1 : 0;
   if (height && value) {      // maps.py:332-350: second projection, NINF fill, max
     // its mask is not returned (maps.py:340): it goes to scratch at the workspace tail
     const size_t hm = (size_t)p.B * p.dc * p.mh * p.mw;
@@ -626,6 +676,13 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
   }
 #endif
   return hipSuccess;
+}
+
+extern "C" __attribute__((visibility("default"))) int dm_debug_last_flow_fused(void) { return g_last_flow_fused; }
+extern "C" __attribute__((visibility("default"))) int dm_debug_flow_fused(int on) {
+  const int old = g_flow_fused;
+  g_flow_fused = on != 0;
+  return old;
 }
 
 // dm_orth_project_fused_f32: scatter into the LDS windows, then reduce the slabs of

@@ -61,7 +61,18 @@ struct ScatterArgs {
   float* out;
   uint8_t* mask;
   int mh, mw;
+  // HAS_FLOW: the ego-motion flow grid of the same depth maps (camera_affine_grid, maps.py:353-460)
+  // computed from the depth the projection has loaded anyway: (B) records in device memory, the
+  // grid (B, dc, H, W, 2)
+  const struct FlowRec* flow;
+  float* flow_grid;
 };
+
+// What camera_affine_grid needs of a frame beyond the projection's own record (whose pitch
+// rotation and camera height it shares): the rotation of the pose transition, its translation,
+// and rotate([1,0,0], -cam_pitch).
+struct FlowRec { float ry[9], tx, tz, ri[9], pad[4]; };
+static_assert(sizeof(FlowRec) == 96, "FlowRec layout");
 
 // (int)floorf(x) in one instruction; NaN -> 0, saturating (like v_cvt_i32_f32)
 __device__ inline int floor_to_int(float x) {
@@ -108,9 +119,13 @@ __device__ inline float combine(float a, float b) {
 //       (no border clip, no valid map): a non-finite or out-of-range pixel is then
 //       already rejected by the two depth compares, so the ordered-compare and the
 //       height compare are dropped.  (Pipeline-tail rows are poisoned through z.)
-template <int RED, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC, bool LEAN>
+// HAS_FLOW (FAST, VEC = 4, LEAN, heights, no depth bands): every pixel's ego-motion flow (flow_pixel,
+//       dm_pixel.hpp) goes to a.flow_grid beside the projection -- one depth read for both.
+template <int RED, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC, bool LEAN, bool HAS_FLOW = false>
 __global__ void __launch_bounds__(kScatterThreads)
 k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
+  static_assert(!HAS_FLOW || (FAST && VEC == 4 && LEAN && !HAS_VALUE && !HAS_VALID && !additive(RED)),
+                "the fused flow rides on the lean height projection");
   const ScatterTables& t = *tables;            // this launch's chunk of frames
   extern __shared__ float lds[];
   const int part = blockIdx.x;                 // pr-major, pc-minor
@@ -196,6 +211,23 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
                       "+s"(fr[12]), "+s"(fr[13]), "+s"(fr[14]), "+s"(fr[15]), "+s"(fr[16]),
                       "+s"(fr[17]), "+s"(fr[18]), "+s"(fr[19]), "+s"(fr[20]), "+s"(fr[21]),
                       "+s"(fr[22]));
+  }
+  // (HAS_FLOW: the frame's flow record, requested with the rest)
+  float fl_ry[9], fl_ri[9], fl_tx = 0.0f, fl_tz = 0.0f;
+  if (HAS_FLOW) {
+    // (through the constant address space and pinned: the kernel's stores to the flow grid would
+    // otherwise turn these wave-uniform loads into vector loads held in twenty VGPRs)
+    typedef const __attribute__((address_space(4))) float cfloat;
+    const uintptr_t fp = reinterpret_cast<uintptr_t>(a.flow + b);
+    cfloat* tf = (cfloat*)(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(fp >> 32)) << 32) |
+                           (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(fp & 0xffffffffu)));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { fl_ry[i] = tf[i]; fl_ri[i] = tf[11 + i]; }
+    fl_tx = tf[9]; fl_tz = tf[10];
+    asm volatile("" : "+s"(fl_ry[0]), "+s"(fl_ry[1]), "+s"(fl_ry[2]), "+s"(fl_ry[3]), "+s"(fl_ry[4]),
+                      "+s"(fl_ry[5]), "+s"(fl_ry[6]), "+s"(fl_ry[7]), "+s"(fl_ry[8]), "+s"(fl_tx), "+s"(fl_tz),
+                      "+s"(fl_ri[0]), "+s"(fl_ri[1]), "+s"(fl_ri[2]), "+s"(fl_ri[3]), "+s"(fl_ri[4]),
+                      "+s"(fl_ri[5]), "+s"(fl_ri[6]), "+s"(fl_ri[7]), "+s"(fl_ri[8]));
   }
   const Win16 w_few = {(short)(w_raw[0] & 0xffff), (short)(w_raw[0] >> 16),
                        (short)(w_raw[1] & 0xffff), (short)(w_raw[1] >> 16)};
@@ -311,8 +343,11 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
                            float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
         load_rows_at(z, sv, q, r);
       };
+      // (always_inline: called twice per pipeline trip; past a size -- the fused flow -- the inliner
+      // would leave it a function of its own, with every capture handed over through scratch)
       auto project_rows = [&](const float (&z)[kRowsInFlight][VEC],
-                              const float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r) {
+                              const float (&sv)[HAS_VALUE ? kRowsInFlight : 1][VEC], int r)
+                              __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u) {
           int rr = r + u * rows_per_iter;
@@ -338,6 +373,30 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
             // dependent-instruction issue, and the packed forms have the same rounding
             // per element as the scalar ones
             typedef float f2 __attribute__((ext_vector_type(2)));
+            if (HAS_FLOW) {
+              // The flow of the row's four pixels FIRST, two pixels at a time, each pair stored (16
+              // bytes, non-temporal) before anything else is computed -- scheduling barriers keep the
+              // compiler from interleaving it with the projection (all of it at once needs ~50 more
+              // registers than the kernel's 128).  The stand-alone kernel's arithmetic (flow_pixel)
+              // on the same X = ax * z, Y = ay * z.  (Tail rows and idle threads repeat a row: the
+              // same values to the same place.)
+              const float rp9[9] = {p0, p1, p2, p3, p4, p5, p6, p7, p8};
+              typedef float f32x4 __attribute__((ext_vector_type(4)));
+              f32x4* dst = reinterpret_cast<f32x4*>(
+                  a.flow_grid + 2 * (((size_t)b * a.dc + dch) * N + (size_t)rr * a.W + q));
+#pragma unroll
+              for (int k = 0; k < VEC; k += 2) {
+                float o4[4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                  const float zz = z[u][k + j];
+                  flow_pixel(zz, ax[k + j] * zz, ay * zz, rp9, cam_h, fl_ry, fl_tx, fl_tz, fl_ri, a.fx, a.cx,
+                             a.fy, a.cy, a.flip_h != 0, a.Hm1, o4[2 * j], o4[2 * j + 1]);
+                }
+                __builtin_nontemporal_store((f32x4){o4[0], o4[1], o4[2], o4[3]}, dst + (k >> 1));
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
 #pragma unroll
             for (int k = 0; k < VEC; k += 2) {
               const f2 zz = {z[u][k], z[u][(k + 1) % VEC]};

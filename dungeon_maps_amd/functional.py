@@ -11,6 +11,7 @@ Differences from the reference, on purpose:
 * inputs on the CPU are accepted, computed on the GPU and returned on the CPU;
   without a GPU the call raises -- there is no CPU fallback.
 """
+import ctypes
 from typing import Any, Optional, Tuple, Union
 
 import numpy as np
@@ -20,7 +21,7 @@ from . import _native, frames, utils
 from .utils import NINF, Reduction
 
 __all__ = [
-    "CenterMode", "get", "orth_project", "orth_project_and_fuse", "orth_project_fused", "fuse_batch", "mask_from_map", "camera_affine_grid",
+    "CenterMode", "get", "orth_project", "orth_project_and_fuse", "orth_project_and_flow", "orth_project_fused", "fuse_batch", "mask_from_map", "camera_affine_grid",
     "PreparedProjection", "prepare_orth_project",
     "depth_map_to_point_cloud", "height_map_to_point_cloud", "image_to_camera_space",
     "camera_to_image_space", "camera_to_local_space", "local_to_camera_space",
@@ -313,6 +314,52 @@ def orth_project_and_fuse(depth_map, value_map, valid_map, cam_pose, width_offse
                        center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
                        clip_border, to_global, flip_h, fill_value, reduction, False, device,
                        True, fused_out, out)
+
+
+def orth_project_and_flow(depth_map, trans_pose, valid_map, cam_pose, width_offset, height_offset,
+                          cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
+                          center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
+                          clip_border, to_global=True, flip_h=True, fill_value=NINF, reduction=None,
+                          device=None, out=None
+                          ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+  """``orth_project`` (heights) and ``camera_affine_grid`` of the SAME depth maps in one call:
+  ``(topdown (b,c,mh,mw), mask, grid (b,c,h,w,2))`` -- what the reference's ego-flow demo
+  computes per frame with two calls (demos/ego_flow/run.py:75-90, maps.py:127-351 and 353-460).
+  ``trans_pose`` = [x, z, yaw] is the camera's motion (``camera_affine_grid``'s argument), the
+  other arguments are ``orth_project``'s.  One native call (dm_orth_project_flow_f32): the
+  projection's launches and the flow kernel behind them; the library's LDS-window kernel for lean
+  height maps can also compute the flow from the depth it has loaded (one depth read for both,
+  ``dm_debug_flow_fused(1)``), which measured slower on MI355X than the two kernels and is off by
+  default.  Bit-identical to the two separate calls either way.  ``out`` = (float32, bool) tensors of shape
+  (b, c, mh, mw) to write the maps into."""
+  call = _Call(depth_map, None, valid_map, cam_pose, width_offset, height_offset,
+               cam_pitch, cam_height, map_res, map_width, map_height, focal_x, focal_y,
+               center_x, center_y, trunc_depth_min, trunc_depth_max, trunc_height_max,
+               clip_border, to_global, flip_h, fill_value, reduction, device)
+  p = call.params
+  B, dc, H, W = call.depth.shape
+  shape = (p.B, call.oc, p.mh, p.mw)
+  if out is not None:
+    topdown, mask = out
+    for t, dt in ((topdown, torch.float32), (mask, torch.bool)):
+      if tuple(t.shape) != shape or t.dtype != dt or t.device != call.dev or not t.is_contiguous():
+        raise ValueError(f"`out` must be contiguous {dt} {shape} tensors on {call.dev}")
+  else:
+    topdown = torch.empty(shape, dtype=torch.float32, device=call.dev)
+    mask = torch.empty(shape, dtype=torch.bool, device=call.dev)
+  flow_table = frames.build_frame_table(B, trans_pose, cam_pitch, cam_height, 0., 0., inverse_pitch=True)
+  grid = torch.empty((B, dc, H, W, 2), dtype=torch.float32, device=call.dev)
+  ws_bytes = max(call.ws_bytes, B * _native.FRAME_FLOATS * 4)
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=call.dev)
+  _native.check_status()
+  with _on_device(call.dev):
+    _native.check(_native.lib().dm_orth_project_flow_f32(
+        ctypes.byref(p), _ptr(call.frames), _ptr(flow_table), _ptr(call.depth), _ptr(call.valid),
+        _ptr(topdown), _ptr(mask), None, None, _ptr(grid), _ptr(ws), ws_bytes, _native.status_ptr(),
+        _stream_ptr(call.dev)))
+  if call.target != call.dev:
+    topdown, mask, grid = topdown.to(call.target), mask.to(call.target), grid.to(call.target)
+  return topdown, mask, grid
 
 
 def orth_project_fused(

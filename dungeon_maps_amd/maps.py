@@ -203,6 +203,7 @@ for _fn, _ref in (
     (F.orth_project, "maps.py:1406-1465"),
     (F.orth_project_and_fuse, "new: per-frame maps + batch-fused map in one call"),
     (F.orth_project_fused, "new: batch-fused partial global map"),
+    (F.orth_project_and_flow, "new: orth_project + camera_affine_grid of the same depth maps (maps.py:1406-1493)"),
     (F.camera_affine_grid, "maps.py:1467-1493"),
     (F.depth_map_to_point_cloud, "maps.py:1495-1521"),
     (F.height_map_to_point_cloud, "maps.py:1523-1543"),

@@ -90,6 +90,21 @@ typedef struct dm_frame {
 } dm_frame;
 
 /*
+ * Host-only helper: the per-call columns of a dm_frame table.  `static_table` (B, 32 floats)
+ * holds what does not change from call to call for one camera rig (pitch rotation, camera
+ * height, offsets, a neutral yaw); `pose` (B, 3) is cam_pose = (x, z, yaw); `sin_yaw` / `cos_yaw`
+ * (B) are sin / cos of the yaw column as the CALLER's libm gives them (the Python side passes
+ * torch's CPU results -- the values the reference itself computes with, utils.py:318-327 --
+ * so that no second libm is involved).  out_table = static_table with, per frame,
+ *   Ry = rotate([0,1,0], yaw) built element-wise as the reference builds it
+ *        (R = (I + sin S) + (1 - cos) S^2; |yaw| <= 1e-3 clamps to the identity, utils.py:323-324),
+ *   tx, tz = pose x, z  (maps.py:887-892).
+ * No GPU involved; returns DM_OK or DM_ERR_INVALID_ARGUMENT.
+ */
+int dm_frames_fill_f32(const float* static_table, int32_t B, const float* pose, const float* sin_yaw,
+                       const float* cos_yaw, float* out_table);
+
+/*
  * Call-wide parameters of orth_project (maps.py:127-153).
  *   depth   (B, dc, H, W)      value (B, vc, H, W) or NULL (vc = 0: project
  *   heights, maps.py:311-313)  valid (B, valid_c, H, W) uint8/bool or NULL
@@ -162,6 +177,25 @@ int dm_orth_project_fused_f32(const dm_params* p, const dm_frame* frames,
                               uint8_t* mask_dev, int accumulate,
                               void* workspace_dev, size_t workspace_bytes,
                               int32_t* status_dev, void* stream);
+
+/*
+ * orth_project and camera_affine_grid of the SAME depth maps in one call (the reference's ego-flow
+ * demo runs both on every frame, demos/ego_flow/run.py:75-90; BASELINE configs[4]): the projection
+ * of dm_orth_project_f32 (heights: p->vc = 0) plus the flow grid of dm_camera_affine_grid_f32,
+ * `flow_frames` being that entry point's frame table (the pose TRANSITION in Ry / tx / tz,
+ * rotate(X, -pitch) in reserved) and grid_dev (B, dc, H, W, 2) f32.  Where the LDS-window path's
+ * lean height kernel takes the projection (both depth bounds finite, no valid map / border /
+ * height truncation, max or min, no depth bands) that kernel CAN compute the flow of every pixel
+ * from the depth it has loaded -- one depth read for both results (dm_debug_flow_fused(1)); measured
+ * on MI355X the two kernels one after the other are the faster form (the flow's divisions want the
+ * stand-alone kernel's occupancy), so that is what runs by default.  Bit-identical results either
+ * way (dm_debug_last_flow_fused tells which ran).  Workspace: dm_orth_project_workspace_bytes(p).
+ */
+int dm_orth_project_flow_f32(const dm_params* p, const dm_frame* frames, const dm_frame* flow_frames,
+                             const float* depth_dev, const uint8_t* valid_dev, float* out_dev,
+                             uint8_t* mask_dev, float* fused_dev, uint8_t* fused_mask_dev,
+                             float* grid_dev, void* workspace_dev, size_t workspace_bytes,
+                             int32_t* status_dev, void* stream);
 
 /*
  * camera_affine_grid (maps.py:353-460): per pixel of depth (B, dc, H, W) the
@@ -383,6 +417,12 @@ int dm_debug_force_bands(int on);
  *                                column strips whatever the cost model says (0 = back to the
  *                                model); returns the previous setting.  Lets the tests run the
  *                                strip path on small images.
+ *   dm_debug_fill_split          where the strip path's projections of the calling thread store the
+ *                                fill value of the map rows outside a frame's union window: -1
+ *                                under the pixel loop with the rest of the fill duty; 0..8 out of
+ *                                the loop -- that many of every eight such rows of a wave in the
+ *                                scatter kernel's head, the others in the combine kernel (the
+ *                                default: 4).  Returns the previous setting.  Same results.
  *   dm_debug_force_nt_fill       which cache policy the strip path's fill stores of the calling
  *                                thread's projections take: 1 non-temporal, 0 the default policy,
  *                                -1 the library's own rule (non-temporal where the call's batch
@@ -427,8 +467,13 @@ int dm_debug_force_bands(int on);
  *                                the caller); returns P, 0 (not applicable) or < 0.
  */
 int dm_debug_last_path(void);
+int dm_debug_last_flow_fused(void);      /* 1: the last dm_orth_project_flow_f32 of the calling thread computed
+                                            the flow inside the projection kernel */
+int dm_debug_flow_fused(int on);         /* non-zero: dm_orth_project_flow_f32 of the calling thread fuses where it
+                                            can (default 0: two kernels); returns the previous setting */
 int dm_debug_force_legacy_window(int on);
 int dm_debug_force_strips(int strips);
+int dm_debug_fill_split(int head_share);
 int dm_debug_force_nt_fill(int mode);
 int dm_debug_strip_value_list(int on);
 size_t dm_debug_strip_slab_budget(size_t bytes);

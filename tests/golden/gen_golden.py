@@ -461,6 +461,100 @@ def g9(dmap):
   save("g9_topdownmap_queries", **pack_kwargs(cfg), **arrays)
 
 
+def g5b(dmap):
+  """Eight seeded random MapBuilder.step(merge=True) sequences of four frames (maps.py:2357-2508,
+  2181-2287): local and global step maps, height and semantic, the three centre modes, two
+  resolutions, keep_pose -- the world map (content, size, offsets) after every step."""
+  h, w = 40, 56
+  hfov, pitch, camh = np.radians(70.), np.radians(-20.), 0.88
+  arrays, meta = {}, []
+  for s in range(8):
+    rng = np.random.default_rng(5500 + s)
+    semantic = s % 2 == 1
+    to_global = bool((s >> 1) & 1)
+    mode = ("none", "origin", "camera")[s % 3]
+    res = (0.05, 0.1)[(s >> 2) & 1]
+    keep_pose = s == 5
+    mw, mh = (48, 40) if s % 4 == 0 else (64, 64)
+    cfg = dict(width=w, height=h, hfov=hfov, cam_pose=[0., 0., 0.], width_offset=mw / 2.,
+               height_offset=0. if not to_global else mh / 2., cam_pitch=pitch, cam_height=camh,
+               map_res=res, map_width=mw, map_height=mh, trunc_depth_min=0.15,
+               trunc_depth_max=5.05, clip_border=s % 3, fill_value=0. if semantic else -np.inf,
+               to_global=to_global)
+    proj = dmap.MapProjector(**cfg)
+    build = dmap.MapBuilder(map_projector=proj)
+    build.reset()
+    poses = np.stack([rng.uniform(-1.2, 1.2, 4), rng.uniform(-1.2, 1.2, 4),
+                      rng.uniform(-np.pi, np.pi, 4)], 1).astype(np.float32)
+    poses[0] = 0.
+    C = 3
+    for t in range(4):
+      depth = scene_depth(rng, h, w, hfov, pitch, camh)[None]
+      value = None
+      if semantic:
+        labels = rng.integers(0, C, size=(h, w))
+        value = np.eye(C, dtype=np.float32)[labels].transpose(2, 0, 1).copy()
+      local = build.step(depth_map=T(depth), value_map=None if value is None else T(value),
+                         cam_pose=poses[t].copy(), center_mode=mode, merge=True,
+                         keep_pose=keep_pose and t > 0)
+      wm = build.world_map
+      k = f"s{s}_"
+      arrays[k + f"depth{t}"] = depth
+      if semantic:
+        arrays[k + f"labels{t}"] = labels.astype(np.uint8)
+      arrays[k + f"local_map{t}"] = local.topdown_map.numpy().copy()
+      arrays[k + f"local_mask{t}"] = np.packbits(local.mask.numpy())
+      arrays[k + f"world_map{t}"] = wm.topdown_map.numpy().copy()
+      arrays[k + f"world_mask{t}"] = np.packbits(wm.mask.numpy())
+      arrays[k + f"world_height{t}"] = wm.height_map.contiguous().numpy()[:, :1].copy()
+      arrays[k + f"world_woff{t}"] = np.asarray(wm.proj.width_offset, dtype=np.float32)
+      arrays[k + f"world_hoff{t}"] = np.asarray(wm.proj.height_offset, dtype=np.float32)
+      arrays[k + f"world_size{t}"] = np.array([wm.proj.map_width, wm.proj.map_height])
+      arrays[k + f"world_pose{t}"] = np.asarray(wm.proj.cam_pose, dtype=np.float32).reshape(-1)
+    arrays[f"s{s}_poses"] = poses
+    meta.append([int(semantic), int(to_global), ("none", "origin", "camera").index(mode),
+                 int(round(res * 100)), int(keep_pose), mw, mh, s % 3])
+  save("g5b_builder_random_sequences", meta=np.asarray(meta), height=np.int64(h), width=np.int64(w),
+       hfov=np.float64(hfov), pitch=np.float64(pitch), cam_height=np.float64(camh), **arrays)
+
+
+def g9b(dmap):
+  """TopdownMap.select on a 2048 x 2048 map (BASELINE configs[4]'s map size; maps.py:1959-2037,
+  utils.py:571-652): 1024 x 1024 and odd-sized crops at integral, fractional and out-of-range
+  centres.  The map is regenerated from the seed by the test; the fixture keeps every 8th
+  row / column of each crop plus its checksum and the shifted offsets."""
+  seed, n, stride = 9009, 2048, 8
+  rng = np.random.default_rng(seed)
+  top = rng.uniform(-1.0, 3.0, (1, 1, n, n)).astype(np.float32)
+  mask = rng.uniform(size=(1, 1, n, n)) > 0.35
+  top[~mask] = -np.inf
+  cfg = dict(width=1280, height=960, hfov=np.radians(70.), cam_pose=[0.4, -0.3, 0.7],
+             width_offset=1024., height_offset=1024., cam_pitch=np.radians(-20.),
+             cam_height=0.88, map_res=0.03, map_width=n, map_height=n, to_global=True,
+             fill_value=-np.inf)
+  proj = dmap.MapProjector(**cfg)
+  tm = dmap.TopdownMap(topdown_map=T(top), mask=torch.from_numpy(mask), height_map=T(top),
+                       map_projector=proj)
+  arrays = {}
+  cases = [([1024., 1024.], 1024, 1024), ([1037.25, 991.75], 1024, 1024), ([100.5, 2000.49], 1024, 1024),
+           ([-300., 2500.], 1024, 1024), ([1500.5, 700.5], 777, 1001), ([2047., 0.], 512, 2048)]
+  for i, (center, cw, ch) in enumerate(cases):
+    crop = tm.select(T([center]), cw, ch)
+    cm, ck = crop.topdown_map.numpy(), crop.mask.numpy()
+    arrays[f"c{i}_center"] = np.asarray(center, dtype=np.float32)
+    arrays[f"c{i}_size"] = np.array([cw, ch])
+    arrays[f"c{i}_map"] = cm[:, :, ::stride, ::stride].copy()
+    arrays[f"c{i}_mask"] = ck[:, :, ::stride, ::stride].copy()
+    finite = np.isfinite(cm)
+    arrays[f"c{i}_sum"] = np.float64(cm[finite].astype(np.float64).sum())
+    arrays[f"c{i}_cells"] = np.array([int(finite.sum()), int(ck.sum())])
+    arrays[f"c{i}_woff"] = np.asarray(crop.proj.width_offset, dtype=np.float32)
+    arrays[f"c{i}_hoff"] = np.asarray(crop.proj.height_offset, dtype=np.float32)
+  save("g9b_crop_2048_sampled", **pack_kwargs(cfg), seed=np.int64(seed), stride=np.int64(stride),
+       ncases=np.int64(len(cases)), top_checksum=np.float64(top[np.isfinite(top)].astype(np.float64).sum()),
+       **arrays)
+
+
 def g10(dmap):
   """Docstring known answers (utils.py:340-351, 62-67; maps.py:34-39) and
   Rodrigues matrices / intrinsics as the reference computes them."""
@@ -572,6 +666,10 @@ def main():
   torch.set_num_threads(1)
   torch.manual_seed(0)
   dmap = _import_reference()
+  if os.environ.get("DM_GOLDEN_ONLY"):       # e.g. DM_GOLDEN_ONLY=g5b,g9b: only these fixtures
+    for name in os.environ["DM_GOLDEN_ONLY"].split(","):
+      globals()[name](dmap)
+    return
   g1_g2(dmap)
   g3(dmap)
   g4(dmap)
@@ -581,6 +679,8 @@ def main():
   g8(dmap)
   g8b(dmap)
   g9(dmap)
+  g5b(dmap)
+  g9b(dmap)
   g10(dmap)
   g11(dmap)
   g12(dmap)

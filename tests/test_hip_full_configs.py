@@ -123,6 +123,84 @@ def test_cfg5_ego_flow_grid_1280x960(dmap):
   assert torch.equal(g4[3:4], grid)
 
 
+def _same_bits(a, b):
+  return torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_projection_and_flow_in_one_kernel(dmap, oracle):
+  """orth_project_and_flow (dm_orth_project_flow_f32): at BASELINE configs[4]'s frame size the window
+  path's lean height kernel computes the ego-motion flow from the depth it loads -- maps and grid
+  bit-equal to the two separate calls (edge depths included: NaN / inf / 0 / negative reach the
+  grid), the grid equal to the reference's own (fixture g8b), the maps to the oracle; calls the
+  fused kernel does not take (valid map, strip-path shapes) run the two kernels and give the same."""
+  from dungeon_maps_amd import _native
+  lib = _native.lib()
+  g, gcfg = load_golden("g8b_camera_affine_grid_1280x960_sampled")
+  H, W, stride = int(gcfg["height"]), int(gcfg["width"]), int(g["stride"])
+  mh = mw = 2048
+  d0 = np.random.default_rng(int(g["seed"])).uniform(0.1, 10.0, (1, 1, H, W)).astype(np.float32)
+  rng = np.random.default_rng(55)
+  more = rng.uniform(0.1, 10.0, (2, 1, H, W)).astype(np.float32)
+  flat = more.reshape(-1)
+  idx = rng.integers(0, flat.size, 4000)
+  flat[idx[:1000]] = np.nan; flat[idx[1000:2000]] = np.inf; flat[idx[2000:3000]] = 0.0; flat[idx[3000:]] *= -1.0
+  depth = torch.from_numpy(np.concatenate([d0, more])).cuda()
+  B = depth.shape[0]
+  pose = torch.tensor([[0.3, -0.2, 0.5], [-0.8, 0.6, -2.0], [0.1, 0.9, 3.0]])
+  tp = torch.tensor(g["trans_pose"]).repeat(B, 1)
+  tp[2] = torch.tensor([-0.2, 0.15, -0.4])
+  cfg = _cfg(H, W, mh, mw, -np.inf)
+  proj = dmap.MapProjector(**cfg)
+  # the default: one native call, two kernels (the faster form on MI355X)
+  top0, mask0, grid0 = proj.orth_project_and_flow(depth, tp, cam_pose=pose)
+  assert lib.dm_debug_last_flow_fused() == 0
+  lib.dm_debug_flow_fused(1)
+  try:
+    _fused_flow_checks(dmap, lib, oracle, proj, cfg, depth, pose, tp, g, stride, rng, top0, mask0, grid0)
+  finally:
+    lib.dm_debug_flow_fused(0)
+
+
+def _fused_flow_checks(dmap, lib, oracle, proj, cfg, depth, pose, tp, g, stride, rng, top0, mask0, grid0):
+  B, _, H, W = depth.shape
+  mh, mw = cfg["map_height"], cfg["map_width"]
+  top, mask, grid = proj.orth_project_and_flow(depth, tp, cam_pose=pose)
+  assert lib.dm_debug_last_flow_fused() == 1, "expected the fused kernel at this shape"
+  assert torch.equal(top, top0) and torch.equal(mask, mask0) and _same_bits(grid, grid0)
+  top2, mask2 = proj.orth_project(depth, cam_pose=pose)
+  grid2 = proj.camera_affine_grid(depth, tp)
+  torch.cuda.synchronize()
+  assert torch.equal(top, top2) and torch.equal(mask, mask2)
+  assert _same_bits(grid, grid2)
+  np.testing.assert_array_equal(grid[:1].cpu().numpy()[:, :, ::stride, ::stride], g["grid_sampled"])
+  want = oracle.orth_project(depth[:1].cpu().numpy(), nthreads=8,
+                             **dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose[:1].numpy()))
+  np.testing.assert_array_equal(mask[:1].cpu().numpy(), want[1])
+  np.testing.assert_array_equal(top[:1].cpu().numpy(), want[0])
+  # min reduction, caller-owned outputs
+  outs = (torch.empty(B, 1, mh, mw, device="cuda"), torch.empty(B, 1, mh, mw, dtype=torch.bool, device="cuda"))
+  t3, m3, g3 = proj.orth_project_and_flow(depth, tp, cam_pose=pose, reduction="min", fill_value=np.inf, out=outs)
+  assert lib.dm_debug_last_flow_fused() == 1 and t3 is outs[0]
+  t4, m4 = proj.orth_project(depth, cam_pose=pose, reduction="min", fill_value=np.inf)
+  assert torch.equal(t3, t4) and torch.equal(m3, m4) and _same_bits(g3, grid2)
+  # a valid map keeps the projection off the lean kernel: two kernels, same results
+  valid = torch.from_numpy(rng.uniform(size=(B, 1, H, W)) > 0.2).cuda()
+  t5, m5, g5 = proj.orth_project_and_flow(depth, tp, valid_map=valid, cam_pose=pose)
+  assert lib.dm_debug_last_flow_fused() == 0
+  t6, m6 = proj.orth_project(depth, valid_map=valid, cam_pose=pose)
+  assert torch.equal(t5, t6) and torch.equal(m5, m6) and _same_bits(g5, grid2)
+  # a shape the strip path takes (BASELINE configs[1]'s frames): not fused, same results
+  Hs, Ws = 480, 640
+  ds = torch.from_numpy(rng.uniform(0.1, 10.0, (64, 1, Hs, Ws)).astype(np.float32)).cuda()
+  ps = torch.from_numpy(np.stack([rng.uniform(-1, 1, 64), rng.uniform(-1, 1, 64), rng.uniform(-np.pi, np.pi, 64)], 1).astype(np.float32))
+  projs = dmap.MapProjector(**_cfg(Hs, Ws, 512, 512, -np.inf))
+  t7, m7, g7 = projs.orth_project_and_flow(ds, [0.05, 0.1, 0.02], cam_pose=ps)
+  assert lib.dm_debug_last_path() == 2 and lib.dm_debug_last_flow_fused() == 0
+  t8, m8 = projs.orth_project(ds, cam_pose=ps)
+  assert torch.equal(t7, t8) and torch.equal(m7, m8)
+  assert _same_bits(g7, projs.camera_affine_grid(ds, [0.05, 0.1, 0.02]))
+
+
 def _bench(args, launcher):
   env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
   cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py")] + args

@@ -12,6 +12,8 @@ g = torch.Generator().manual_seed(1234)
 ROT = int(os.environ.get("DM_STAMPS_ROT", "1"))     # depth batches / output blocks in rotation (> 256 MiB live: HBM-served)
 depths = [torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g).cuda() for _ in range(ROT)]
 depth = depths[0]
+if os.environ.get("DM_STAMPS_FILL_SPLIT"):
+  _native.lib().dm_debug_fill_split(int(os.environ["DM_STAMPS_FILL_SPLIT"]))
 if os.environ.get("DM_STAMPS_NT"):
   _native.lib().dm_debug_force_nt_fill(int(os.environ["DM_STAMPS_NT"]))
 pose = torch.empty(B, 3).uniform_(-1, 1, generator=g); pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)

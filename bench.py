@@ -466,7 +466,7 @@ def main():
     on_strips = lib.dm_debug_last_path() == 2
     result["roofline"]["kernel"] = (
         "dm_orth_project_fused_f32 launch sequence: "
-        + (f"k_strip_fused ({split[0]} strips of {split[1]} columns, groups of {split[2]} frames) + k_fuse_windows"
+        + (f"k_strip_fused ({split[1]} strips of {split[0]} columns, {split[3]} groups of {split[2]} frame(s)) + k_fuse_windows"
            if on_strips else "k_window_scatter + k_fuse_windows (window path)"))
     result["config"]["workload"] = (f"cfg4: B={B}/GPU, {W}x{H} depth fused straight into one "
                                     f"{mw}x{mh} global map (max)"

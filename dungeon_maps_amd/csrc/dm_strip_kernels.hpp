@@ -259,7 +259,10 @@ k_strip_scatter(StripArgs a) {
   // fill steps (wave-level, 1 KB each) per pipeline half-iteration: three or four make every wait for
   // the depth loads wait for older stores too (+2 us per extra step at cfg2), none or one moves
   // the stores behind the loop for the same total
-  constexpr int kStripFillPerHalf = 2;
+#ifndef DM_X_FILL_PER_HALF
+#define DM_X_FILL_PER_HALF 2
+#endif
+  constexpr int kStripFillPerHalf = DM_X_FILL_PER_HALF;
   extern __shared__ float lds[];
   // (the value pass runs channel-major: the workgroups of one (frame, strip) -- which read the same
   // part of the pixel list -- are dispatched together)
@@ -1078,7 +1081,10 @@ constexpr int kCombineThreads = 256;
 // blocks per frame: the kernel is one chain of round trips), four for value maps of many channels
 // (the chip holds 2 K blocks at a time: with one entry per thread 40 channels were twenty rounds
 // of that chain, 200 us; with four, 80 us).
-constexpr int kCombineSlots = 32;       // (the lists hold about as many dead entries as live ones: twice the blocks of round 2)
+#ifndef DM_X_COMBINE_SLOTS
+#define DM_X_COMBINE_SLOTS 32
+#endif
+constexpr int kCombineSlots = DM_X_COMBINE_SLOTS;       // (the lists hold about as many dead entries as live ones: twice the blocks of round 2)
 
 // The combine kernel's share of the fill duty (StripArgs::defer_outer): the map rows z of (frame b,
 // channel chl) outside the union window's rows [uz0, uz0 + uh) whose index among their wave's rows

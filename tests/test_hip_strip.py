@@ -154,7 +154,7 @@ def test_value_list_path_was_exercised(dmap):
 
 def test_cfg2_full_size_strip_path_vs_oracle(dmap, oracle):
   """BASELINE configs[1] at full size through the strip path (the path bench.py measures):
-  64 x 640x480 -> 512x512 against the oracle on 8 of the frames, and == the generic path on all."""
+  64 x 640x480 -> 512x512 against the oracle on ALL 64 frames, and == the generic path on all."""
   lib = _lib()
   B, H, W, mh, mw = 64, 480, 640, 512, 512
   g = torch.Generator().manual_seed(1234)
@@ -170,11 +170,15 @@ def test_cfg2_full_size_strip_path_vs_oracle(dmap, oracle):
   top, mask, fused, fmask = proj.orth_project_and_fuse(d, cam_pose=pose)
   assert lib.dm_debug_last_path() == 2
   torch.cuda.synchronize()
-  idx = [0, 1, 7, 13, 31, 32, 50, 63]
-  want = oracle.orth_project(depth[idx].numpy(), nthreads=8,
-                             **dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose[idx].numpy()))
-  np.testing.assert_array_equal(mask[idx].cpu().numpy(), want[1])
-  np.testing.assert_array_equal(top[idx].cpu().numpy(), want[0])
+  want = oracle.orth_project(depth.numpy(), nthreads=16,
+                             **dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose.numpy()))
+  np.testing.assert_array_equal(mask.cpu().numpy(), want[1])
+  np.testing.assert_array_equal(top.cpu().numpy(), want[0])
+  # the batch-fused map against the oracle's own fusion of the same frames
+  fwant = oracle.orth_project(depth.numpy(), nthreads=16, fused=True,
+                              **dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose.numpy()))
+  np.testing.assert_array_equal(fmask.cpu().numpy(), fwant[1])
+  np.testing.assert_array_equal(fused.cpu().numpy(), fwant[0])
   lib.dm_debug_force_generic_path(1)
   try:
     gtop, gmask, gfused, gfmask = proj.orth_project_and_fuse(d, cam_pose=pose)

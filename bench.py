@@ -418,7 +418,7 @@ def main():
           "working_set": f"{rot} depth batches and {rot} caller-owned output sets in rotation "
                          f"({rot * alg / 2**20:.0f} MiB live: beyond the 256 MiB Infinity Cache)"
                          if rot > 1 else "one depth batch, one output set",
-          "parallelism": f"frames sharded {world}-way; fused maps all-reduced (RCCL max) "
+          "parallelism": f"frames sharded {world}-way; fused maps all-reduced ({'RCCL' if backend == 'nccl' else backend} max) "
                          f"{RING_MAX} steps at a time, overlapped with the next steps"
                          if dist is not None else "single GPU",
       },

@@ -259,7 +259,11 @@ thread_local int g_fill_split = kFillSplitDefault;
 thread_local int g_force_nt_fill = -1;      // dm_debug_force_nt_fill: -1 the rule below, 0 never, 1 always
 inline bool nt_fill_pays(const dm_params& p, int oc_total, bool fuse_follows) {
   if (g_force_nt_fill >= 0) return g_force_nt_fill != 0;
-  return fuse_follows || (size_t)p.B * oc_total * p.mh * p.mw * 5 > ((size_t)128 << 20);
+  // the streaming variant (fill stores and depth loads non-temporal): where the call's own batch fuse
+  // follows, or where what the call reads and writes once -- depth maps + maps + masks -- is more than the
+  // Infinity Cache could keep beside anything else (half of its 256 MiB)
+  const size_t once = (size_t)p.B * p.dc * p.H * p.W * 4 + (size_t)p.B * oc_total * p.mh * p.mw * 5;
+  return fuse_follows || once > ((size_t)128 << 20);
 }
 
 

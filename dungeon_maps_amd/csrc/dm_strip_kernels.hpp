@@ -241,6 +241,20 @@ struct StripArgs {
 //   kFromList    the value pass, one workgroup per (strip, channel, frame): cells from the list,
 //                values from the channel's image -- 8 + 16 bytes per thread and row, four
 //                instructions per pixel instead of twenty, four rows in flight.
+// (measurement switches: cache policy of the depth loads / value loads / the fill duty's mask stores; 0 = the
+// kernel's own choice or the default policy, 2 = nt)
+#ifndef DM_X_DEPTH_POLICY
+#define DM_X_DEPTH_POLICY 0
+#endif
+#ifndef DM_X_VALUE_POLICY
+#define DM_X_VALUE_POLICY 0
+#endif
+#ifndef DM_X_FLUSH_POLICY
+#define DM_X_FLUSH_POLICY 0
+#endif
+#ifndef DM_X_MASK_POLICY
+#define DM_X_MASK_POLICY 0
+#endif
 enum { kProject = 0, kIndexOut = 1, kFromList = 2 };
 template <int RED, bool HAS_VALID, bool HAS_VALUE, bool LEAN, int MODE = kProject, bool NT_FILL = true>
 __global__ void __launch_bounds__(kScatterThreads)
@@ -256,6 +270,15 @@ k_strip_scatter(StripArgs a) {
   // alike): the window reduces the raw heights from the reduction's identity, and the flush
   // turns a cell into combine(fill, cell + cam_h) -- which is the fill value where nothing landed.
   constexpr bool kDeferCamH = !HAS_VALUE && LEAN && MODE == kProject;
+  // Cache policy of the depth loads: non-temporal in the streaming variant (NT_FILL: the host picks it where
+  // the call's bytes cannot stay cache resident anyway, dm_strip.hip streaming_call).  A depth map is read
+  // once per call; loaded under the default policy it evicts what IS read again soon (slabs, lists, the
+  // cells the batch fuse reads) -- HBM-served cfg2 launch sequence 50.0-50.5 -> 48.1 us, 54.0 -> 49.0 on a
+  // slower box (round 4).  Not in the other kernels: the value pass's values measured slower non-temporal
+  // (cfg3 1 473 -> 1 545 us), k_strip_fused no different, and the window path's projection is followed by
+  // the ego-motion flow kernel, which finds the depth maps in the Infinity Cache only under the default
+  // policy (cfg5 flow call 153 -> 176 us).
+  constexpr int kDepthPolicy = DM_X_DEPTH_POLICY ? DM_X_DEPTH_POLICY : ((NT_FILL && MODE == kProject) ? 2 : 0);
   // fill steps (wave-level, 1 KB each) per pipeline half-iteration: three or four make every wait for
   // the depth loads wait for older stores too (+2 us per extra step at cfg2), none or one moves
   // the stores behind the loop for the same total
@@ -311,7 +334,7 @@ k_strip_scatter(StripArgs a) {
         const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(rs_list, (__mul24(rr, a.wp) + (q - q0)) << 1, 0, 0);
         z[u][0] = __uint_as_float(c.x); z[u][1] = __uint_as_float(c.y);
       } else {
-        const f32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_depth, at << 2, 0, 0);
+        const f32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_depth, at << 2, 0, kDepthPolicy);
         z[u][0] = t.x; z[u][1] = t.y; z[u][2] = t.z; z[u][3] = t.w;
       }
       if (HAS_VALID && MODE != kFromList) {                         // (four bools at once: q is a multiple of 4)
@@ -321,7 +344,7 @@ k_strip_scatter(StripArgs a) {
           z[u][k] = ((ok4 >> (8 * k)) & 0xffu) ? z[u][k] : qnan;
       }
       if (HAS_VALUE) {
-        const f32x4 s = __builtin_amdgcn_raw_buffer_load_b128(rs_value, at << 2, 0, 0);
+        const f32x4 s = __builtin_amdgcn_raw_buffer_load_b128(rs_value, at << 2, 0, DM_X_VALUE_POLICY);
         sv[u][0] = s.x; sv[u][1] = s.y; sv[u][2] = s.z; sv[u][3] = s.w;
       }
     }
@@ -710,7 +733,7 @@ k_strip_scatter(StripArgs a) {
     const int cell0 = __builtin_amdgcn_readfirstlane(live ? f_row * la->mw + (f_chunk << 8) : 0);
     buffer_store_b128_at_scalar_offset<NT_FILL ? kFillCachePolicy : 0>(
         (u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, skip ? 0x7ffffff0 : lane4 << 2, cell0 << 2);
-    __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, skip ? 0x7ffffff0 : lane4, cell0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, skip ? 0x7ffffff0 : lane4, cell0, DM_X_MASK_POLICY);
     ++fs;
     advance(f_row, f_chunk);
     f_reach = f_reach1;
@@ -1022,7 +1045,7 @@ k_strip_scatter(StripArgs a) {
           }
           if (mine) {
             const int cell = z * fa->mw + x;
-            __builtin_amdgcn_raw_buffer_store_b128((f32x4){v.x, v.y, v.z, v.w}, rs_out, cell << 2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128((f32x4){v.x, v.y, v.z, v.w}, rs_out, cell << 2, 0, DM_X_FLUSH_POLICY);
             __builtin_amdgcn_raw_buffer_store_b32(
                 (uint32_t)mask_of(v.x, fa->fill) | ((uint32_t)mask_of(v.y, fa->fill) << 8) |
                 ((uint32_t)mask_of(v.z, fa->fill) << 16) | ((uint32_t)mask_of(v.w, fa->fill) << 24), rs_mask, cell, 0, 0);

@@ -204,8 +204,13 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
   const bool is_max = red == kMax;             // (the fuse kernels: max / min only)
   // the ego-motion flow rides on the lean height projection (every pixel is visited exactly once
   // per launch: no depth bands, one depth channel group)
-  const bool with_flow = flow_grid != nullptr && g_flow_fused && lean && !has_value && (red == kMax || red == kMin) &&
-                         st.parts.pd == 1 && reinterpret_cast<uintptr_t>(flow_grid) % 16 == 0;
+  bool with_flow = flow_grid != nullptr && g_flow_fused && lean && !has_value && (red == kMax || red == kMin) &&
+                   st.parts.pd == 1 && reinterpret_cast<uintptr_t>(flow_grid) % 16 == 0;
+  // (a part whose window is empty -- its pixels cannot reach the map -- leaves the kernel in front of the
+  // pixel loop, and with it the flow of its pixels: such a call takes the stand-alone kernel.  Found by the
+  // parity campaign's flow mode, round 4.)
+  for (size_t i = 0; with_flow && i < (size_t)p.B * st.nparts; ++i)
+    with_flow = (int)st.wins[i].w * st.wins[i].h > 0;
   if (flow_done) *flow_done = with_flow;
   if (with_flow) { sa.flow = st.d_flow; sa.flow_grid = flow_grid; }
   const Kernel kfn = with_flow ? pick_flow_kernel(is_max)

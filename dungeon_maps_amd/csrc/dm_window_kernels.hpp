@@ -166,7 +166,12 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
       int rr = r + u * rows_per_iter;
       rr = rr < r1 ? rr : r1 - 1;
       if (VEC == 4) {
+#if defined(DM_X_DEPTH_POLICY) && DM_X_DEPTH_POLICY == 2
+        typedef float wf32x4 __attribute__((ext_vector_type(4)));
+        const wf32x4 t = __builtin_nontemporal_load(reinterpret_cast<const wf32x4*>(dimg + (size_t)rr * a.W + q));
+#else
         const float4 t = *reinterpret_cast<const float4*>(dimg + (size_t)rr * a.W + q);
+#endif
         z[u][0] = t.x; z[u][1 % VEC] = t.y; z[u][2 % VEC] = t.z; z[u][3 % VEC] = t.w;
       } else {
         z[u][0] = dimg[(size_t)rr * a.W + q];

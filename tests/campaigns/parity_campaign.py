@@ -17,6 +17,10 @@ in profiles/r03_parity_campaigns.log):
                          heights: order-dependent float sums, rtol = atol = 1e-5)
   DM_CAMPAIGN_OFFSETS    one map offset and one camera height per frame
   DM_CAMPAIGN_DC         depth maps of two or three channels (one map channel each), valid maps shared or per channel
+  DM_CAMPAIGN_FILL_SPLIT where the strip path's fill duty of the rows outside a frame's union window runs, at random per
+                         configuration (dm_debug_fill_split: under the loop / kernel head / combine kernel)
+  DM_CAMPAIGN_FLOW       height maps through orth_project_and_flow (dm_orth_project_flow_f32), the one-kernel form switched
+                         on at random: maps against the oracle, the flow grid against camera_affine_grid bit for bit
   DM_CAMPAIGN_SEMANTIC=0 no value maps;  DM_CAMPAIGN_EDGE=0 no NaN / inf depths, no missing truncations
   DM_CAMPAIGN_VERBOSE    print the configuration and the first differing cells"""
 import ctypes, os, sys
@@ -95,7 +99,7 @@ def one(seed):
       valid = rng.uniform(size=(B, dcs, H, W)) > 0.1
   value = None
   if SUM:       # point counts per class: small integers, exact in float32 whatever the order
-    cfg["reduction"] = os.environ["DM_CAMPAIGN_SUM"] if os.environ["DM_CAMPAIGN_SUM"] in ("mean", "prod") else "sum"
+    cfg["reduction"] = SUM_KIND if SUM_KIND in ("mean", "prod") else "sum"
     cfg["fill_value"] = float(rng.choice([0.0, 1.0, 5.0]))
   C = int(rng.choice([0, 0, 3, 9])) if SEMANTIC and not FUSED and not DC else 0
   if DC and SEMANTIC and not FUSED and not SUM and rng.integers(2):
@@ -133,11 +137,14 @@ def one(seed):
     return bad_m, bad_v, (B, H, W, mh, mw, res, tuple(split))
   if ONE_PITCH:      # any number of column strips, whatever the cost model says (the strip path's own hook)
     LIB.dm_debug_force_strips(int(rng.integers(0, 9)))
+  if FILL_SPLIT:
+    LIB.dm_debug_fill_split(int(rng.choice([-1, 0, 3, 5, 8])))
   d_dev = torch.from_numpy(depth).cuda()
   v_dev = None if value is None else torch.from_numpy(value).cuda()
   m_dev = None if valid is None else torch.from_numpy(valid).cuda()
   how = int(rng.integers(3)) if CALLS else 0
   fused_pair = None
+  flow_bad = 0
   if how == 1 and cfg["reduction"] in ("max", "min"):      # per-frame maps + the batch-fused map in one call
     top, msk, fo, fm = proj.orth_project_and_fuse(d_dev, value_map=v_dev, valid_map=m_dev, cam_pose=pose)
     outs = (top, msk)
@@ -155,6 +162,19 @@ def one(seed):
       outs = prep.orth_project(d_dev, value_map=v_dev, valid_map=m_dev, get_height_map=get_h)
     else:
       outs = proj.orth_project(d_dev, value_map=v_dev, valid_map=m_dev, cam_pose=pose, get_height_map=get_h)
+  elif FLOW and value is None and cfg["reduction"] in ("max", "min"):
+    tp = np.stack([rng.uniform(-0.3, 0.3, B), rng.uniform(-0.3, 0.3, B), rng.uniform(-0.5, 0.5, B)], axis=1).astype(np.float32)
+    LIB.dm_debug_flow_fused(int(rng.integers(2)))
+    try:
+      top, msk, grid = proj.orth_project_and_flow(d_dev, tp, valid_map=m_dev, cam_pose=pose)
+      STATS["flow_fused"] = STATS.get("flow_fused", 0) + LIB.dm_debug_last_flow_fused()
+    finally:
+      LIB.dm_debug_flow_fused(0)
+    alone = proj.camera_affine_grid(d_dev, tp)
+    if not torch.equal(grid.view(torch.int32), alone.view(torch.int32)):
+      flow_bad = int((grid.view(torch.int32) != alone.view(torch.int32)).sum())
+    outs = (top, msk)
+    get_h = False
   else:
     outs = proj.orth_project(d_dev, value_map=v_dev, valid_map=m_dev, cam_pose=pose, get_height_map=get_h)
   split = (ctypes.c_int32 * 4)()
@@ -167,7 +187,7 @@ def one(seed):
                              nthreads=16, **kw)
   got = [o.cpu().numpy() for o in outs]
   bad_m = int((got[1] != want[1]).sum())
-  bad_v = 0
+  bad_v = flow_bad
   if fused_pair is not None:
     wf = want[0].max(axis=0) if cfg["reduction"] == "max" else want[0].min(axis=0)
     bad_m += int((fused_pair[1] != want[1].any(axis=0)).sum())
@@ -190,35 +210,56 @@ def one(seed):
     bad_m = 0                               # a sum that lands on the fill value by rounding
   return bad_m, bad_v, (B, H, W, mh, mw, res, C)
 
-ODD = os.environ.get("DM_CAMPAIGN_ODD", "0") != "0"      # odd map widths
-SUM = os.environ.get("DM_CAMPAIGN_SUM", "0") != "0"      # reduction='sum' of one-hot values
-FINE = os.environ.get("DM_CAMPAIGN_FINE", "0") != "0"    # fine map_res: depth bands (forced)
-ONE_PITCH = os.environ.get("DM_CAMPAIGN_ONE_PITCH", "0") != "0"   # one pitch per batch + forced strips: the strip path
-OFFSETS = os.environ.get("DM_CAMPAIGN_OFFSETS", "0") != "0"    # per-frame map offsets and camera heights
-DC = os.environ.get("DM_CAMPAIGN_DC", "0") != "0"          # depth maps of two or three channels
-BIG = os.environ.get("DM_CAMPAIGN_BIG", "0") != "0"        # 240x320 .. 480x640 frames, maps up to 768x768, up to 70 frames
-CALLS = os.environ.get("DM_CAMPAIGN_CALLS", "0") != "0"    # a third of the calls through orth_project_and_fuse, a third through prepared frames
-FUSED = os.environ.get("DM_CAMPAIGN_FUSED", "0") != "0"    # orth_project_fused (one map for the whole batch), forced strips x frame groups
+_MODES = ("ODD", "SUM", "FINE", "ONE_PITCH", "OFFSETS", "DC", "BIG", "CALLS", "FUSED", "FILL_SPLIT", "FLOW")
 STATS = {"banded": 0, "generic": 0, "strip": 0}
 from dungeon_maps_amd import _native
 LIB = _native.lib()
-LIB.dm_debug_force_bands(1 if FINE else 0)
-SEMANTIC = os.environ.get("DM_CAMPAIGN_SEMANTIC", "1") != "0"
-EDGE = os.environ.get("DM_CAMPAIGN_EDGE", "1") != "0"      # NaN/inf depths, missing truncations
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-bad = 0
-for s in range(first, first + count):
-  try:
-    bm, bv, shape = one(s)
-  except Exception:
-    print("EXCEPTION at seed", s, flush=True)
-    raise
-  if bm or bv:
-    bad += 1
-    print("MISMATCH seed", s, shape, "mask cells", bm, "map cells", bv, flush=True)
-  if (s - first) % 50 == 49:
-    print("  ... %d configurations, %d with mismatches" % (s - first + 1, bad), flush=True)
-print("done: %d configurations, %d with mismatches (%d took the strip path, %d depth bands, %d the generic path%s)"
-      % (count, bad, STATS["strip"], STATS["banded"], STATS["generic"],
-         ", %d through prepared frames" % STATS["prepared"] if "prepared" in STATS else ""))
+
+
+def configure(env=None):
+  """Set the campaign's modes from DM_CAMPAIGN_* variables (`env`: a dict, default os.environ); the GPU test
+  suite runs a slice of every mode through this (tests/test_hip_parity.py)."""
+  env = os.environ if env is None else env
+  g = globals()
+  for name in _MODES:
+    g[name] = env.get("DM_CAMPAIGN_" + name, "0") != "0"
+  g["SUM_KIND"] = env.get("DM_CAMPAIGN_SUM", "0")
+  g["SEMANTIC"] = env.get("DM_CAMPAIGN_SEMANTIC", "1") != "0"
+  g["EDGE"] = env.get("DM_CAMPAIGN_EDGE", "1") != "0"      # NaN/inf depths, missing truncations
+  for k in list(STATS):
+    STATS[k] = 0
+  LIB.dm_debug_force_bands(1 if g["FINE"] else 0)
+
+
+def reset_switches():
+  """Back to the library's defaults (the modes leave per-thread debug switches set)."""
+  LIB.dm_debug_force_bands(0); LIB.dm_debug_force_strips(0); LIB.dm_debug_fill_split(-1); LIB.dm_debug_flow_fused(0)
+  LIB.dm_debug_force_fused_split(0, 0)
+
+
+configure()
+
+
+def main():
+  first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+  count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+  bad = 0
+  for s in range(first, first + count):
+    try:
+      bm, bv, shape = one(s)
+    except Exception:
+      print("EXCEPTION at seed", s, flush=True)
+      raise
+    if bm or bv:
+      bad += 1
+      print("MISMATCH seed", s, shape, "mask cells", bm, "map cells", bv, flush=True)
+    if (s - first) % 50 == 49:
+      print("  ... %d configurations, %d with mismatches" % (s - first + 1, bad), flush=True)
+  print("done: %d configurations, %d with mismatches (%d took the strip path, %d depth bands, %d the generic path%s)"
+        % (count, bad, STATS["strip"], STATS["banded"], STATS["generic"],
+           (", %d through prepared frames" % STATS["prepared"] if "prepared" in STATS else "") +
+           (", %d flow grids from the projection kernel" % STATS["flow_fused"] if "flow_fused" in STATS else "")))
+
+
+if __name__ == "__main__":
+  main()

@@ -189,6 +189,14 @@ def _fused_flow_checks(dmap, lib, oracle, proj, cfg, depth, pose, tp, g, stride,
   assert lib.dm_debug_last_flow_fused() == 0
   t6, m6 = proj.orth_project(depth, valid_map=valid, cam_pose=pose)
   assert torch.equal(t5, t6) and torch.equal(m5, m6) and _same_bits(g5, grid2)
+  # frames whose pixels cannot reach the map leave the projection kernel in front of its pixel loop: such
+  # a call must not take the one-kernel form (found by the parity campaign's flow mode: their grids were
+  # left unwritten)
+  far = pose.clone()
+  far[1, :2] = torch.tensor([400.0, -350.0])
+  t9, m9, g9 = proj.orth_project_and_flow(depth, tp, cam_pose=far)
+  assert lib.dm_debug_last_flow_fused() == 0
+  assert _same_bits(g9, grid2) and not bool(m9[1].any())
   # a shape the strip path takes (BASELINE configs[1]'s frames): not fused, same results
   Hs, Ws = 480, 640
   ds = torch.from_numpy(rng.uniform(0.1, 10.0, (64, 1, Hs, Ws)).astype(np.float32)).cuda()

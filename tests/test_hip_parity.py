@@ -7,6 +7,9 @@ and through exact equality of max/min maps; float heights within 1e-5 (they
 are in fact bit-equal); order-dependent sum/mean/prod within rtol 1e-5.
 """
 import ctypes
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -14,6 +17,7 @@ import torch
 from conftest import assert_masks_equal_away_from_fill, load_golden, project_kwargs
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -774,3 +778,40 @@ def test_three_host_threads_on_their_own_streams(dmap):
   for t in threads:
     t.join()
   assert not errors, errors
+
+
+# --------------------------------------------------------------------------
+# a slice of every mode of the builder-run parity campaign (tests/campaigns/parity_campaign.py)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("modes", [
+    {},
+    {"ONE_PITCH": "1", "CALLS": "1"},
+    {"FILL_SPLIT": "1", "ONE_PITCH": "1", "CALLS": "1"},
+    {"FLOW": "1"},
+    {"FLOW": "1", "ONE_PITCH": "1", "SEMANTIC": "0"},
+    {"FUSED": "1"},
+    {"SUM": "1"},
+    {"SUM": "mean"},
+    {"ODD": "1"},
+    {"OFFSETS": "1", "ONE_PITCH": "1", "CALLS": "1"},
+    {"DC": "1", "CALLS": "1"},
+    {"FINE": "1"},
+], ids=lambda m: "+".join(f"{k}={v}" for k, v in m.items()) or "default")
+def test_campaign_slice(dmap, oracle, modes):
+  """Thirty seeded random configurations of each campaign mode against the oracle (cells and heights bit
+  for bit; order-dependent sums 1e-5): the modes that found the defects of earlier rounds, plus this round's
+  (where the fill duty runs, the projection + flow call with the one-kernel form switched at random)."""
+  import importlib
+  sys.path.insert(0, os.path.join(ROOT, "tests", "campaigns"))
+  campaign = importlib.import_module("parity_campaign")
+  campaign.configure({"DM_CAMPAIGN_" + k: v for k, v in modes.items()})
+  try:
+    bad = []
+    for seed in range(4_000_000, 4_000_030):
+      bm, bv, shape = campaign.one(seed)
+      if bm or bv:
+        bad.append((seed, shape, bm, bv))
+    assert not bad, bad
+  finally:
+    campaign.reset_switches()
+    campaign.configure({})

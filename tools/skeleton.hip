@@ -10,10 +10,13 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool NT, bool READ, bool WRITE>
+// ROTATE: frame b starts its image rows at row (b * 37) % H and its fill rows at an offset of (b * 5) steps, wrapping
+// around -- do 64 workgroups walking 64 equally laid out frames in lockstep camp on the same memory channels?
+template <bool NT, bool READ, bool WRITE, bool ROTATE = false>
 __global__ void __launch_bounds__(1024) k_skel(const float* depth, float* out, unsigned char* mask, float* sink,
                                                int P, int H, int W, int mh, int mw) {
   const int part = blockIdx.x, b = blockIdx.z;
+  const int rot_r = ROTATE ? (b * 37) % H : 0;
   const int wp = W / P, nx = wp / 4, rows_per_iter = 1024 / nx;
   const int gx = threadIdx.x % nx, gy = threadIdx.x / nx;
   const float* img = depth + (size_t)b * H * W + part * wp + gx * 4;
@@ -22,7 +25,7 @@ __global__ void __launch_bounds__(1024) k_skel(const float* depth, float* out, u
   f32x4 za[4], zb[4];
   auto load = [&](f32x4 (&z)[4], int r) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { int rr = r + u * rows_per_iter; rr = rr < H ? rr : H - 1; z[u] = *reinterpret_cast<const f32x4*>(img + (size_t)rr * W); }
+    for (int u = 0; u < 4; ++u) { int rr = r + u * rows_per_iter; rr = rr < H ? rr : H - 1; rr += rot_r; rr = rr >= H ? rr - H : rr; z[u] = *reinterpret_cast<const f32x4*>(img + (size_t)rr * W); }
   };
   // fill rows part, part + P, ...: wave v rows part + (v + 16 j) P, 256 cells per step
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -32,14 +35,16 @@ __global__ void __launch_bounds__(1024) k_skel(const float* depth, float* out, u
   const int chunks = (mw + 255) >> 8;
   const int fill_steps = WRITE && wave < rows_mine ? ((rows_mine - wave + 15) >> 4) * chunks : 0;
   int fs = 0, f_row = part + wave * P, f_chunk = 0;
+  const int rot_f = ROTATE ? (b * 5 * 16 * P) % mh : 0;
   auto fill_step = [&]() {
     if (fs < fill_steps) {
       const int x = (f_chunk << 8) + (lane << 2);
       if (x < mw) {
         const f32x4 v = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        f32x4* p = reinterpret_cast<f32x4*>(omap + (size_t)f_row * mw + x);
+        int fr = f_row + rot_f; fr = fr >= mh ? fr - mh : fr;
+        f32x4* p = reinterpret_cast<f32x4*>(omap + (size_t)fr * mw + x);
         if (NT) __builtin_nontemporal_store(v, p); else *p = v;
-        *reinterpret_cast<unsigned*>(mmap + (size_t)f_row * mw + x) = 0u;
+        *reinterpret_cast<unsigned*>(mmap + (size_t)fr * mw + x) = 0u;
       }
       ++fs;
       const bool next = f_chunk + 1 == chunks;
@@ -98,5 +103,8 @@ int main() {
   run("write only nt", k_skel<true, false, true>, ROT, P);
   run("read+write nt", k_skel<true, true, true>, 1, P);
   run("read+write nt (8 strips: 2 rounds)", k_skel<true, true, true>, ROT, 8);
+  run("read+write nt, rows rotated per frame", k_skel<true, true, true, true>, ROT, P);
+  run("read only, rows rotated per frame", k_skel<true, true, false, true>, ROT, P);
+  run("write only nt, rows rotated per frame", k_skel<true, false, true, true>, ROT, P);
   return 0;
 }

@@ -343,13 +343,13 @@ def main():
     HIP event between two kernels is a stream operation of its own, ~1.5 us each way: bracketing
     every launch sequence would time the events too.  This is the figure rocprofv3's per-kernel
     averages add up to, profiles/.)"""
-    for j in range(4):
+    for j in range(16):      # (enough calls for the clocks to settle: the first dozen after an idle gap run ~2 us slower)
       fn(j)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for j in range(n_b2b):
-      fn(4 + j)
+      fn(16 + j)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / n_b2b

@@ -47,7 +47,8 @@ struct alignas(16) GeomLds {
   // list entries of this strip per chunk of 64 rows of the union window (then: before the chunk);
   // [kListMaxRows / 64]: all of them
   int chunk_entries[kListMaxRows / 64 + 1];
-  int pad[3];
+  int has_holes;              // some row of this workgroup's fill duty has groups of its hull in no strip's cover
+  int pad[2];
 };
 constexpr int kGeomFloats = sizeof(GeomLds) / 4;
 static_assert(sizeof(GeomLds) % 16 == 0, "GeomLds size");
@@ -155,6 +156,7 @@ __device__ inline void frame_geometry_wave64(const strip::RigArgs& c, const Stri
   if (lane == 0) {
     g->U = ux1 > ux0 ? Win16{(short)ux0, (short)uz0, (short)(ux1 - ux0), (short)(uz1 - uz0)} : Win16{0, 0, 0, 0};
     g->ok = p.ok;
+    g->has_holes = 0;
     int bits = 0;
 #pragma unroll
     for (int q = 0; q < kMaxStrips; ++q) bits |= (int)((in_mask >> (8 * q)) & 1ull) << q;
@@ -528,23 +530,9 @@ k_strip_scatter(StripArgs a) {
         owned_t[r] = owned;
         reach[r] = rhi > rlo ? make_uint2((unsigned)rlo, (unsigned)(rhi - rlo)) : make_uint2(0u, 0u);
         list_at[r] = before - entries;
-        // Groups of the hull in no strip's cover (not seen in practice, but nothing rules them
-        // out) are written here, with the fill value, by the workgroup whose fill duty owns the
-        // map row.
-        if (__builtin_expect(hole, 0)) {
-          if (MODE != kIndexOut && (U.z0 + r) % nparts == part) {
-            for (int x = rlo; x < rhi; x += 4) {
-              bool any = false;
-#pragma unroll
-              for (int q = 0; q < kP2; ++q) any = any | strip::in_span(cov[q], x);
-              if (!any) {
-                const int cell = (U.z0 + r) * a.mw + x;
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, cell << 2, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, cell, 0, 0);
-              }
-            }
-          }
-        }
+        // (groups of the hull in no strip's cover: stored behind the barrier by the workgroup whose fill
+        // duty owns the map row -- flagged here, so that the others skip that pass)
+        if (__builtin_expect(hole, 0) && (U.z0 + r) % nparts == part) geom->has_holes = 1;
       }
     }
   };
@@ -573,14 +561,11 @@ k_strip_scatter(StripArgs a) {
       int rlo = cov ? (int)(cov & 0xffffu) : 32767, rhi = end;
       int lo = (int)(cov & 0xffffu), hi = end;
       bool continued = cov == 0u;
-      uint32_t oth[kP2];
       auto see = [&](int m, uint32_t other) {
-        oth[m] = other;
         rlo = min(rlo, other ? (int)(other & 0xffffu) : 32767); rhi = max(rhi, (int)(other >> 16));
         strip::cut_span(lo, hi, other);
         continued = continued | (((int)(other & 0xffffu) <= end) & (end < (int)(other >> 16)));
       };
-      oth[0] = cov;
       see(1, (uint32_t)lane_xor<1>((int)cov)); see(2, (uint32_t)lane_xor<2>((int)cov)); see(3, (uint32_t)lane_xor<3>((int)cov));
       if (kP2 == 8) {
         see(4 % kP2, (uint32_t)lane_xor<4>((int)cov)); see(5 % kP2, (uint32_t)lane_xor<5>((int)cov));
@@ -599,23 +584,7 @@ k_strip_scatter(StripArgs a) {
         }
         if (q == 0) {
           reach[r] = rhi > rlo ? make_uint2((unsigned)rlo, (unsigned)(rhi - rlo)) : make_uint2(0u, 0u);
-          // Groups of the hull in no strip's cover (not seen in practice, but nothing rules them
-          // out) are written here, with the fill value, by the workgroup whose fill duty owns the
-          // map row.
-          if (__builtin_expect(hole, 0)) {
-            if (MODE != kIndexOut && (U.z0 + r) % nparts == part) {
-              for (int x = rlo; x < rhi; x += 4) {
-                bool any = false;
-#pragma unroll
-                for (int m = 0; m < kP2; ++m) any = any | strip::in_span(oth[m], x);
-                if (!any) {
-                  const int cell = (U.z0 + r) * a.mw + x;
-                  __builtin_amdgcn_raw_buffer_store_b128((u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, cell << 2, 0, 0);
-                  __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, cell, 0, 0);
-                }
-              }
-            }
-          }
+          if (__builtin_expect(hole, 0) && (U.z0 + r) % nparts == part) geom->has_holes = 1;      // (see row_tables)
         }
       }
     }
@@ -669,6 +638,35 @@ k_strip_scatter(StripArgs a) {
                     "+s"(fy6), "+s"(fy8), "+s"(ftx), "+s"(ftz), "+s"(wo), "+s"(ho));
   lds_barrier();
   DM_STAMP(2);
+  // Groups of a row's hull that lie in NO strip's cover hold the fill value, and neither the fill duty
+  // (outside the hull) nor a flush (inside a cover) writes them.  They occur where one strip's window has
+  // ended between two others' -- a few rows of one or two frames in a batch of random poses.  The
+  // workgroup whose fill duty owns the map row stores them here, wave-level: wave v takes the rows
+  // part + (v + 16 j) P inside the union window, 256 cells of the hull per step, a lane stores its
+  // group when no cover holds it; the row tables flag the workgroups that have such rows, the others
+  // skip the pass (unconditionally it cost every workgroup 1.5 us).  Until round 4 ONE thread per such row stored them group by group inside the
+  // row tables: 6.5 us in the head of the workgroups concerned -- and every launch of the batch waited
+  // for them (profiles/r04_scatter_phase_stamps.log).
+  if (MODE != kIndexOut && __builtin_expect(__builtin_amdgcn_readfirstlane(geom->has_holes) != 0, 0)) {
+    const int first = U.z0 + ((part - U.z0 % nparts + nparts) % nparts);      // first row of the union window that is this workgroup's
+    for (int z = first + wave * nparts; z < U.z0 + U.h; z += 16 * nparts) {  // (scalar)
+      const int r = z - U.z0;
+      const uint2 hull = reach[r];
+      const uint4 c0 = *reinterpret_cast<const uint4*>(covers + r * P2);
+      uint4 c1 = make_uint4(0u, 0u, 0u, 0u);
+      if (P2 == 8) c1 = *reinterpret_cast<const uint4*>(covers + r * 8 + 4);
+      for (unsigned x0 = hull.x; x0 < hull.x + hull.y; x0 += 256) {          // (scalar: the hull is the row's, the same in every lane)
+        const int x = (int)x0 + (lane << 2);
+        const bool covered = strip::in_span(c0.x, x) | strip::in_span(c0.y, x) | strip::in_span(c0.z, x) | strip::in_span(c0.w, x) |
+                             strip::in_span(c1.x, x) | strip::in_span(c1.y, x) | strip::in_span(c1.z, x) | strip::in_span(c1.w, x);
+        const bool store = (x < (int)(hull.x + hull.y)) & !covered;
+        const int cell0 = z * a.mw + (int)x0;
+        buffer_store_b128_at_scalar_offset<NT_FILL ? kFillCachePolicy : 0>(
+            (u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, store ? lane << 4 : 0x7ffffff0, cell0 << 2);
+        __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, store ? lane << 2 : 0x7ffffff0, cell0, 0);
+      }
+    }
+  }
   if (wave == 0) {       // list entries before each chunk of 64 rows (the flush reads them behind the next barrier)
     const int chunks_u = (U.h + 63) >> 6;                      // <= kListMaxRows / 64 = 64
     const int mine = lane < chunks_u ? geom->chunk_entries[lane] : 0;

@@ -107,3 +107,13 @@ if len(loop) % 4 == 0 and not os.environ.get("DM_STAMPS_STRIPS") and not C:
   print("per-WG loop: p10 %.2f  p50 %.2f  p90 %.2f  max %.2f" % tuple(np.percentile(loop, [10, 50, 90, 100])))
   start = (raw[:, 0] - raw[:, 0].min()) * 0.01
   print("corr(loop, start time) = %.2f" % np.corrcoef(loop, start)[0, 1])
+
+if os.environ.get("DM_STAMPS_SLOWEST"):
+  # the slowest workgroups of the launch: (index, frame, strip, index % 8) and their phases
+  order = np.argsort(-tot)[:int(os.environ["DM_STAMPS_SLOWEST"])]
+  t0 = st[:, 0].min()
+  print("slowest workgroups: index frame strip idx%8 | start head loop rest flush total (us)")
+  for i in order:
+    print("  %4d %3d %d %d | %5.2f %5.2f %5.2f %5.2f %5.2f %6.2f" % (
+        i, i // 4, i % 4, i % 8, (st[i, 0] - t0) * 0.01, (raw[i, 11] - raw[i, 0]) * 0.01, (raw[i, 4] - raw[i, 11]) * 0.01,
+        (raw[i, 5] - raw[i, 4]) * 0.01, (raw[i, 6] - raw[i, 5]) * 0.01, tot[i]))

@@ -975,6 +975,9 @@ hipError_t run_strip_fused(const dm_params& p, const dm_frame* frames_host, cons
   fa.fill = p.fill; fa.cam_h = frames_host[0].cam_height;
   fa.inv = fb.inv; fa.reach = fb.reach; fa.g0 = fb.g0; fa.g1 = fb.g1; fa.cone_ok = 1;
   fa.slabs = slabs; fa.wins = wins; fa.spans = spans; fa.status = status;
+#ifdef DM_STAMPS
+  fa.stamps = g_stamp_buffer;
+#endif
   const size_t lds_bytes = fused_lds_bytes(best.slab, p.H, best.rows);
   const size_t N = (size_t)p.H * p.W;
   const int per_launch = kPoseFrames / F * F;           // whole groups per launch

@@ -48,6 +48,9 @@ struct FusedArgs {
   Win16* wins;                // (groups, P)
   uint32_t* spans;            // (groups, P, max_rows)   lo | hi << 16 of every window row: the cells the slab holds
   int* status;
+#ifdef DM_STAMPS
+  long long* stamps;
+#endif
   StripPose poses[kPoseFrames];
 };
 
@@ -122,6 +125,10 @@ k_strip_fused(FusedArgs a) {
     }
   };
   if (col_live) load_stage(za, 0, 0);            // the first rows: kernel arguments only
+#ifdef DM_STAMPS
+  long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  DM_STAMP(0);
 
   float* aytab = lds + a.slab_stride + 64;
   int* gwin = reinterpret_cast<int*>(aytab + ((a.H + 3) & ~3));     // {x0 | z0 << 16, w | h << 16, inside, ok}
@@ -199,7 +206,9 @@ k_strip_fused(FusedArgs a) {
       aytab[r] = ay;
     }
   }
+  DM_STAMP(1);
   lds_barrier();
+  DM_STAMP(2);
   Window w;
   {
     const int g0_ = __builtin_amdgcn_readfirstlane(gwin[0]), g1_ = __builtin_amdgcn_readfirstlane(gwin[1]);
@@ -371,7 +380,9 @@ k_strip_fused(FusedArgs a) {
     }
     __builtin_amdgcn_s_setprio(0);
   };
+  DM_STAMP(3);
   if (inside) pipeline(std::false_type{}); else pipeline(std::true_type{});
+  DM_STAMP(4);
   // The rows' spans: on map row z the group's pixels can only land between its frames' cone edges
   // (strip::row_cover, the cover of k_strip_scatter's strips) -- a fraction of the window's
   // bounding box, which is all the slab has to hold and all k_fuse_windows has to visit.  Eight
@@ -396,7 +407,9 @@ k_strip_fused(FusedArgs a) {
       }
     }
   }
+  DM_STAMP(5);
   lds_barrier();
+  DM_STAMP(6);
   // flush: the spans of the window's rows -> the workgroup's slab, 16 lanes per row
   float* slab = a.slabs + (((size_t)group * a.dc + ch) * a.P + part) * a.slab_stride;
   const int l16 = (int)threadIdx.x & 15;
@@ -410,6 +423,8 @@ k_strip_fused(FusedArgs a) {
       *reinterpret_cast<float4*>(slab + cell0 + x) = v;
     }
   }
+  DM_STAMP(7);
+  DM_STAMPS_OUT();
 }
 
 }  // namespace

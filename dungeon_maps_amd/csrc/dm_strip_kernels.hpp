@@ -657,9 +657,10 @@ k_strip_scatter(StripArgs a) {
       if (P2 == 8) c1 = *reinterpret_cast<const uint4*>(covers + r * 8 + 4);
       for (unsigned x0 = hull.x; x0 < hull.x + hull.y; x0 += 256) {          // (scalar: the hull is the row's, the same in every lane)
         const int x = (int)x0 + (lane << 2);
-        const bool covered = strip::in_span(c0.x, x) | strip::in_span(c0.y, x) | strip::in_span(c0.z, x) | strip::in_span(c0.w, x) |
-                             strip::in_span(c1.x, x) | strip::in_span(c1.y, x) | strip::in_span(c1.z, x) | strip::in_span(c1.w, x);
-        const bool store = (x < (int)(hull.x + hull.y)) & !covered;
+        const int covered = (int)strip::in_span(c0.x, x) | (int)strip::in_span(c0.y, x) | (int)strip::in_span(c0.z, x) |
+                            (int)strip::in_span(c0.w, x) | (int)strip::in_span(c1.x, x) | (int)strip::in_span(c1.y, x) |
+                            (int)strip::in_span(c1.z, x) | (int)strip::in_span(c1.w, x);
+        const bool store = covered ? false : x < (int)(hull.x + hull.y);
         const int cell0 = z * a.mw + (int)x0;
         buffer_store_b128_at_scalar_offset<NT_FILL ? kFillCachePolicy : 0>(
             (u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, store ? lane << 4 : 0x7ffffff0, cell0 << 2);

@@ -123,7 +123,7 @@ inline hipError_t launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
 
 using Kernel = void (*)(ScatterArgs, const ScatterTables*);
 
-Kernel pick_kernel(int red, bool fast, bool has_valid, bool has_value, bool vec4, bool lean) {
+Kernel pick_kernel(int red, bool fast, bool has_valid, bool has_value, bool vec4, bool lean, bool stream = false) {
 #define DM_K(M, F, V, S) {k_window_scatter<M, F, V, S, 1, false>, k_window_scatter<M, F, V, S, 4, false>}
 #define DM_RED(M)                                                                  \
       {{{DM_K(M, false, false, false), DM_K(M, false, false, true)},                \
@@ -143,6 +143,16 @@ Kernel pick_kernel(int red, bool fast, bool has_valid, bool has_value, bool vec4
        k_window_scatter<kSum, true, false, true, 4, true>},
       {k_window_scatter<kMean, true, false, false, 4, true>,
        k_window_scatter<kMean, true, false, true, 4, true>}};
+  static const Kernel stream_table[4][2] = {
+      {k_window_scatter<kMin, true, false, false, 4, true, false, true>,
+       k_window_scatter<kMin, true, false, true, 4, true, false, true>},
+      {k_window_scatter<kMax, true, false, false, 4, true, false, true>,
+       k_window_scatter<kMax, true, false, true, 4, true, false, true>},
+      {k_window_scatter<kSum, true, false, false, 4, true, false, true>,
+       k_window_scatter<kSum, true, false, true, 4, true, false, true>},
+      {k_window_scatter<kMean, true, false, false, 4, true, false, true>,
+       k_window_scatter<kMean, true, false, true, 4, true, false, true>}};
+  if (lean && stream) return stream_table[red][has_value];
   return lean ? lean_table[red][has_value] : table[red][fast][has_valid][has_value][vec4];
 }
 
@@ -168,7 +178,8 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
                        const float* depth, const float* value, const uint8_t* valid, float* out,
                        uint8_t* mask, int oc_total, float fill, int red, size_t slab_bytes,
                        hipStream_t s, float* fused = nullptr, uint8_t* fused_mask = nullptr,
-                       int accumulate = 0, float* flow_grid = nullptr, bool* flow_done = nullptr) {
+                       int accumulate = 0, float* flow_grid = nullptr, bool* flow_done = nullptr,
+                       bool depth_read_again = false) {
   ScatterArgs sa;
   sa.flow = nullptr; sa.flow_grid = nullptr;
   sa.W = p.W; sa.H = p.H;
@@ -213,8 +224,14 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
     with_flow = (int)st.wins[i].w * st.wins[i].h > 0;
   if (flow_done) *flow_done = with_flow;
   if (with_flow) { sa.flow = st.d_flow; sa.flow_grid = flow_grid; }
+  // the depth maps non-temporally: where what the call reads and writes once cannot stay cache resident
+  // (more than half of the Infinity Cache) and no second reader of the depth maps follows inside the call
+  // (the ego-motion flow kernel of dm_orth_project_flow_f32 finds them in the cache only under the default
+  // policy: cfg5 flow call 153 -> 176 us; plain projection 101 -> 96 us)
+  const size_t once = (size_t)p.B * p.dc * p.H * p.W * 4 + (size_t)p.B * oc_total * p.mh * p.mw * 5;
+  const bool stream = !depth_read_again && once > ((size_t)128 << 20) && st.parts.pd == 1;
   const Kernel kfn = with_flow ? pick_flow_kernel(is_max)
-                               : pick_kernel(red, st.fast, has_valid, has_value, vec4, lean);
+                               : pick_kernel(red, st.fast, has_valid, has_value, vec4, lean, stream);
   hipError_t e = hipSuccess;
   {   // raise the dynamic-LDS limit once per kernel variant and device
     static thread_local const void* done[64][8] = {};
@@ -620,6 +637,7 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
                   : p.reduction == DM_REDUCE_MIN ? kMin
                   : p.reduction == DM_REDUCE_SUM ? kSum
                                                  : kMean;
+  const bool flow_wanted = flow_grid != nullptr;       // (the stand-alone flow kernel reads the depth maps again)
   if (flow_grid && flow_frames_host && !value) {
     // the frames' flow records (rotation and translation of the pose transition, rotate(X, -pitch)):
     // one more stream-ordered copy, behind the tables
@@ -638,7 +656,8 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
   }
   bool flowed = false;
   e = window_pass(p, st, slabs, depth, value, valid, out, mask, oc_total, p.fill, red,
-                  slab_bytes, s, nullptr, nullptr, 0, flow_grid, &flowed);
+                  slab_bytes, s, nullptr, nullptr, 0, flow_grid, &flowed,
+                  /*depth_read_again=*/flow_wanted || (height && value));
   if (e != hipSuccess) return e;
   if (flow_done) *flow_done = flowed;
   g_last_flow_fused = flowed ? 1 : 0;

@@ -121,9 +121,13 @@ __device__ inline float combine(float a, float b) {
 //       height compare are dropped.  (Pipeline-tail rows are poisoned through z.)
 // HAS_FLOW (FAST, VEC = 4, LEAN, heights, no depth bands): every pixel's ego-motion flow (flow_pixel,
 //       dm_pixel.hpp) goes to a.flow_grid beside the projection -- one depth read for both.
-template <int RED, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC, bool LEAN, bool HAS_FLOW = false>
+// STREAM (lean variants): the depth maps are loaded non-temporally -- read once, they would otherwise evict
+//       what the merge kernel reads back (the slabs); the host picks it for calls whose bytes cannot stay
+//       cache resident and that no second reader of the depth maps follows (dm_window.hip).
+template <int RED, bool FAST, bool HAS_VALID, bool HAS_VALUE, int VEC, bool LEAN, bool HAS_FLOW = false, bool STREAM = false>
 __global__ void __launch_bounds__(kScatterThreads)
 k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
+  static_assert(!STREAM || (LEAN && VEC == 4 && !HAS_FLOW), "the streaming variant exists for the lean kernels");
   static_assert(!HAS_FLOW || (FAST && VEC == 4 && LEAN && !HAS_VALUE && !HAS_VALID && !additive(RED)),
                 "the fused flow rides on the lean height projection");
   const ScatterTables& t = *tables;            // this launch's chunk of frames
@@ -166,12 +170,9 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
       int rr = r + u * rows_per_iter;
       rr = rr < r1 ? rr : r1 - 1;
       if (VEC == 4) {
-#if defined(DM_X_DEPTH_POLICY) && DM_X_DEPTH_POLICY == 2
         typedef float wf32x4 __attribute__((ext_vector_type(4)));
-        const wf32x4 t = __builtin_nontemporal_load(reinterpret_cast<const wf32x4*>(dimg + (size_t)rr * a.W + q));
-#else
-        const float4 t = *reinterpret_cast<const float4*>(dimg + (size_t)rr * a.W + q);
-#endif
+        const wf32x4* const src4 = reinterpret_cast<const wf32x4*>(dimg + (size_t)rr * a.W + q);
+        const wf32x4 t = STREAM ? __builtin_nontemporal_load(src4) : *src4;
         z[u][0] = t.x; z[u][1 % VEC] = t.y; z[u][2 % VEC] = t.z; z[u][3 % VEC] = t.w;
       } else {
         z[u][0] = dimg[(size_t)rr * a.W + q];

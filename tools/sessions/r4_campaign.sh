@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 4 parity campaigns on the final library (builder-run; profiles/r04_parity_campaigns.log)
 O=gpurun_out/r4_campaign
+rm -rf $O
 mkdir -p $O
 L=$O/campaign.log
 echo "# library md5 $(md5sum dungeon_maps_amd/csrc/libdungeon_maps_amd.so | cut -d' ' -f1); seeds from ${SEED0:=3000000}" > $L

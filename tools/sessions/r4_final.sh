@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 4: the measurements the committed profiles/r04_* files come from (one gpurun call).
 O=gpurun_out/r4_final
+rm -rf $O
 mkdir -p $O
 export TMPDIR=/tmp
 md5sum dungeon_maps_amd/csrc/libdungeon_maps_amd.so > $O/lib.md5

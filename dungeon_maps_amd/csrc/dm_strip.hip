@@ -247,15 +247,16 @@ StripKernel pick_strip_kernel(bool is_max, bool has_valid, bool has_value, bool 
   return table[is_max ? 1 : 0][has_valid][has_value][lean && !has_valid][nt_fill];
 }
 
-// Whether the fill value's stores should bypass the caches (dm_pixel.hpp kFillCachePolicy): where
-// the call's own batch fuse follows -- it reads the flushed cells and never the fill -- and where
-// the maps are larger than the Infinity Cache (256 MB) could hold on to next to the depth maps.
 // dm_debug_fill_split: where the fill duty of the map rows outside a frame's union window runs
 // (StripArgs::defer_outer / head_share).  -1: under the pixel loop with the rest (rounds 2-3);
 // 0..8: out of the loop -- that many of every eight such rows of a wave in the kernel's head, the
 // others in the combine kernel.
-constexpr int kFillSplitDefault = -1;     // (measured: no gain in the head, a loss in the combine kernel -- DESIGN)
+constexpr int kFillSplitDefault = -1;     // (measured: no gain in the head, a loss in the combine kernel -- DESIGN 4.6)
 thread_local int g_fill_split = kFillSplitDefault;
+
+// Whether the call takes the kernel's STREAMING variant (template parameter NT_FILL): the fill value's
+// stores bypass the caches (dm_pixel.hpp kFillCachePolicy) and the depth maps are loaded non-temporally
+// (k_strip_scatter kDepthPolicy).
 thread_local int g_force_nt_fill = -1;      // dm_debug_force_nt_fill: -1 the rule below, 0 never, 1 always
 inline bool nt_fill_pays(const dm_params& p, int oc_total, bool fuse_follows) {
   if (g_force_nt_fill >= 0) return g_force_nt_fill != 0;

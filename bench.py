@@ -361,8 +361,9 @@ def main():
                 "stream, total / 64")
   else:
     # The launch sequence of the per-frame maps (k_strip_scatter + k_strip_combine) exactly as the
-    # timed steps launch it: the kernel variant a call with a batch fuse takes (non-temporal fill
-    # stores, forced through the library's measurement switch), the rotating depth batches, and
+    # timed steps launch it: the kernel variant a call with a batch fuse takes (the streaming one:
+    # non-temporal fill stores and depth loads; forced through the library's measurement switch -- a
+    # plain call of this size picks it by itself, a smaller one would not), the rotating depth batches, and
     # output blocks that rotate too -- plain orth_project allocates its outputs, so the last `rot`
     # results are kept alive and the allocator has to hand out another block every call.
     keep = [None] * (rot + 1)
@@ -516,7 +517,7 @@ def main():
           "launch_us": us,
           "note": "MapProjector.prepare(...).orth_project_and_fuse(depth): one fixed set of poses in a "
                   "device buffer, the same rotating buffers (64 launch sequences back to back between one "
-                  "pair of events; a plain prepared call keeps the default cache policy on its fill stores)"}
+                  "pair of events)"}
       del prep
     except _native.NativeError as e:
       result["prepared_frames"] = {"error": str(e)[:200]}

@@ -823,6 +823,10 @@ struct FuseWinArgs {
 };
 
 constexpr int kFuseChunk = 1024;    // windows examined per candidate-list round
+#ifndef DM_X_FUSE_DEPTH
+#define DM_X_FUSE_DEPTH 16
+#endif
+constexpr int kFuseDepth = DM_X_FUSE_DEPTH;   // slab loads a lane keeps in flight
 
 template <bool IS_MAX>
 __global__ void __launch_bounds__(kFuseGroups * kFuseLanes)
@@ -912,12 +916,14 @@ k_fuse_windows(FuseWinArgs a) {
       }
     }
     __syncthreads();
-    // round 2: the 8 lanes of a group split the candidates, eight slab loads in flight
+    // round 2: the 8 lanes of a group split the candidates, kFuseDepth slab loads in flight (16: a tile of a
+    // trajectory has 100-200 candidates, 12-25 per lane -- with eight in flight that was up to four dependent
+    // rounds of loads, 10.3 us per launch at cfg4; with sixteen 9.2)
     const int n = ncand;
-    for (int i0 = lane; i0 < n; i0 += 8 * kFuseLanes) {
-      float4 v[8];
+    for (int i0 = lane; i0 < n; i0 += kFuseDepth * kFuseLanes) {
+      float4 v[kFuseDepth];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < kFuseDepth; ++k) {
         const int i = i0 + k * kFuseLanes;
         v[k] = acc;
         if (i < n) {
@@ -928,7 +934,7 @@ k_fuse_windows(FuseWinArgs a) {
         }
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < kFuseDepth; ++k) {
         acc.x = IS_MAX ? fmaxf(acc.x, v[k].x) : fminf(acc.x, v[k].x);
         acc.y = IS_MAX ? fmaxf(acc.y, v[k].y) : fminf(acc.y, v[k].y);
         acc.z = IS_MAX ? fmaxf(acc.z, v[k].z) : fminf(acc.z, v[k].z);

@@ -257,6 +257,35 @@ __device__ inline void flow_pixel(float z, float X, float Y, const float (&rp)[9
   if (flip_h) w = Hm1 - w;
 }
 
+// flow_pixel for two pixels at a time: the same float32 operations in the same order on both
+// halves of 64-bit register pairs (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 issue once for two
+// pixels; the stand-alone kernel is bound by VALU issue -- 85 instructions per pixel one by one,
+// profiles/r04_sq_counters.md).  The coefficients come as {c, c} pairs the caller builds once
+// (wave-uniform: the compiler keeps them in scalar register pairs).  The two perspective
+// divisions stay IEEE divisions per pixel.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct FlowPairs {
+  f32x2 rp[9], ry[9], ri[9], cam_h, neg_cam_h, tx, tz, fx, cx, fy, cy, zero, eps, Hm1;
+};
+__device__ inline void flow_pixel2(f32x2 z, f32x2 X, f32x2 Y, const FlowPairs& c, bool flip_h, f32x2& u, f32x2& w) {
+  auto fma2 = [](f32x2 a, f32x2 b, f32x2 d) { return __builtin_elementwise_fma(a, b, d); };
+  const f32x2 x1 = fma2(z, c.rp[6], fma2(Y, c.rp[3], X * c.rp[0])) + c.zero;
+  const f32x2 y1 = fma2(z, c.rp[7], fma2(Y, c.rp[4], X * c.rp[1])) + c.cam_h;
+  const f32x2 z1 = fma2(z, c.rp[8], fma2(Y, c.rp[5], X * c.rp[2])) + c.zero;
+  const f32x2 x2 = fma2(z1, c.ry[6], fma2(y1, c.ry[3], x1 * c.ry[0])) + c.tx;
+  const f32x2 y2 = fma2(z1, c.ry[7], fma2(y1, c.ry[4], x1 * c.ry[1])) + c.zero;
+  const f32x2 z2 = fma2(z1, c.ry[8], fma2(y1, c.ry[5], x1 * c.ry[2])) + c.tz;
+  const f32x2 x3 = x2 + c.zero, y3 = y2 + c.neg_cam_h, z3 = z2 + c.zero;
+  const f32x2 xc = fma2(z3, c.ri[6], fma2(y3, c.ri[3], x3 * c.ri[0]));
+  const f32x2 yc = fma2(z3, c.ri[7], fma2(y3, c.ri[4], x3 * c.ri[1]));
+  const f32x2 zc = fma2(z3, c.ri[8], fma2(y3, c.ri[5], x3 * c.ri[2]));
+  const f32x2 z_eps = zc + c.eps;
+  const f32x2 qu = {xc.x / z_eps.x, xc.y / z_eps.y}, qw = {yc.x / z_eps.x, yc.y / z_eps.y};
+  u = qu * c.fx + c.cx;
+  w = qw * c.fy + c.cy;
+  if (flip_h) w = c.Hm1 - w;
+}
+
 // ---------------------------------------------------------------------------
 // order-preserving float <-> uint key: k(a) < k(b)  <=>  a < b (with -0 < +0)
 __device__ inline uint32_t f2key(float f) {

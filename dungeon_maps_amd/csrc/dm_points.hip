@@ -148,24 +148,11 @@ k_camera_affine_grid(View v, int dc, const dm_frame* __restrict__ frames,
   const size_t k = ((size_t)b * dc + ch) * N + i;
   const float z = depth[k];
   const float X = ray_x(v, q) * z, Y = ray_y(v, r) * z;
-  // camera -> local
-  const float x1 = __builtin_fmaf(z, rp[6], __builtin_fmaf(Y, rp[3], X * rp[0])) + 0.0f;
-  const float y1 = __builtin_fmaf(z, rp[7], __builtin_fmaf(Y, rp[4], X * rp[1])) + f->cam_height;
-  const float z1 = __builtin_fmaf(z, rp[8], __builtin_fmaf(Y, rp[5], X * rp[2])) + 0.0f;
-  // apply the pose transition
-  const float x2 = __builtin_fmaf(z1, ry[6], __builtin_fmaf(y1, ry[3], x1 * ry[0])) + f->tx;
-  const float y2 = __builtin_fmaf(z1, ry[7], __builtin_fmaf(y1, ry[4], x1 * ry[1])) + 0.0f;
-  const float z2 = __builtin_fmaf(z1, ry[8], __builtin_fmaf(y1, ry[5], x1 * ry[2])) + f->tz;
-  // local -> camera: translate first, then rotate by -pitch
-  const float x3 = x2 + 0.0f, y3 = y2 + (-f->cam_height), z3 = z2 + 0.0f;
-  const float xc = __builtin_fmaf(z3, ri[6], __builtin_fmaf(y3, ri[3], x3 * ri[0]));
-  const float yc = __builtin_fmaf(z3, ri[7], __builtin_fmaf(y3, ri[4], x3 * ri[1]));
-  const float zc = __builtin_fmaf(z3, ri[8], __builtin_fmaf(y3, ri[5], x3 * ri[2]));
-  // camera -> image
-  const float z_eps = zc + 1e-7f;
-  float u = xc / z_eps * v.fx + v.cx;
-  float w = yc / z_eps * v.fy + v.cy;
-  if (v.flip_h) w = v.Hm1 - w;
+  float rp9[9], ry9[9], ri9[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { rp9[j] = rp[j]; ry9[j] = ry[j]; ri9[j] = ri[j]; }
+  float u, w;
+  flow_pixel(z, X, Y, rp9, f->cam_height, ry9, f->tx, f->tz, ri9, v.fx, v.cx, v.fy, v.cy, v.flip_h != 0, v.Hm1, u, w);
   reinterpret_cast<float2*>(grid)[k] = make_float2(u, w);
 }
 
@@ -202,20 +189,38 @@ k_camera_affine_grid4(View v, float fx_inv, float fy_inv, int dc, GridFrames arg
     cam_h = f->cam_height; tx = f->tx; tz = f->tz;
   }
   const size_t base = ((size_t)b * dc + ch) * ((size_t)v.H * v.W);
-  auto project4 = [&](int i, const float4 zz) {
-    const int r = i / W4, q0 = (i - r * W4) << 2;
+  // the coefficients as {c, c} pairs (flow_pixel2).  Two pixels per instruction: 85 -> 58 VALU instructions
+  // per pixel, 61 -> 46 us at 16 x 1280x960 with the working set beyond the Infinity Cache.  (Pinned in
+  // vector registers, -DDM_X_FLOW_VPAIRS, the pairs need no scalar moves but 128 registers per
+  // thread instead of 60: half the waves per SIMD, 69-71 us.)
+  FlowPairs c;
+#ifdef DM_X_FLOW_VPAIRS
+  auto pair = [](float x) { f32x2 p = {x, x}; asm volatile("" : "+v"(p)); return p; };
+#else
+  auto pair = [](float x) { return (f32x2){x, x}; };
+#endif
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { c.rp[i] = pair(rp[i]); c.ry[i] = pair(ry[i]); c.ri[i] = pair(ri[i]); }
+  c.cam_h = pair(cam_h); c.neg_cam_h = pair(-cam_h); c.tx = pair(tx); c.tz = pair(tz);
+  c.fx = pair(v.fx); c.cx = pair(v.cx); c.fy = pair(v.fy); c.cy = pair(v.cy);
+  c.zero = pair(0.0f); c.eps = pair(1e-7f); c.Hm1 = pair(v.Hm1);
+  // chunk i of the image = columns 4 q4 ... 4 q4 + 3 of row r; (r, q4) walk with i (no division per trip)
+  auto project4 = [&](int r, int q4, const float4 zz) {
+    const int q0 = q4 << 2;
     const float zs[4] = {zz.x, zz.y, zz.z, zz.w};
     float yr = (float)r;
     if (v.flip_h) yr = v.Hm1 - yr;
     const float ay = div_f<FAST_DIV>(yr - v.cy, v.fy, fy_inv);          // maps.py:670-678
     float out[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float z = zs[j];
-      const float X = div_f<FAST_DIV>((float)(q0 + j) - v.cx, v.fx, fx_inv) * z, Y = ay * z;
-      float u, w;
-      flow_pixel(z, X, Y, rp, cam_h, ry, tx, tz, ri, v.fx, v.cx, v.fy, v.cy, v.flip_h != 0, v.Hm1, u, w);
-      out[2 * j] = u; out[2 * j + 1] = w;
+    for (int j = 0; j < 4; j += 2) {       // two pixels per instruction
+      const f32x2 z = {zs[j], zs[j + 1]};
+      const f32x2 ax = {div_f<FAST_DIV>((float)(q0 + j) - v.cx, v.fx, fx_inv),
+                        div_f<FAST_DIV>((float)(q0 + j + 1) - v.cx, v.fx, fx_inv)};
+      const f32x2 X = ax * z, Y = (f32x2){ay, ay} * z;
+      f32x2 u, w;
+      flow_pixel2(z, X, Y, c, v.flip_h != 0, u, w);
+      out[2 * j] = u.x; out[2 * j + 1] = w.x; out[2 * j + 2] = u.y; out[2 * j + 3] = w.y;
     }
     float4* dst = reinterpret_cast<float4*>(grid + 2 * (base + (size_t)r * v.W + q0));
     // (write-once output, read by nobody in this kernel: non-temporal stores, 48-53 -> 46.6-47.1 us at
@@ -231,12 +236,23 @@ k_camera_affine_grid4(View v, float fx_inv, float fy_inv, int dc, GridFrames arg
   const int end = min(total, ((int)blockIdx.x + 1) * per_block);
   int i = (int)blockIdx.x * per_block + (int)threadIdx.x;
   constexpr int kStep = 256;
+  const int step_r = kStep / W4, step_q = kStep - step_r * W4;          // (scalar) one step of kStep chunks in rows / columns
+  int r = i / W4, q4 = i - r * W4;
+  auto advance = [&](int& rr, int& qq) {
+    qq += step_q; rr += step_r;
+    const bool wrap = qq >= W4;
+    qq -= wrap ? W4 : 0; rr += wrap ? 1 : 0;
+  };
   for (; i + kStep < end; i += 2 * kStep) {
     const float4 za = src[i], zb = src[i + kStep];
-    project4(i, za);
-    project4(i + kStep, zb);
+    int r1 = r, q1 = q4;
+    advance(r1, q1);
+    project4(r, q4, za);
+    project4(r1, q1, zb);
+    r = r1; q4 = q1;
+    advance(r, q4);
   }
-  if (i < end) project4(i, src[i]);
+  if (i < end) project4(r, q4, src[i]);
 }
 
 inline int nblocks(size_t n, int cap = 8192) {

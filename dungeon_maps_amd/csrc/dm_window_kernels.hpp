@@ -119,7 +119,7 @@ __device__ inline float combine(float a, float b) {
 //       (no border clip, no valid map): a non-finite or out-of-range pixel is then
 //       already rejected by the two depth compares, so the ordered-compare and the
 //       height compare are dropped.  (Pipeline-tail rows are poisoned through z.)
-// HAS_FLOW (FAST, VEC = 4, LEAN, heights, no depth bands): every pixel's ego-motion flow (flow_pixel,
+// HAS_FLOW (FAST, VEC = 4, LEAN, heights, no depth bands): every pixel's ego-motion flow (flow_pixel2,
 //       dm_pixel.hpp) goes to a.flow_grid beside the projection -- one depth read for both.
 // STREAM (lean variants): the depth maps are loaded non-temporally -- read once, they would otherwise evict
 //       what the merge kernel reads back (the slabs); the host picks it for calls whose bytes cannot stay
@@ -316,6 +316,16 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
   const float cam_h = fr[9], tx = fr[19], tz = fr[20];
   const float wo = fr[21], ho = fr[22];
   const float flip_s = a.flip_h ? -1.0f : 1.0f, flip_c = a.flip_h ? a.mhm1 : 0.0f;
+  FlowPairs flow_pairs;      // (HAS_FLOW: the flow's coefficients as {c, c} pairs, flow_pixel2)
+  if (HAS_FLOW) {
+    auto pair = [](float x) { return (f32x2){x, x}; };
+    const float rp9[9] = {p0, p1, p2, p3, p4, p5, p6, p7, p8};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { flow_pairs.rp[i] = pair(rp9[i]); flow_pairs.ry[i] = pair(fl_ry[i]); flow_pairs.ri[i] = pair(fl_ri[i]); }
+    flow_pairs.cam_h = pair(cam_h); flow_pairs.neg_cam_h = pair(-cam_h); flow_pairs.tx = pair(fl_tx); flow_pairs.tz = pair(fl_tz);
+    flow_pairs.fx = pair(a.fx); flow_pairs.cx = pair(a.cx); flow_pairs.fy = pair(a.fy); flow_pairs.cy = pair(a.cy);
+    flow_pairs.zero = pair(0.0f); flow_pairs.eps = pair(1e-7f); flow_pairs.Hm1 = pair(a.Hm1);
+  }
   DM_STAMP(1);
   bool lds_ready = false;
   const unsigned dummy = (unsigned)(RED == kMean ? 2 * area : area) + (threadIdx.x & 63u);   // 64 scratch cells after the window(s)
@@ -383,23 +393,19 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
               // The flow of the row's four pixels FIRST, two pixels at a time, each pair stored (16
               // bytes, non-temporal) before anything else is computed -- scheduling barriers keep the
               // compiler from interleaving it with the projection (all of it at once needs ~50 more
-              // registers than the kernel's 128).  The stand-alone kernel's arithmetic (flow_pixel)
+              // registers than the kernel's 128).  The stand-alone kernel's arithmetic (flow_pixel2)
               // on the same X = ax * z, Y = ay * z.  (Tail rows and idle threads repeat a row: the
               // same values to the same place.)
-              const float rp9[9] = {p0, p1, p2, p3, p4, p5, p6, p7, p8};
               typedef float f32x4 __attribute__((ext_vector_type(4)));
               f32x4* dst = reinterpret_cast<f32x4*>(
                   a.flow_grid + 2 * (((size_t)b * a.dc + dch) * N + (size_t)rr * a.W + q));
 #pragma unroll
               for (int k = 0; k < VEC; k += 2) {
-                float o4[4];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                  const float zz = z[u][k + j];
-                  flow_pixel(zz, ax[k + j] * zz, ay * zz, rp9, cam_h, fl_ry, fl_tx, fl_tz, fl_ri, a.fx, a.cx,
-                             a.fy, a.cy, a.flip_h != 0, a.Hm1, o4[2 * j], o4[2 * j + 1]);
-                }
-                __builtin_nontemporal_store((f32x4){o4[0], o4[1], o4[2], o4[3]}, dst + (k >> 1));
+                const f32x2 zz = {z[u][k], z[u][k + 1]};
+                const f32x2 axp = {ax[k], ax[k + 1]};
+                f32x2 fu, fw;
+                flow_pixel2(zz, axp * zz, (f32x2){ay, ay} * zz, flow_pairs, a.flip_h != 0, fu, fw);
+                __builtin_nontemporal_store((f32x4){fu.x, fw.x, fu.y, fw.y}, dst + (k >> 1));
                 __builtin_amdgcn_sched_barrier(0);
               }
             }

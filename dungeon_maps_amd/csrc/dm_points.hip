@@ -416,56 +416,97 @@ k_crop_nearest(const float* __restrict__ src, const uint8_t* __restrict__ src_ma
 // mask bytes instead of four of each -- the scalar kernel's one-byte mask stores set its pace
 // (0.35 of the HBM roofline for a 1024 x 1024 crop of sixteen 2048 x 2048 maps; this form: see
 // DESIGN).  Per cell the arithmetic above, operation for operation.
+struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };     // 16 bytes at 4-byte alignment
+struct __attribute__((packed, aligned(1))) U4u { uint32_t v; };            // 4 bytes at any alignment
+// ROWS crop rows per thread (rows i, i + rows_per, ...: the same four columns, their coordinates
+// computed once), every load of the thread issued before the first is used.
+template <int ROWS>
 __global__ void __launch_bounds__(256)
 k_crop_nearest4(const float* __restrict__ src, const uint8_t* __restrict__ src_mask,
                 const float* __restrict__ center, int C, int h, int w, int ch, int cw, float fill,
                 int has_fill, float* __restrict__ dst, uint8_t* __restrict__ dst_mask) {
   const int b = blockIdx.z, c = blockIdx.y;
   const int cw4 = cw >> 2;
+  const int rows_per = (ch + ROWS - 1) / ROWS;
   const int o4 = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o4 >= ch * cw4) return;
-  const int i = o4 / cw4, j0 = (o4 - i * cw4) << 2;
+  if (o4 >= rows_per * cw4) return;
+  const int i0 = o4 / cw4, j0 = (o4 - i0 * cw4) << 2;
   const float pw = (float)(w + 2), ph = (float)(h + 2);
   const float cxp = center[2 * b] + 1.0f, cyp = center[2 * b + 1] + 1.0f;
-  const float gy = (((float)i - (float)ch / 2.0f) + (cyp - ph / 2.0f)) / (ph / 2.0f);
-  float iy = ((gy + 1.0f) / 2.0f) * (ph - 1.0f);
-  if (has_fill) iy = fminf(ph - 1.0f, fmaxf(iy, 0.0f));
-  const float fy = nearbyintf(iy);
-  const bool row_in = fy >= 1.0f && fy <= (float)h;
-  const bool row_pad = fy >= 0.0f && fy <= ph - 1.0f;
   const size_t plane = ((size_t)b * C + c);
-  const float* srow = src + plane * h * w + (size_t)(row_in ? (int)fy - 1 : 0) * w;
-  const uint8_t* mrow = src_mask ? src_mask + plane * h * w + (size_t)(row_in ? (int)fy - 1 : 0) * w : nullptr;
-  float v[4];
-  uint32_t m4 = 0;
+  // the four source columns first, then every load unconditionally -- a cell outside the map reads
+  // column 0 of the row and discards it -- so that all of a thread's loads are in flight together
+  // (behind per-cell branches they went out one by one: the kernel waited 73 % of its time)
+  int col[4];
+  bool in_x[4], pad_x[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float gx = (((float)(j0 + k) - (float)cw / 2.0f) + (cxp - pw / 2.0f)) / (pw / 2.0f);
     float ix = ((gx + 1.0f) / 2.0f) * (pw - 1.0f);
     if (has_fill) ix = fminf(pw - 1.0f, fmaxf(ix, 0.0f));
     const float fx = nearbyintf(ix);
-    float val = has_fill ? fill : 0.0f;
-    uint32_t m = 0;
-    if (row_in && fx >= 1.0f && fx <= (float)w) {
-      val = srow[(int)fx - 1];
-      if (mrow) m = mrow[(int)fx - 1];
-    } else if (!(row_pad && fx >= 0.0f && fx <= pw - 1.0f)) {
-      val = 0.0f;
-    }
-    v[k] = val;
-    m4 |= m << (8 * k);
+    in_x[k] = (fx >= 1.0f) & (fx <= (float)w);
+    pad_x[k] = (fx >= 0.0f) & (fx <= pw - 1.0f);
+    col[k] = in_x[k] ? (int)fx - 1 : 0;
   }
-  const size_t to = plane * ch * cw + (size_t)i * cw + j0;
-  *reinterpret_cast<float4*>(dst + to) = make_float4(v[0], v[1], v[2], v[3]);
-  if (dst_mask) *reinterpret_cast<uint32_t*>(dst_mask + to) = m4;
+  const bool run4 = in_x[0] & in_x[3] & (col[1] == col[0] + 1) & (col[2] == col[0] + 2) & (col[3] == col[0] + 3);
+  bool row_in[ROWS], row_pad[ROWS], live[ROWS];
+  float v[ROWS][4];
+  uint32_t mk[ROWS][4];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int i = i0 + r * rows_per;
+    live[r] = i < ch;
+    const float gy = (((float)i - (float)ch / 2.0f) + (cyp - ph / 2.0f)) / (ph / 2.0f);
+    float iy = ((gy + 1.0f) / 2.0f) * (ph - 1.0f);
+    if (has_fill) iy = fminf(ph - 1.0f, fmaxf(iy, 0.0f));
+    const float fy = nearbyintf(iy);
+    row_in[r] = fy >= 1.0f && fy <= (float)h;
+    row_pad[r] = fy >= 0.0f && fy <= ph - 1.0f;
+    const size_t row_at = plane * h * w + (size_t)(row_in[r] ? (int)fy - 1 : 0) * w;
+    if (run4) {
+      // four consecutive source columns (all but the few groups where the sampling grid's scale
+      // (w + 1) / (w + 2) repeats a column, and those at the map's edge): ONE 16-byte load of the values
+      // and one 4-byte load of the mask bytes, at whatever alignment the crop's offset gives them
+      const F4u t = *reinterpret_cast<const F4u*>(src + row_at + col[0]);
+      v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
+      const uint32_t m = src_mask ? reinterpret_cast<const U4u*>(src_mask + row_at + col[0])->v : 0u;
+      mk[r][0] = m & 0xffu; mk[r][1] = (m >> 8) & 0xffu; mk[r][2] = (m >> 16) & 0xffu; mk[r][3] = m >> 24;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[r][k] = src[row_at + col[k]];
+        mk[r][k] = src_mask ? src_mask[row_at + col[k]] : 0u;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    if (!live[r]) continue;
+    uint32_t m4 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool in = row_in[r] & in_x[k], pad = row_pad[r] & pad_x[k];
+      v[r][k] = in ? v[r][k] : (pad ? (has_fill ? fill : 0.0f) : 0.0f);
+      m4 |= (in ? mk[r][k] : 0u) << (8 * k);
+    }
+    const size_t to = plane * ch * cw + (size_t)(i0 + r * rows_per) * cw + j0;
+    *reinterpret_cast<float4*>(dst + to) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+    if (dst_mask) *reinterpret_cast<uint32_t*>(dst_mask + to) = m4;
+  }
 }
+
+#ifndef DM_X_CROP_ROWS
+#define DM_X_CROP_ROWS 1
+#endif
 
 hipError_t run_crop_nearest(const float* src, const uint8_t* src_mask, const float* center, int B,
                             int C, int h, int w, int ch, int cw, float fill, int has_fill,
                             float* dst, uint8_t* dst_mask, hipStream_t s) {
   if (cw % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0 && reinterpret_cast<uintptr_t>(dst_mask) % 4 == 0) {
-    const dim3 grid((unsigned)(((size_t)ch * (cw / 4) + 255) / 256), C, B);
-    hipLaunchKernelGGL(k_crop_nearest4, grid, dim3(256), 0, s, src, src_mask, center, C, h, w, ch, cw,
+    constexpr int kRows = DM_X_CROP_ROWS;
+    const dim3 grid((unsigned)(((size_t)((ch + kRows - 1) / kRows) * (cw / 4) + 255) / 256), C, B);
+    hipLaunchKernelGGL(k_crop_nearest4<kRows>, grid, dim3(256), 0, s, src, src_mask, center, C, h, w, ch, cw,
                        fill, has_fill, dst, dst_mask);
     return hipGetLastError();
   }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/build_variant.sh NAME [extra hipcc flags]: an experimental build of the library
-# (dm_window.hip and dm_strip.hip recompiled with the flags) -> tools/tmp/libdm_NAME.so; select it with
+# (dm_window.hip, dm_strip.hip and dm_points.hip recompiled with the flags) -> tools/tmp/libdm_NAME.so; select it with
 # DUNGEON_MAPS_AMD_LIB=$PWD/tools/tmp/libdm_NAME.so
 set -e
 name=$1; shift
@@ -12,6 +12,8 @@ make -C $src >/dev/null
   "$@" -c $src/dm_window.hip -o /tmp/dm_window_$name.o
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
   "$@" -c $src/dm_strip.hip -o /tmp/dm_strip_$name.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
+  "$@" -c $src/dm_points.hip -o /tmp/dm_points_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $here/tools/tmp/libdm_$name.so \
-  $src/dm_api.o $src/dm_generic.o /tmp/dm_window_$name.o /tmp/dm_strip_$name.o $src/dm_points.o
+  $src/dm_api.o $src/dm_generic.o /tmp/dm_window_$name.o /tmp/dm_strip_$name.o /tmp/dm_points_$name.o
 echo $here/tools/tmp/libdm_$name.so

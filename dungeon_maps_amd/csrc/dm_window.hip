@@ -682,8 +682,8 @@ hipError_t run_window(const dm_params& p, const dm_frame* frames_host, const flo
     fa.B = p.B; fa.b0 = 0; fa.accumulate = 0;
     fa.dc = oc_total; fa.mh = p.mh; fa.mw = p.mw; fa.fill = p.fill;
     fa.unions = st.g_unions; fa.maps = out; fa.fused = fused; fa.fused_mask = fused_mask;
-    const dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kFuseGroups - 1) / kFuseGroups), oc_total);
-    const dim3 blk(kFuseGroups * kFuseLanes);
+    const dim3 g((unsigned)(((size_t)p.mh * p.mw / 4 + kUnionGroups - 1) / kUnionGroups), oc_total);
+    const dim3 blk(kUnionGroups * kUnionLanes);
     e = is_max ? launch(k_fuse_unions<true>, g, blk, 0, s, fa)
                : launch(k_fuse_unions<false>, g, blk, 0, s, fa);
     if (e != hipSuccess) return e;

@@ -737,18 +737,30 @@ struct FuseArgs {
 constexpr int kFuseGroups = 32;     // float4 groups of the fused map per block
 constexpr int kFuseLanes = 8;       // threads sharing one group, frames b = lane (mod 8)
 
+#ifndef DM_X_UNION_GROUPS
+#define DM_X_UNION_GROUPS 32
+#endif
+#ifndef DM_X_UNION_LANES
+#define DM_X_UNION_LANES 8
+#endif
+#ifndef DM_X_UNION_DEPTH
+#define DM_X_UNION_DEPTH 8
+#endif
+constexpr int kUnionGroups = DM_X_UNION_GROUPS;   // k_fuse_unions: float4 groups of the fused map per block,
+constexpr int kUnionLanes = DM_X_UNION_LANES;     //   threads sharing one group (frames b = lane mod that many),
+constexpr int kUnionDepth = DM_X_UNION_DEPTH;     //   map loads a thread keeps in flight
 // Block = 32 groups x 8 frame lanes.  Each thread tests the unions of its frames
 // (lane, lane + 8, ...) eight at a time, loads the covered maps (independent
 // 16-byte loads), and the 8 partial results of a group are combined through LDS.
 template <bool IS_MAX>
-__global__ void __launch_bounds__(kFuseGroups * kFuseLanes)
+__global__ void __launch_bounds__(kUnionGroups * kUnionLanes)
 k_fuse_unions(FuseArgs a) {
-  __shared__ float4 part[kFuseLanes][kFuseGroups];
-  __shared__ int4 lunion[kFuseGroups * kFuseLanes];      // union windows of up to 256 frames
+  __shared__ float4 part[kUnionLanes][kUnionGroups];
+  __shared__ int4 lunion[kUnionGroups * kUnionLanes];      // union windows of up to 256 frames
   const int ch = blockIdx.y;
   const int g4 = a.mw >> 2;
-  const int gi = threadIdx.x & (kFuseGroups - 1), lane = threadIdx.x / kFuseGroups;
-  const int g = blockIdx.x * kFuseGroups + gi;
+  const int gi = threadIdx.x & (kUnionGroups - 1), lane = threadIdx.x / kUnionGroups;
+  const int g = blockIdx.x * kUnionGroups + gi;
   const bool live = g < g4 * a.mh;
   const int z = live ? g / g4 : 0, x = live ? (g - z * g4) << 2 : 0;
   const size_t M = (size_t)a.mh * a.mw;
@@ -756,7 +768,7 @@ k_fuse_unions(FuseArgs a) {
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
   if (a.accumulate && lane == 0 && live)
     acc = *reinterpret_cast<const float4*>(a.fused + (size_t)ch * M + cell);
-  constexpr int kStage = kFuseGroups * kFuseLanes;
+  constexpr int kStage = kUnionGroups * kUnionLanes;
   for (int c0 = 0; c0 < a.B; c0 += kStage) {
     // the union windows go through LDS: one load per thread instead of a dependent global
     // load in front of every map load
@@ -767,11 +779,11 @@ k_fuse_unions(FuseArgs a) {
     }
     __syncthreads();
     const int n = a.B - c0 < kStage ? a.B - c0 : kStage;
-    for (int b0 = lane; b0 < n; b0 += 8 * kFuseLanes) {
-      float4 v[8];
+    for (int b0 = lane; b0 < n; b0 += kUnionDepth * kUnionLanes) {
+      float4 v[kUnionDepth];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int bb = b0 + k * kFuseLanes;
+      for (int k = 0; k < kUnionDepth; ++k) {
+        const int bb = b0 + k * kUnionLanes;
         v[k] = acc;
         if (bb < n) {
           const int4 U = lunion[bb];
@@ -781,7 +793,7 @@ k_fuse_unions(FuseArgs a) {
         }
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < kUnionDepth; ++k) {
         acc.x = IS_MAX ? fmaxf(acc.x, v[k].x) : fminf(acc.x, v[k].x);
         acc.y = IS_MAX ? fmaxf(acc.y, v[k].y) : fminf(acc.y, v[k].y);
         acc.z = IS_MAX ? fmaxf(acc.z, v[k].z) : fminf(acc.z, v[k].z);
@@ -793,7 +805,7 @@ k_fuse_unions(FuseArgs a) {
   __syncthreads();
   if (lane == 0 && live) {
 #pragma unroll
-    for (int k = 1; k < kFuseLanes; ++k) {
+    for (int k = 1; k < kUnionLanes; ++k) {
       const float4 o = part[k][gi];
       acc.x = IS_MAX ? fmaxf(acc.x, o.x) : fminf(acc.x, o.x);
       acc.y = IS_MAX ? fmaxf(acc.y, o.y) : fminf(acc.y, o.y);

@@ -738,20 +738,24 @@ constexpr int kFuseGroups = 32;     // float4 groups of the fused map per block
 constexpr int kFuseLanes = 8;       // threads sharing one group, frames b = lane (mod 8)
 
 #ifndef DM_X_UNION_GROUPS
-#define DM_X_UNION_GROUPS 32
+#define DM_X_UNION_GROUPS 64
 #endif
 #ifndef DM_X_UNION_LANES
-#define DM_X_UNION_LANES 8
+#define DM_X_UNION_LANES 4
 #endif
 #ifndef DM_X_UNION_DEPTH
-#define DM_X_UNION_DEPTH 8
+#define DM_X_UNION_DEPTH 16
 #endif
 constexpr int kUnionGroups = DM_X_UNION_GROUPS;   // k_fuse_unions: float4 groups of the fused map per block,
 constexpr int kUnionLanes = DM_X_UNION_LANES;     //   threads sharing one group (frames b = lane mod that many),
 constexpr int kUnionDepth = DM_X_UNION_DEPTH;     //   map loads a thread keeps in flight
-// Block = 32 groups x 8 frame lanes.  Each thread tests the unions of its frames
-// (lane, lane + 8, ...) eight at a time, loads the covered maps (independent
-// 16-byte loads), and the 8 partial results of a group are combined through LDS.
+// Block = 64 groups x 4 frame lanes.  Each thread tests the unions of its frames
+// (lane, lane + 4, ...) sixteen at a time, loads the covered maps (independent
+// 16-byte loads), and the 4 partial results of a group are combined through LDS.
+// (Round 4: 1 KB of a frame's map row per block instead of 512 B -- longer bursts per frame -- and
+// all of a thread's 16 loads of a 64-frame batch in flight at once: 163 -> 136 us per cfg3 step
+// (40 channels), 6.5 -> 5.7 us at cfg2; 32 x 8 x 8 before, 64 x 8, 128 x 2 / x 4, 64 x 2, 32 x 4
+// measured worse: -DDM_X_UNION_GROUPS / _LANES / _DEPTH.)
 template <bool IS_MAX>
 __global__ void __launch_bounds__(kUnionGroups * kUnionLanes)
 k_fuse_unions(FuseArgs a) {

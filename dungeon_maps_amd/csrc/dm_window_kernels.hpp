@@ -591,6 +591,10 @@ struct MergeArgs {
 };
 
 constexpr int kMergeThreads = 256;
+#ifndef DM_X_MERGE_DEPTH
+#define DM_X_MERGE_DEPTH 8
+#endif
+constexpr int kMergeDepth = DM_X_MERGE_DEPTH;      // slab loads a thread of the merge kernels keeps in flight
 
 // Writes the union window U of every (frame, channel): max/min over the slabs covering
 // each cell, fill where none does.  One float4 group per thread, row-major inside U, so
@@ -612,21 +616,37 @@ k_window_merge(MergeArgs a) {
   const int zb = U.z0 + row, x = U.x0 + ((i - row * ug4) << 2);
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
   uint4 cnt = make_uint4(0u, 0u, 0u, 0u);      // mean: points per cell
-  for (int p = 0; p < a.nparts; ++p) {
-    const Window w = widen(a.wins[bl * win_stride + p]);
-    if (w.w == 0) continue;
-    const unsigned ux = (unsigned)(x - w.x0), uz = (unsigned)(zb - w.z0);
-    if (ux >= (unsigned)w.w || uz >= (unsigned)w.h) continue;
-    const float* slab = a.slabs + ((size_t)fc * a.nparts + p) * a.slab_stride;
-    const float4 s = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
-    if (RED == kMean) {
-      const uint4 c = *reinterpret_cast<const uint4*>(slab + (size_t)w.w * w.h + (size_t)uz * w.w + ux);
-      cnt.x += c.x; cnt.y += c.y; cnt.z += c.z; cnt.w += c.w;
+  // kMergeDepth parts at a time: which of their windows hold the group first, then their slab loads all in
+  // flight together, then the reduction in part order (part by part -- test, load, wait, combine -- a group under
+  // six windows was six dependent round trips: 11.5 us per launch at cfg5)
+  for (int p0 = 0; p0 < a.nparts; p0 += kMergeDepth) {
+    float4 s[kMergeDepth];
+    uint4 c[kMergeDepth];
+    bool hit[kMergeDepth];
+#pragma unroll
+    for (int k = 0; k < kMergeDepth; ++k) {
+      const int p = p0 + k < a.nparts ? p0 + k : a.nparts - 1;
+      const Window w = widen(a.wins[bl * win_stride + p]);
+      const unsigned ux = (unsigned)(x - w.x0), uz = (unsigned)(zb - w.z0);
+      hit[k] = p0 + k < a.nparts && w.w != 0 && ux < (unsigned)w.w && uz < (unsigned)w.h;
+      const float* slab = a.slabs + ((size_t)fc * a.nparts + p) * a.slab_stride;
+      s[k] = acc;
+      c[k] = cnt;
+      if (hit[k]) {
+        s[k] = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
+        if (RED == kMean)
+          c[k] = *reinterpret_cast<const uint4*>(slab + (size_t)w.w * w.h + (size_t)uz * w.w + ux);
+      }
     }
-    acc.x = combine<RED>(acc.x, s.x);
-    acc.y = combine<RED>(acc.y, s.y);
-    acc.z = combine<RED>(acc.z, s.z);
-    acc.w = combine<RED>(acc.w, s.w);
+#pragma unroll
+    for (int k = 0; k < kMergeDepth; ++k) {
+      if (!hit[k]) continue;
+      if (RED == kMean) { cnt.x += c[k].x; cnt.y += c[k].y; cnt.z += c[k].z; cnt.w += c[k].w; }
+      acc.x = combine<RED>(acc.x, s[k].x);
+      acc.y = combine<RED>(acc.y, s[k].y);
+      acc.z = combine<RED>(acc.z, s[k].z);
+      acc.w = combine<RED>(acc.w, s[k].w);
+    }
   }
   if (RED == kMean) mean_of(acc, cnt);
   const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw + x;
@@ -697,20 +717,34 @@ k_window_merge_tiled(MergeArgs a) {
   float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
   uint4 cnt = make_uint4(0u, 0u, 0u, 0u);      // mean: points per cell
   const float* slabs = a.slabs + (size_t)fc * a.nparts * a.slab_stride;
-  for (int j = 0; j < n; ++j) {
-    const Window w = widen(lwin[j]);
-    const unsigned ux = (unsigned)(x - w.x0), uz = (unsigned)(zb - w.z0);
-    if (ux >= (unsigned)w.w || uz >= (unsigned)w.h) continue;
-    const float* slab = slabs + (size_t)lpart[j] * a.slab_stride;
-    const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
-    if (RED == kMean) {
-      const uint4 c = *reinterpret_cast<const uint4*>(slab + (size_t)w.w * w.h + (size_t)uz * w.w + ux);
-      cnt.x += c.x; cnt.y += c.y; cnt.z += c.z; cnt.w += c.w;
+  for (int j0 = 0; j0 < n; j0 += kMergeDepth) {        // (as in k_window_merge: the loads of kMergeDepth candidates together)
+    float4 s[kMergeDepth];
+    uint4 c[kMergeDepth];
+    bool hit[kMergeDepth];
+#pragma unroll
+    for (int k = 0; k < kMergeDepth; ++k) {
+      const int j = j0 + k < n ? j0 + k : n - 1;
+      const Window w = widen(lwin[j]);
+      const unsigned ux = (unsigned)(x - w.x0), uz = (unsigned)(zb - w.z0);
+      hit[k] = j0 + k < n && ux < (unsigned)w.w && uz < (unsigned)w.h;
+      const float* slab = slabs + (size_t)lpart[j] * a.slab_stride;
+      s[k] = acc;
+      c[k] = cnt;
+      if (hit[k]) {
+        s[k] = *reinterpret_cast<const float4*>(slab + (size_t)uz * w.w + ux);
+        if (RED == kMean)
+          c[k] = *reinterpret_cast<const uint4*>(slab + (size_t)w.w * w.h + (size_t)uz * w.w + ux);
+      }
     }
-    acc.x = combine<RED>(acc.x, v.x);
-    acc.y = combine<RED>(acc.y, v.y);
-    acc.z = combine<RED>(acc.z, v.z);
-    acc.w = combine<RED>(acc.w, v.w);
+#pragma unroll
+    for (int k = 0; k < kMergeDepth; ++k) {
+      if (!hit[k]) continue;
+      if (RED == kMean) { cnt.x += c[k].x; cnt.y += c[k].y; cnt.z += c[k].z; cnt.w += c[k].w; }
+      acc.x = combine<RED>(acc.x, s[k].x);
+      acc.y = combine<RED>(acc.y, s[k].y);
+      acc.z = combine<RED>(acc.z, s[k].z);
+      acc.w = combine<RED>(acc.w, s[k].w);
+    }
   }
   if (RED == kMean) mean_of(acc, cnt);
   const size_t cell = fo * (size_t)a.mh * a.mw + (size_t)zb * a.mw + x;

@@ -768,8 +768,16 @@ struct FuseArgs {
   uint8_t* fused_mask;
 };
 
-constexpr int kFuseGroups = 32;     // float4 groups of the fused map per block
-constexpr int kFuseLanes = 8;       // threads sharing one group, frames b = lane (mod 8)
+#ifndef DM_X_FUSEWIN_GROUPS
+#define DM_X_FUSEWIN_GROUPS 16
+#endif
+#ifndef DM_X_FUSEWIN_LANES
+#define DM_X_FUSEWIN_LANES 16
+#endif
+// (16 groups x 16 lanes x 16 loads in flight: 8.0 us per launch at cfg4; 32 x 8 x 16: 8.9-9.2, 32 x 16: 8.2, 16 x 32: 9.2,
+// 8 x 32: 9.8, 64 x 8: 11.3, 64 x 4 / 32 x 4 with 32 loads: 13.2 / 13.4 -- a tile's 100-200 candidates want many lanes)
+constexpr int kFuseGroups = DM_X_FUSEWIN_GROUPS;     // k_fuse_windows: float4 groups of the fused map per block
+constexpr int kFuseLanes = DM_X_FUSEWIN_LANES;       //   threads sharing one group (they split the candidate windows)
 
 #ifndef DM_X_UNION_GROUPS
 #define DM_X_UNION_GROUPS 64
@@ -861,7 +869,7 @@ k_fuse_unions(FuseArgs a) {
 // Direct batch fuse from the slabs (dm_orth_project_fused_f32): fused[c] =
 // max/min over every (frame, part) window covering c of its slab value -- the
 // per-frame maps are never materialised.  Same block shape as k_fuse_unions; the
-// 8 lanes of a group split the B * nparts windows.
+// kFuseLanes lanes of a group split the B * nparts windows.
 struct FuseWinArgs {
   int nwin;                   // windows of this launch: (frames of the chunk) * nparts
   int b0;                     // first frame of the chunk
@@ -896,7 +904,7 @@ k_fuse_windows(FuseWinArgs a) {
   const int total = g4 * a.mh;
   const size_t M = (size_t)a.mh * a.mw;
   // Most of a large global map is out of reach of the whole call.  The first `heavy`
-  // blocks own the 32-group tiles of the call's bounding box (one map row each); the
+  // blocks own the kFuseGroups-group tiles of the call's bounding box (one map row each); the
   // others stream the fill value (or, accumulating, only refresh the mask) over
   // everything outside it, 8 groups per thread: few, fat blocks instead of one tiny
   // block per 128 cells of a mostly empty map.
@@ -972,7 +980,7 @@ k_fuse_windows(FuseWinArgs a) {
       }
     }
     __syncthreads();
-    // round 2: the 8 lanes of a group split the candidates, kFuseDepth slab loads in flight (16: a tile of a
+    // round 2: the lanes of a group split the candidates, kFuseDepth slab loads in flight (16: a tile of a
     // trajectory has 100-200 candidates, 12-25 per lane -- with eight in flight that was up to four dependent
     // rounds of loads, 10.3 us per launch at cfg4; with sixteen 9.2)
     const int n = ncand;

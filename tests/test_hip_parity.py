@@ -385,6 +385,27 @@ def test_full_size_properties(dmap):
   assert torch.equal(f3, t3.amax(dim=0))
 
 
+@pytest.mark.parametrize("reduction,fill", [("max", -np.inf), ("min", np.inf), ("max", 0.25)])
+def test_batch_fuse_over_many_frames_and_channels(dmap, reduction, fill):
+  """The batch fuse (k_fuse_unions) beyond one stage of its union table (more than 256 frames) and over
+  several channels: fused == max / min over the batch axis of the per-frame maps, mask == f(map, fill)."""
+  B, C, H, W, M = 300, 3, 24, 32, 64
+  depth, pose = _synthetic(B, H, W, seed=77)
+  g = np.random.default_rng(5)
+  value = g.normal(size=(B, C, H, W)).astype(np.float32)
+  proj = dmap.MapProjector(
+      width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
+      width_offset=M / 2., height_offset=M / 2., map_res=0.12, map_width=M, map_height=M,
+      trunc_depth_min=0.15, trunc_depth_max=5.05, to_global=True, fill_value=fill, reduction=reduction)
+  for vm in (None, torch.from_numpy(value).cuda()):
+    top, mask, fused, fmask = proj.orth_project_and_fuse(torch.from_numpy(depth).cuda(), value_map=vm,
+                                                         cam_pose=torch.from_numpy(pose))
+    want = top.amax(dim=0) if reduction == "max" else top.amin(dim=0)
+    assert torch.equal(fused, want)
+    assert torch.equal(fmask, dmap.mask_from_map(fused, fill))
+    assert mask.any()
+
+
 # --------------------------------------------------------------------------
 # LDS-windowed fast path vs the generic global-atomic path (same device)
 # --------------------------------------------------------------------------

@@ -521,6 +521,31 @@ def main():
       del prep
     except _native.NativeError as e:
       result["prepared_frames"] = {"error": str(e)[:200]}
+  if rank == 0 and world == 1 and not fused_only and not cfg5 and rot >= 2:
+    # the same steps issued alternately on TWO streams (independent batches, their own outputs): reported beside
+    # `value`, which stays one stream in program order.  A scatter workgroup fills a CU's LDS, so the second
+    # stream's workgroups start where the first's end -- the launches are out of step and the kernel
+    # boundaries and heads of one stream run under the loops of the other
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    n_t = max(32, min(128, args.steps)) // 2 * 2
+
+    def two(n):
+      for j in range(n):
+        with torch.cuda.stream(streams[j % 2]):
+          proj.orth_project_and_fuse(depth_sets[j % rot], value_map=value_sets[j % rot],
+                                     cam_pose=pose_sets[j % len(pose_sets)], out=out_sets[j % rot],
+                                     fused_out=fused_sets[j % rot])
+    torch.cuda.synchronize()
+    two(8)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    two(n_t)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    result["two_streams"] = {"value": B * n_t / dt, "unit": "frames/s", "steps": n_t, "ms_per_step": dt / n_t * 1e3,
+                             "note": "the timed loop's call alternately on two HIP streams (independent batches and "
+                                     "output sets; wall clock over all steps): what a caller with two batches in "
+                                     "flight gets; NOT the headline `value`"}
   if rank == 0 and world == 1 and args.depth == "uniform" and not fused_only and C == 0 and not cfg5:
     # the same step on scene-like depth (floor + walls: many pixels per cell):
     # reported beside the headline number, outside its timed region

@@ -276,6 +276,12 @@ StripKernel pick_index_kernel(bool has_valid, bool lean) {
   return has_valid ? k_strip_scatter<kMax, true, false, false, kIndexOut>
                    : k_strip_scatter<kMax, false, false, false, kIndexOut>;
 }
+#ifdef DM_X_NO_XCD_UNITS
+constexpr bool g_no_xcd_units = true;       // (measurement: the value pass in plain dispatch order)
+#else
+constexpr bool g_no_xcd_units = false;
+#endif
+
 StripKernel pick_value_kernel(bool is_max) {
   return is_max ? k_strip_scatter<kMax, false, true, true, kFromList>
                 : k_strip_scatter<kMin, false, true, true, kFromList>;
@@ -408,6 +414,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const
   // k_strip_combine_one, which takes its share of the fill duty)
   sa.defer_outer = g_fill_split >= 0 && oc_total < kListMinChannels;
   sa.head_share = sa.defer_outer ? g_fill_split : 0;
+  sa.xcd_units = 0;
   sa.rig = rg.args;
 #ifdef DM_STAMPS
   sa.stamps = g_stamp_buffer;
@@ -450,6 +457,7 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const
     for (int ch0 = 0; ch0 < oc_total; ch0 += group) {
       const int oc = oc_total - ch0 < group ? oc_total - ch0 : group;
       sa.oc = oc; sa.ch0 = ch0;
+      sa.xcd_units = from_list && (plan.P * nb) % 8 == 0 && !g_no_xcd_units;
       e = launch(kfn, from_list ? dim3(oc, plan.P, nb) : dim3(plan.P, oc, nb), dim3(kScatterThreads),
                  lds_bytes, s, sa);
       if (e != hipSuccess) return e;

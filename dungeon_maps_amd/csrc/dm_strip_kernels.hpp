@@ -206,6 +206,7 @@ struct StripArgs {
   // (HBM idles there while the row tables are derived), the others by the combine kernel (a chain
   // of dependent round trips under which HBM idles too): kFillSplit* below.
   int defer_outer, head_share;
+  int xcd_units;              // value pass: the workgroups of one (frame, strip) share an XCD (its L2 keeps their part of the pixel list)
   const float* poses_dev;     // (B, kPoseFloats) in device memory (prepared frames), or NULL: `poses`
   const float* depth;
   const float* value;         // (B, oc_total, H, W) or NULL: project the heights
@@ -290,10 +291,24 @@ k_strip_scatter(StripArgs a) {
   constexpr int kStripFillPerHalf = DM_X_FILL_PER_HALF;
   extern __shared__ float lds[];
   // (the value pass runs channel-major: the workgroups of one (frame, strip) -- which read the same
-  // part of the pixel list -- are dispatched together)
-  const int part = MODE == kFromList ? blockIdx.y : blockIdx.x;   // column strip
-  const int chl = MODE == kFromList ? blockIdx.x : blockIdx.y;    // channel within this launch's group
-  const int bl = blockIdx.z, b = a.b0 + bl;
+  // part of the pixel list -- are dispatched together, and on one XCD where the launch allows it: below)
+  int part = MODE == kFromList ? blockIdx.y : blockIdx.x;   // column strip
+  int chl = MODE == kFromList ? blockIdx.x : blockIdx.y;    // channel within this launch's group
+  int bl = blockIdx.z;
+  if (MODE == kFromList && a.xcd_units) {
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one: observed, for speed only).  The
+    // channels of one (frame, strip) read the same part of the pixel list: with consecutive block indices they
+    // sat on all eight XCDs and every L2 fetched that part (the list was read ~14 times per call, PMC).  Here the
+    // blocks of one XCD walk the units (frame, strip) it owns channel by channel: one L2 fetches a unit's part once.
+    const int lin = (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z);
+    const int xcd = lin & 7, slot = lin >> 3, oc = (int)gridDim.x;
+    const int round = slot / oc;
+    const int unit = round * 8 + xcd;           // (units = strips x frames of the launch: a multiple of 8)
+    chl = slot - round * oc;
+    bl = unit / a.P;
+    part = unit - bl * a.P;
+  }
+  const int b = a.b0 + bl;
   const int ch = a.ch0 + chl;
   const int dch = a.dc == 1 ? 0 : ch;
   const int nparts = a.P;

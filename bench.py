@@ -106,6 +106,9 @@ def main():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-other-configs", action="store_true",
                   help="skip the other BASELINE.json configs (reported outside the timed region)")
+  ap.add_argument("--no-two-streams", action="store_true",
+                  help="skip the two-stream figure (profiling runs: its overlapping kernels would blur the "
+                       "per-kernel averages)")
   ap.add_argument("--cpu-seconds", type=float, default=12.0)
   ap.add_argument("--event-every", type=int, default=8,
                   help="bracket every n-th timed step with HIP events (an event record costs "
@@ -521,7 +524,7 @@ def main():
       del prep
     except _native.NativeError as e:
       result["prepared_frames"] = {"error": str(e)[:200]}
-  if rank == 0 and world == 1 and not fused_only and not cfg5 and rot >= 2:
+  if rank == 0 and world == 1 and not fused_only and not cfg5 and rot >= 2 and not args.no_two_streams:
     # the same steps issued alternately on TWO streams (independent batches, their own outputs): reported beside
     # `value`, which stays one stream in program order.  A scatter workgroup fills a CU's LDS, so the second
     # stream's workgroups start where the first's end -- the launches are out of step and the kernel

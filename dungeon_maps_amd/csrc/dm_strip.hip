@@ -276,10 +276,15 @@ StripKernel pick_index_kernel(bool has_valid, bool lean) {
   return has_valid ? k_strip_scatter<kMax, true, false, false, kIndexOut>
                    : k_strip_scatter<kMax, false, false, false, kIndexOut>;
 }
-#ifdef DM_X_NO_XCD_UNITS
-constexpr bool g_no_xcd_units = true;       // (measurement: the value pass in plain dispatch order)
-#else
+// The value pass with the workgroups of one (frame, strip) on one XCD (StripArgs::xcd_units): that XCD's L2 then
+// fetches the unit's part of the pixel list once (PMC at cfg3: 3.72 -> 3.36 GB fetched by the pass, the list read
+// ~5.5 times per call instead of ~14) -- and the pass takes 2 % LONGER (1 442 / 1 451 against 1 416 / 1 421 us on one
+// box): the re-reads were hits in the Infinity Cache, which cost HBM nothing, while a fixed 32 units per XCD
+// balance worse than blocks dealt one by one.  Off; -DDM_X_XCD_UNITS switches it on.
+#ifdef DM_X_XCD_UNITS
 constexpr bool g_no_xcd_units = false;
+#else
+constexpr bool g_no_xcd_units = true;
 #endif
 
 StripKernel pick_value_kernel(bool is_max) {

@@ -13,8 +13,8 @@ python bench.py --gpus 1 --steps 20 --warmup 5 --workload cfg5 --no-cpu-baseline
 python bench.py --gpus 1 --steps 20 --warmup 5 --workload cfg4 --no-cpu-baseline > $O/bench_cfg4.json 2> $O/bench_cfg4.err; echo "cfg4 rc=$?"
 python bench.py --gpus 1 --steps 6 --warmup 2 --workload cfg3 --no-cpu-baseline > $O/bench_cfg3.json 2> $O/bench_cfg3.err; echo "cfg3 rc=$?"
 DM_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $O/bench_gloo2.json 2> $O/bench_gloo2.err; echo "gloo2 rc=$?"
-B2="python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs"
-B3="python3 bench.py --gpus 1 --steps 4 --warmup 2 --workload cfg3 --no-cpu-baseline"
+B2="python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-two-streams"
+B3="python3 bench.py --gpus 1 --steps 4 --warmup 2 --workload cfg3 --no-cpu-baseline --no-two-streams"
 B4="python3 bench.py --gpus 1 --steps 20 --warmup 5 --workload cfg4 --no-cpu-baseline"
 B5="python3 bench.py --gpus 1 --steps 10 --warmup 3 --workload cfg5 --no-cpu-baseline"
 for w in cfg2 cfg3 cfg4 cfg5; do

@@ -532,12 +532,15 @@ def main():
     streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     n_t = max(32, min(128, args.steps)) // 2 * 2
 
+    per_stream = max(1, rot // 2)       # buffer sets of each stream (its own: no two streams write one set)
+
     def two(n):
       for j in range(n):
+        k = (j // 2 % per_stream) * 2 + j % 2          # (rot >= 2: sets 0, 2, ... for stream 0, 1, 3, ... for stream 1)
         with torch.cuda.stream(streams[j % 2]):
-          proj.orth_project_and_fuse(depth_sets[j % rot], value_map=value_sets[j % rot],
-                                     cam_pose=pose_sets[j % len(pose_sets)], out=out_sets[j % rot],
-                                     fused_out=fused_sets[j % rot])
+          proj.orth_project_and_fuse(depth_sets[k], value_map=value_sets[k],
+                                     cam_pose=pose_sets[j % len(pose_sets)], out=out_sets[k],
+                                     fused_out=fused_sets[k])
     torch.cuda.synchronize()
     two(8)
     torch.cuda.synchronize()

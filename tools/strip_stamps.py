@@ -108,6 +108,25 @@ if len(loop) % 4 == 0 and not os.environ.get("DM_STAMPS_STRIPS") and not C:
   start = (raw[:, 0] - raw[:, 0].min()) * 0.01
   print("corr(loop, start time) = %.2f" % np.corrcoef(loop, start)[0, 1])
 
+if len(loop) % 4 == 0 and len(loop) == 4 * B and not os.environ.get("DM_STAMPS_STRIPS") and not C:
+  # does a workgroup's loop time follow its LDS window's row stride?  (row stride mod 32 words: the banks a
+  # column of cells falls into)
+  from dungeon_maps_amd import functional as Fn
+  cam = proj.cam_params
+  call = Fn._Call(depth, None, None, pose, mw / 2., mh / 2., proj.cam_pitch, proj.cam_height, 0.03, mw, mh, cam.fx, cam.fy,
+                  cam.cx, cam.cy, 0.15, 5.05, None, None, True, True, -np.inf, None, None)
+  geom = np.zeros((B, 8 + 4 * 8), dtype=np.int32)
+  P = _native.lib().dm_debug_strip_geometry(ctypes.byref(call.params), ctypes.c_void_p(call.frames.data_ptr()),
+                                            geom.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), None, None)
+  if P == 4:
+    ww = geom[:, 8:8 + 16].reshape(B, 4, 4)[:, :, 2].reshape(-1)        # window width of workgroup (frame, strip)
+    hh = geom[:, 8:8 + 16].reshape(B, 4, 4)[:, :, 3].reshape(-1)
+    for m in (32, 16, 8):
+      print("pixel loop by window width mod %d:" % m, {int(k): (round(float(loop[ww % m == k].mean()), 2), int((ww % m == k).sum()))
+                                                       for k in sorted(set((ww % m).tolist()))})
+    print("corr(loop, window cells) = %.2f   corr(loop, window width) = %.2f   corr(loop, window rows) = %.2f" % (
+        np.corrcoef(loop, ww * hh)[0, 1], np.corrcoef(loop, ww)[0, 1], np.corrcoef(loop, hh)[0, 1]))
+
 if os.environ.get("DM_STAMPS_SLOWEST"):
   # the slowest workgroups of the launch: (index, frame, strip, index % 8) and their phases
   order = np.argsort(-tot)[:int(os.environ["DM_STAMPS_SLOWEST"])]

@@ -110,7 +110,7 @@ def main():
                   help="skip the two-stream figure (profiling runs: its overlapping kernels would blur the "
                        "per-kernel averages)")
   ap.add_argument("--cpu-seconds", type=float, default=12.0)
-  ap.add_argument("--event-every", type=int, default=8,
+  ap.add_argument("--event-every", type=int, default=16,
                   help="bracket every n-th timed step with HIP events (an event record costs "
                        "a few us of stream time, so not every step carries one)")
   ap.add_argument("--rotate", type=int, default=0,
@@ -197,6 +197,10 @@ def main():
   # HIP events on the launch stream (torch's current stream): before the call and,
   # through the library's measurement hook, right after the kernels that produce the
   # per-frame maps + masks (i.e. before the batch fuse).
+  # the timed steps that carry their own pair of events (a cross-check of the back-to-back figure, not the
+  # source of any reported rate): every event_every-th, starting in the middle of the first stretch -- an
+  # event record is a stream operation of its own (~1.5-4 us), so few steps carry one
+  bracketed_steps = set(range(min(args.event_every // 2, max(0, args.steps - 1)), args.steps, max(1, args.event_every)))
   ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
   ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
   for e in ev_a + ev_b:
@@ -244,7 +248,7 @@ def main():
     return ring[buf][slot], ring_mask[buf][slot]
 
   def step(i=None):
-    if i is not None and i % args.event_every != 0:
+    if i is not None and i not in bracketed_steps:
       i = None                   # untimed by events (the wall clock still covers it)
     n = calls["n"]
     calls["n"] = n + 1
@@ -337,7 +341,7 @@ def main():
       "sum": float(torch.where(finite, fz, torch.zeros_like(fz)).double().sum().item()),
   }
   del fz, fm, finite
-  proj_ms = np.array([ev_a[i].elapsed_time(ev_b[i]) for i in range(0, args.steps, args.event_every)])
+  proj_ms = np.array([ev_a[i].elapsed_time(ev_b[i]) for i in sorted(bracketed_steps)])
   bracketed_s = float(np.mean(proj_ms)) * 1e-3
   last_pose = pose_sets[(calls["n"] - 1) % len(pose_sets)]      # the poses of `out`
 

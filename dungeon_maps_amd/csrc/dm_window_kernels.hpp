@@ -158,6 +158,10 @@ k_window_scatter(ScatterArgs a, const ScatterTables* __restrict__ tables) {
       ? a.valid + ((size_t)b * a.valid_c + (a.valid_c == 1 ? 0 : dch)) * N : nullptr;
   const float* simg = HAS_VALUE ? a.value + ((size_t)b * a.oc_total + ch) * N : nullptr;
   const float qnan = __builtin_nanf("");
+  // rows of a thread in flight per pipeline stage: value maps carry a second float4 per row and spilled 21-95
+  // vector registers into scratch at four (the kernel is capped at 128 VGPRs by its 1024 threads;
+  // tests/test_codegen_guard.py) -- two, as in k_strip_scatter
+  constexpr int kRowsInFlight = (HAS_VALUE && VEC == 4) ? 2 : dm::kRowsInFlight;
   float za[kRowsInFlight][VEC], zb_[kRowsInFlight][VEC];
   float va[HAS_VALUE ? kRowsInFlight : 1][VEC], vb_[HAS_VALUE ? kRowsInFlight : 1][VEC];
   auto load_rows_at = [&](float (&z)[kRowsInFlight][VEC],

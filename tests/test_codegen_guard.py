@@ -1,0 +1,71 @@
+"""Static check of the built library's kernels (no GPU needed): the hot kernels keep everything in registers.
+
+The projection kernels are capped at 128 VGPRs by their 1024 threads; a change that tips one of them over the
+edge compiles, passes every parity test and runs with its spilled registers in scratch memory -- this round's
+fused-flow variant did exactly that (80 VGPR spills) until its lambda was forced inline.  The code objects'
+own metadata says so: every kernel on a measured path must report no scratch and no VGPR spills.  (SGPR
+spills into vector lanes are tolerated: the compiler keeps them out of the pixel loops -- tools)
+The general-rotation / IEEE-division variants of the window kernel with value maps (FAST = false) do spill
+and are listed as such: they are the fallback no projector call reaches."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+from dungeon_maps_amd import _native
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+HOT = ("k_strip_scatter", "k_strip_combine", "k_strip_fused", "k_fuse_unions", "k_fuse_windows", "k_window_merge",
+       "k_camera_affine_grid4", "k_crop_nearest4")
+
+
+def _kernels(path):
+  """{mangled name: {private_segment_fixed_size, vgpr_spill_count, vgpr_count}} of a code object."""
+  notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", path], capture_output=True, text=True,
+                         check=True).stdout
+  out, cur = {}, None
+  fields = {}
+  for line in notes.splitlines():
+    m = re.match(r"\s*-?\s*\.(\w+):\s*(\S+)\s*$", line)
+    if not m:
+      continue
+    key, val = m.group(1), m.group(2)
+    if key in ("private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count", "vgpr_count", "name", "symbol"):
+      fields[key] = val
+    if key == "vgpr_spill_count":          # (the last of a kernel's fields we read)
+      if "name" in fields:
+        out[fields["name"]] = {k: int(v) for k, v in fields.items() if k not in ("name", "symbol")}
+      fields = {}
+  return out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="needs the ROCm llvm tools")
+def test_hot_kernels_use_no_scratch_and_spill_no_vector_registers():
+  _native.lib()                            # the library must be there: no fallback
+  tmp = tempfile.mkdtemp(prefix="dm_codegen_")
+  try:
+    lib = shutil.copy(_native.LIB_PATH, tmp)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", lib], capture_output=True, text=True,
+                   check=True, cwd=tmp)
+    objects = sorted(f for f in os.listdir(tmp) if "amdgcn" in f and "gfx950" in f)
+    assert objects, "no gfx950 code object in the library"
+    seen, bad = set(), []
+    for f in objects:
+      for name, k in _kernels(os.path.join(tmp, f)).items():
+        hot = [h for h in HOT if h in name]
+        if re.search(r"k_window_scatterILi\dELb1E", name):      # the window kernel's FAST variants (template parameter 2)
+          hot = ["k_window_scatter<., FAST>"]
+        if not hot:
+          continue
+        seen.add(hot[0])
+        if k.get("private_segment_fixed_size", 0) or k.get("vgpr_spill_count", 0):
+          bad.append((name, k))
+        assert k.get("vgpr_count", 0) <= 128 or "k_strip" not in name, (name, k)
+    want = set(HOT) | {"k_window_scatter<., FAST>"}
+    assert seen == want, "kernels not found in the library's metadata: %s" % sorted(want - seen)
+    assert not bad, "\n".join("%s: %s" % b for b in bad)
+  finally:
+    shutil.rmtree(tmp, ignore_errors=True)

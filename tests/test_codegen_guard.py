@@ -5,8 +5,10 @@ edge compiles, passes every parity test and runs with its spilled registers in s
 fused-flow variant did exactly that (80 VGPR spills) until its lambda was forced inline.  The code objects'
 own metadata says so: every kernel on a measured path must report no scratch and no VGPR spills.  (SGPR
 spills into vector lanes are tolerated: the compiler keeps them out of the pixel loops -- tools)
-The general-rotation / IEEE-division variants of the window kernel with value maps (FAST = false) do spill
-and are listed as such: they are the fallback no projector call reaches."""
+Writing this test found the window kernel's value-map variants spilling 21-95 registers (fixed: two image rows
+in flight).  One kernel is left and listed: the general-rotation / IEEE-division fallback (FAST = false) of the
+mean reduction with a valid map spills ONE register; no projector call reaches it.  Every other kernel of the
+library, hot or not, must be clean."""
 import os
 import re
 import shutil
@@ -20,6 +22,9 @@ from dungeon_maps_amd import _native
 LLVM = "/opt/rocm/lib/llvm/bin"
 HOT = ("k_strip_scatter", "k_strip_combine", "k_strip_fused", "k_fuse_unions", "k_fuse_windows", "k_window_merge",
        "k_camera_affine_grid4", "k_crop_nearest4")
+
+
+KNOWN_TO_SPILL = r"k_window_scatterILi3ELb0ELb1ELb0E"      # <mean, FAST = false, HAS_VALID, no values>: 1 VGPR
 
 
 def _kernels(path):
@@ -43,7 +48,7 @@ def _kernels(path):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="needs the ROCm llvm tools")
-def test_hot_kernels_use_no_scratch_and_spill_no_vector_registers():
+def test_kernels_use_no_scratch_and_spill_no_vector_registers():
   _native.lib()                            # the library must be there: no fallback
   tmp = tempfile.mkdtemp(prefix="dm_codegen_")
   try:
@@ -55,12 +60,13 @@ def test_hot_kernels_use_no_scratch_and_spill_no_vector_registers():
     seen, bad = set(), []
     for f in objects:
       for name, k in _kernels(os.path.join(tmp, f)).items():
-        hot = [h for h in HOT if h in name]
+        for h in HOT:                      # (the kernels of the measured paths must be there at all)
+          if h in name:
+            seen.add(h)
         if re.search(r"k_window_scatterILi\dELb1E", name):      # the window kernel's FAST variants (template parameter 2)
-          hot = ["k_window_scatter<., FAST>"]
-        if not hot:
+          seen.add("k_window_scatter<., FAST>")
+        if re.search(KNOWN_TO_SPILL, name):
           continue
-        seen.add(hot[0])
         if k.get("private_segment_fixed_size", 0) or k.get("vgpr_spill_count", 0):
           bad.append((name, k))
         assert k.get("vgpr_count", 0) <= 128 or "k_strip" not in name, (name, k)

@@ -234,6 +234,21 @@ const Rig* rig_of(const dm_params& p, const Plan& plan, const float* pitch4, int
 
 using StripKernel = void (*)(StripArgs);
 
+// Compact planes (k_strip_scatter<..., PLANES> + k_strip_combine_planes): calls of at most four strips and two
+// output channels.  dm_debug_planes: -1 the default (on), 0 / 1.
+thread_local int g_planes = -1;
+StripKernel pick_planes_kernel(bool is_max, bool has_valid, bool has_value, bool lean, bool nt_fill) {
+#define DM_K(M, VALID, VALUE, LEAN) {k_strip_scatter<M, VALID, VALUE, LEAN, kProject, false, true>, k_strip_scatter<M, VALID, VALUE, LEAN, kProject, true, true>}
+#define DM_S(M) {{{DM_K(M, false, false, false), DM_K(M, false, false, true)},   \
+                  {DM_K(M, false, true, false), DM_K(M, false, true, true)}},    \
+                 {{DM_K(M, true, false, false), DM_K(M, true, false, false)},    \
+                  {DM_K(M, true, true, false), DM_K(M, true, true, false)}}}
+  static const StripKernel table[2][2][2][2][2] = {DM_S(kMin), DM_S(kMax)};
+#undef DM_S
+#undef DM_K
+  return table[is_max ? 1 : 0][has_valid][has_value][lean && !has_valid][nt_fill];
+}
+
 StripKernel pick_strip_kernel(bool is_max, bool has_valid, bool has_value, bool lean, bool nt_fill) {
 #define DM_K(M, VALID, VALUE, LEAN) {k_strip_scatter<M, VALID, VALUE, LEAN, kProject, false>, k_strip_scatter<M, VALID, VALUE, LEAN, kProject, true>}
 #define DM_S(M) {{{DM_K(M, false, false, false), DM_K(M, false, false, true)},   \
@@ -427,9 +442,18 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const
   const bool has_valid = valid != nullptr, has_value = value != nullptr;
   const bool from_list = has_value && l.pixel_list != nullptr && wants_pixel_list(p);
   sa.list = from_list ? l.pixel_list : nullptr;
+  // Compact planes: the shared groups of a frame numbered frame-wide, P planes of plane_cap float4 per (frame,
+  // channel) in the slab region, the groups' places in the first plane_cap words of the frame's list segments.
+  // plane_cap: a frame cannot share more groups than half of what its P windows hold.
+  const int plane_cap = ((plan.P * (rg.slab_stride / 4) / 2 + 255) / 256) * 256;
+  const bool planes = !from_list && oc_total <= 2 && plan.P <= 4 && g_planes != 0 && !sa.defer_outer &&
+                      (size_t)p.B * oc_total * plan.P * plane_cap * 16 <= slab_bytes &&
+                      plane_cap <= plan.P * sa.seg_cap;
+  sa.plane_cap = planes ? plane_cap : 0;
+  const bool nt = nt_fill_pays(p, oc_total, fuse_follows);
   const StripKernel kfn = from_list ? pick_value_kernel(is_max)
-                                    : pick_strip_kernel(is_max, has_valid, has_value, plan.lean,
-                                                        nt_fill_pays(p, oc_total, fuse_follows));
+                          : planes ? pick_planes_kernel(is_max, has_valid, has_value, plan.lean, nt)
+                                   : pick_strip_kernel(is_max, has_valid, has_value, plan.lean, nt);
   hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn));
   if (e != hipSuccess) return e;
   const size_t lds_bytes = strip_lds_bytes(rg.slab_stride, rg.max_rows, p.H, plan.P);
@@ -476,6 +500,24 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const
       ca.defer_outer = sa.defer_outer; ca.head_share = sa.head_share;
       // grid.y = frames * channels <= 65535 per launch
       const int per_launch = 65535 / oc > 0 ? 65535 / oc : 1;
+      if (planes) {
+        PlaneCombineArgs pa;
+        pa.b0 = b0; pa.oc = oc; pa.ch0 = ch0; pa.oc_total = oc_total; pa.mh = p.mh; pa.mw = p.mw;
+        pa.P = plan.P; pa.plane_cap = plane_cap; pa.fill = fill;
+        pa.g_counts = l.t.counts; pa.g_meta = l.t.list; pa.planes = l.slabs; pa.out = out; pa.mask = mask;
+        // blocks per (frame, channel): the usual number of shared groups (about a twelfth of the windows' groups
+        // at the headline geometry) at a round per thread; frames with more take further rounds
+        int blocks = (plane_cap / 6 + kCombineThreads - 1) / kCombineThreads;
+        if (blocks < 1) blocks = 1;
+        if (blocks * kCombineThreads > plane_cap) blocks = plane_cap / kCombineThreads;      // (plane_cap: a multiple of 256)
+        pa.spec_blocks = (blocks + 1) / 2;
+        const dim3 g(blocks, (unsigned)(nb * oc));
+        e = is_max ? launch(k_strip_combine_planes<kMax>, g, dim3(kCombineThreads), 0, s, pa)
+                   : launch(k_strip_combine_planes<kMin>, g, dim3(kCombineThreads), 0, s, pa);
+        if (e != hipSuccess) return e;
+        ++g_last_info[2];
+        continue;
+      }
       for (int c0 = 0; c0 < nb; c0 += per_launch) {
         const int nc = nb - c0 < per_launch ? nb - c0 : per_launch;
         ca.b0 = b0 + c0;
@@ -791,7 +833,7 @@ void compute_fused_bound(const dm_params& p, int wp, const float* pitch4, int ma
     const float ax_lo = (float)(((double)q0 - (double)p.cx) / (double)p.fx);
     const float ax_hi = (float)(((double)(q1 - 1) - (double)p.cx) / (double)p.fx);
     amax = strip::fmax2(amax, strip::fmax2(strip::fabs_(ax_lo), strip::fabs_(ax_hi)));
-    strip::strip_corners(ax_lo, ax_hi, fb.g0, fb.g1, p.dmin, p.dmax, fb.inv, &cx[s * 8], &cz[s * 8]);
+    strip::strip_corners(false, ax_lo, ax_hi, fb.g0, fb.g1, p.dmin, p.dmax, fb.inv, &cx[s * 8], &cz[s * 8]);
     for (int k = 0; k < 8; ++k) {
       const double r = sqrt((double)cx[s * 8 + k] * cx[s * 8 + k] + (double)cz[s * 8 + k] * cz[s * 8 + k]);
       if (r > rmax) rmax = r;
@@ -802,7 +844,7 @@ void compute_fused_bound(const dm_params& p, int wp, const float* pitch4, int ma
     const int q0 = clip, q1 = p.W - clip;       // (r0 < r1 holds; a clip that eats every column leaves no live strip)
     const float ax_lo = (float)(((double)q0 - (double)p.cx) / (double)p.fx);
     const float ax_hi = (float)(((double)(q1 > q0 ? q1 - 1 : q0) - (double)p.cx) / (double)p.fx);
-    strip::strip_corners(ax_lo, ax_hi, fb.g0, fb.g1, p.dmin, p.dmax, fb.inv, fb.fcx, fb.fcz);
+    strip::strip_corners(false, ax_lo, ax_hi, fb.g0, fb.g1, p.dmin, p.dmax, fb.inv, fb.fcx, fb.fcz);
   }
   const double slack_d = 2.0 + 16.0 * ((double)mag_q + 2.0 * (double)fb.reach) * (1.0 / 8388608.0) + 0.01;
   fb.slack = slack_d > 16.0 ? -1 : (int)ceil(slack_d);
@@ -1075,6 +1117,11 @@ extern "C" __attribute__((visibility("default"))) void dm_debug_last_strip_info(
   for (int i = 0; i < 4; ++i) out4[i] = dm::g_last_info[i];
 }
 
+extern "C" __attribute__((visibility("default"))) int dm_debug_planes(int mode) {
+  const int old = dm::g_planes;
+  dm::g_planes = mode < 0 ? -1 : (mode != 0);
+  return old;
+}
 extern "C" __attribute__((visibility("default"))) int dm_debug_force_legacy_window(int on) {
   const int old = dm::g_force_legacy;
   dm::g_force_legacy = on != 0;

@@ -119,8 +119,8 @@ __device__ inline void frame_geometry_wave64(const strip::RigArgs& c, const Stri
   }
   const bool live = (st < c.P) & (((c.live_mask >> st) & 1) != 0);
   const float d = (k & 1) ? c.dmax : c.dmin;
-  const float ax = (k & 2) ? ax_hi : ax_lo;
   const float gg = (k & 4) ? c.g1 : c.g0;
+  const float ax = corner_slope(c.wedge != 0, (k & 2) ? ax_hi : ax_lo, gg);
   float cx = ax * d * c.inv, cz = gg * d * c.inv;                 // strip_corners
   cx = live ? cx : 0.0f; cz = live ? cz : 0.0f;                   // (cfg_rig: a dead strip's corners are zero)
   const Pose p = pose_of(c, ps.y0, ps.y2, ps.y6, ps.y8, ps.tx, ps.tz, ps.wo, ps.ho);
@@ -217,6 +217,13 @@ struct StripArgs {
   int mh, mw;
   FrameTables t;
   int* status;                // device-visible status word (or NULL)
+  // PLANES (up to four strips, one or two output channels): the groups two or more strips' covers hold are
+  // numbered frame-wide -- every workgroup of the frame derives the same numbers from the same covers -- and
+  // a strip stores its values of them COMPACTLY, at their numbers, in its plane (B * oc, P, plane_cap) float4
+  // (in the slab region); the lowest strip that holds a group also stores {float4 group of the map, covers that
+  // hold it} at that number in the frame's segment of the list region (B, plane_cap).  k_strip_combine_planes
+  // then needs ONE round of coalesced loads per group.
+  int plane_cap;
   uint16_t* list;             // (B, P, H, wp) cells of the pixels inside their strips' windows (index / value pass)
 #ifdef DM_STAMPS
   long long* stamps;
@@ -258,11 +265,14 @@ struct StripArgs {
 #ifndef DM_X_MASK_POLICY
 #define DM_X_MASK_POLICY 0
 #endif
+// PLANES (kProject, at most four strips): the shared groups go to compact planes instead of slabs + lists
+// (StripArgs::plane_cap); k_strip_combine_planes follows instead of k_strip_combine_one.
 enum { kProject = 0, kIndexOut = 1, kFromList = 2 };
-template <int RED, bool HAS_VALID, bool HAS_VALUE, bool LEAN, int MODE = kProject, bool NT_FILL = true>
+template <int RED, bool HAS_VALID, bool HAS_VALUE, bool LEAN, int MODE = kProject, bool NT_FILL = true, bool PLANES = false>
 __global__ void __launch_bounds__(kScatterThreads)
 k_strip_scatter(StripArgs a) {
   constexpr int VEC = 4;
+  static_assert(!PLANES || MODE == kProject, "compact planes: the whole projection in one scatter kernel");
   static_assert(MODE != kFromList || HAS_VALUE, "the value pass scatters values");
   static_assert(MODE != kIndexOut || !HAS_VALUE, "the index pass reads no values");
   // rows of a thread in flight per pipeline stage: value maps carry a second float4 per row and
@@ -521,6 +531,8 @@ k_strip_scatter(StripArgs a) {
       const uint32_t owned = hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
       // entries of this strip's list on the row: the groups of its cover outside the owned span
       int entries = (int)((mine >> 16) - (mine & 0xffffu)) - (hi > lo ? hi - lo : 0);
+      // (compact planes: the row's groups in two or more covers -- the same number in every workgroup of the frame)
+      if (PLANES && kP2 == 4) entries = strip::shared_before(cov[0], cov[1 % kP2], cov[2 % kP2], cov[3 % kP2], 1 << 30);
       entries = live ? entries >> 2 : 0;
       const int before = wave_inclusive_scan(entries);       // over the wave's rows
       if (lane == 63) geom->chunk_entries[r0 >> 6] = before;
@@ -1035,9 +1047,13 @@ k_strip_scatter(StripArgs a) {
   const GeomLds* const fgeom = reinterpret_cast<const GeomLds*>(
       reinterpret_cast<const float*>(fcovers) + (fP2 + 4) * fa->max_rows + ((fa->H + 3) & ~3));
   const bool emit = MODE != kFromList && chl == 0;
-  if (area > 0 && (MODE != kIndexOut || emit)) {
+  const int unit = b * fa->oc + chl;               // (frame, channel): the P workgroups that share a map
+  auto mask_bits = [&](float4 v) {
+    return (uint32_t)mask_of(v.x, fa->fill) | ((uint32_t)mask_of(v.y, fa->fill) << 8) |
+           ((uint32_t)mask_of(v.z, fa->fill) << 16) | ((uint32_t)mask_of(v.w, fa->fill) << 24);
+  };
+  if (!PLANES && area > 0 && (MODE != kIndexOut || emit)) {
     const int l16 = (int)threadIdx.x & 15;
-    const int unit = b * fa->oc + chl;             // (frame, channel): the P workgroups that share a map
     float* slab = fa->slabs + ((size_t)unit * nparts + part) * fa->slab_stride;
     uint32_t* seg = fa->t.list + ((size_t)b * nparts + part) * fa->seg_cap;
     const uint32_t lower = (1u << part) - 1u;
@@ -1061,9 +1077,7 @@ k_strip_scatter(StripArgs a) {
           if (mine) {
             const int cell = z * fa->mw + x;
             __builtin_amdgcn_raw_buffer_store_b128((f32x4){v.x, v.y, v.z, v.w}, rs_out, cell << 2, 0, DM_X_FLUSH_POLICY);
-            __builtin_amdgcn_raw_buffer_store_b32(
-                (uint32_t)mask_of(v.x, fa->fill) | ((uint32_t)mask_of(v.y, fa->fill) << 8) |
-                ((uint32_t)mask_of(v.z, fa->fill) << 16) | ((uint32_t)mask_of(v.w, fa->fill) << 24), rs_mask, cell, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(mask_bits(v), rs_mask, cell, 0, 0);
           } else {
             *reinterpret_cast<float4*>(slab + cell0 + x) = v;
           }
@@ -1087,11 +1101,62 @@ k_strip_scatter(StripArgs a) {
       }
     }
   }
-  if (emit && threadIdx.x == 0) {
+  if (!PLANES && emit && threadIdx.x == 0) {
     const int n = area > 0 ? fgeom->chunk_entries[kListMaxRows / 64] : 0;
     fa->t.counts[(size_t)b * strip::kMaxStrips + part] = n < fa->seg_cap ? n : fa->seg_cap;
     if (n > fa->seg_cap && fa->status)       // (cannot happen: a strip lists at most the groups of its window)
       raise_status(fa->status, kStatusListOverflow);
+  }
+  if (PLANES) {
+    // Compact planes (at most four strips).  A group of this strip's cover that NO other strip's cover holds goes
+    // straight to the map; a group two or more covers hold has a number in the frame -- the shared groups of the
+    // rows before it (the row tables' scan: the same in every workgroup of the frame) + those of its row left of
+    // it (strip::shared_before) -- and the strip stores its values at that number in its plane; the lowest strip
+    // that holds the group also stores where it lies in the map and which covers hold it.
+    const int cap = fa->plane_cap;
+    const __amdgpu_buffer_rsrc_t rs_plane = __builtin_amdgcn_make_buffer_rsrc(
+        fa->slabs + ((size_t)unit * nparts + part) * (size_t)cap * 4, 0, (unsigned)cap * 16u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_meta = __builtin_amdgcn_make_buffer_rsrc(
+        fa->t.list + (size_t)b * cap, 0, (unsigned)cap * 4u, 0x00020000);
+    if (area > 0) {
+      const int l16 = (int)threadIdx.x & 15;
+      const uint32_t me = 1u << part, lower = me - 1u;
+      for (int row = (int)threadIdx.x >> 4; row < w.h; row += kScatterThreads / 16) {
+        const int z = w.z0 + row;
+        const int ur = z - U.z0;
+        const uint4 c0 = *reinterpret_cast<const uint4*>(fcovers + ur * 4);
+        const uint32_t cover = part == 0 ? c0.x : part == 1 ? c0.y : part == 2 ? c0.z : c0.w;
+        const int lo = (int)(cover & 0xffffu), hi = (int)(cover >> 16);
+        const int cell0 = row * w.w - w.x0;
+        const int base = flist_at[ur] + fgeom->chunk_entries[ur >> 6];
+        for (int x = lo + (l16 << 2); x < hi; x += 64) {
+          float4 v = *reinterpret_cast<const float4*>(lds + cell0 + x);
+          if (kDeferCamH) {
+            v.x = combine<RED>(v.x + cam_h, fa->fill); v.y = combine<RED>(v.y + cam_h, fa->fill);
+            v.z = combine<RED>(v.z + cam_h, fa->fill); v.w = combine<RED>(v.w + cam_h, fa->fill);
+          }
+          const uint32_t hits = (strip::in_span(c0.x, x) ? 1u : 0u) | (strip::in_span(c0.y, x) ? 2u : 0u) |
+                                (strip::in_span(c0.z, x) ? 4u : 0u) | (strip::in_span(c0.w, x) ? 8u : 0u);
+          const int cell = z * fa->mw + x;
+          if (hits == me) {
+            __builtin_amdgcn_raw_buffer_store_b128((f32x4){v.x, v.y, v.z, v.w}, rs_out, cell << 2, 0, DM_X_FLUSH_POLICY);
+            __builtin_amdgcn_raw_buffer_store_b32(mask_bits(v), rs_mask, cell, 0, 0);
+          } else {
+            const int pos = base + (strip::shared_before(c0.x, c0.y, c0.z, c0.w, x) >> 2);
+            // (a number past the planes' end cannot occur -- the host sizes them for every group of every window --
+            // and is dropped by the buffers' range check)
+            __builtin_amdgcn_raw_buffer_store_b128((f32x4){v.x, v.y, v.z, v.w}, rs_plane, pos < cap ? pos << 4 : 0x7ffffff0, 0, 0);
+            if (emit && (hits & lower) == 0u)
+              __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(cell >> 2) | (hits << 28), rs_meta, pos < cap ? pos << 2 : 0x7ffffff0, 0, 0);
+          }
+        }
+      }
+    }
+    if (emit && part == 0 && threadIdx.x == 0) {      // the frame's shared groups (every workgroup of the frame has the number)
+      const int n = fgeom->chunk_entries[kListMaxRows / 64];
+      fa->t.counts[(size_t)b * strip::kMaxStrips] = n < cap ? n : cap;
+      if (n > cap && fa->status) raise_status(fa->status, kStatusListOverflow);
+    }
   }
   DM_STAMP(6);
   DM_STAMPS_OUT();
@@ -1174,13 +1239,15 @@ k_strip_combine_one(StripCombineArgs a) {
   const int2 u_raw = *reinterpret_cast<const int2*>(a.g_unions + b);
   const int listed = min(a.g_counts[(size_t)b * strip::kMaxStrips + seg], a.seg_cap);
   const int ux0 = (short)(u_raw.x & 0xffff), uz0 = (short)(u_raw.x >> 16);
-  if (a.defer_outer)      // this kernel's share of the map rows outside the union window: fill value, mask 0
-    combine_fill_outer(a, b, chl, uz0, (short)(u_raw.y >> 16));
-  if (lane_block * kCombineThreads >= listed) return;
+  // (the strips' windows: requested with the entry, in front of the early exit -- one round trip less)
   int2 wq[strip::kMaxStrips];
 #pragma unroll
   for (int q = 0; q < strip::kMaxStrips; ++q)
     wq[q] = *reinterpret_cast<const int2*>(a.g_wins + (size_t)b * strip::kMaxStrips + (q < a.P ? q : 0));
+  asm volatile("" : "+v"(wq[0].x), "+v"(entry));
+  if (a.defer_outer)      // this kernel's share of the map rows outside the union window: fill value, mask 0
+    combine_fill_outer(a, b, chl, uz0, (short)(u_raw.y >> 16));
+  if (lane_block * kCombineThreads >= listed) return;
   const float* const slabs = a.slabs + ((size_t)(b * a.oc + chl) * a.P) * a.slab_stride;
   const size_t fo = ((size_t)b * a.oc_total + a.ch0 + chl) * (size_t)a.mh * a.mw;
   const float ident = RED == kMax ? -INFINITY : INFINITY;
@@ -1294,6 +1361,62 @@ k_strip_combine(StripCombineArgs a) {
           (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
           ((uint32_t)mask_of(acc.z, a.fill) << 16) | ((uint32_t)mask_of(acc.w, a.fill) << 24);
     }
+  }
+}
+
+// Compact planes: the frame's shared groups by number -- where each lies in the map and which strips' covers hold
+// it (meta), the strips' values of it at the same number in their planes: ONE round of coalesced loads per
+// group, then max / min with the fill value and the map + mask stores.  Block x of a (frame, channel) takes the
+// numbers x * 256 + thread, + gridDim.x * 256, ...; the first `spec_blocks` blocks request their first round
+// before they know the frame's count (the numbers below the usual count are nearly always live).
+struct PlaneCombineArgs {
+  int b0, oc, ch0, oc_total, mh, mw;
+  int P, plane_cap, spec_blocks;
+  float fill;
+  const int* g_counts;        // (B, kMaxStrips): [b][0] = shared groups of frame b
+  const uint32_t* g_meta;     // (B, plane_cap)
+  const float* planes;        // (B * oc, P, plane_cap) float4
+  float* out;
+  uint8_t* mask;
+};
+
+template <int RED>
+__global__ void __launch_bounds__(kCombineThreads)
+k_strip_combine_planes(PlaneCombineArgs a) {
+  const int fcl = blockIdx.y;                  // (frame of the launch) * oc + channel of the group
+  const int bl = fcl / a.oc, b = a.b0 + bl;
+  const int chl = fcl - bl * a.oc;
+  const int cap = a.plane_cap;
+  const uint32_t* const meta = a.g_meta + (size_t)b * cap;
+  const float4* const pl = reinterpret_cast<const float4*>(a.planes) + ((size_t)(b * a.oc + chl) * a.P) * (size_t)cap;
+  const size_t fo = ((size_t)b * a.oc_total + a.ch0 + chl) * (size_t)a.mh * a.mw;
+  const int stride = (int)gridDim.x * kCombineThreads;
+  int i = (int)blockIdx.x * kCombineThreads + (int)threadIdx.x;       // (< plane_cap: the host sizes the grid)
+  // (a vector load of the count: it returns in order with the round's other loads)
+  const int n = min(*reinterpret_cast<const volatile int*>(a.g_counts + (size_t)b * strip::kMaxStrips), cap);
+  if ((int)blockIdx.x >= a.spec_blocks && (int)blockIdx.x * kCombineThreads >= n) return;
+  for (;;) {
+    const uint32_t m = meta[i];
+    float4 t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = pl[(size_t)(q < a.P ? q : 0) * cap + i];
+    if (i >= n) return;
+    // (the fill value takes part: utils.py:470-477 reduces INTO the filled canvas)
+    float4 acc = make_float4(a.fill, a.fill, a.fill, a.fill);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if ((m >> (28 + q)) & 1u) {
+        acc.x = combine<RED>(acc.x, t[q].x); acc.y = combine<RED>(acc.y, t[q].y);
+        acc.z = combine<RED>(acc.z, t[q].z); acc.w = combine<RED>(acc.w, t[q].w);
+      }
+    }
+    const size_t cell = fo + ((size_t)(m & 0x0fffffffu) << 2);
+    *reinterpret_cast<float4*>(a.out + cell) = acc;
+    *reinterpret_cast<uint32_t*>(a.mask + cell) =
+        (uint32_t)mask_of(acc.x, a.fill) | ((uint32_t)mask_of(acc.y, a.fill) << 8) |
+        ((uint32_t)mask_of(acc.z, a.fill) << 16) | ((uint32_t)mask_of(acc.w, a.fill) << 24);
+    i += stride;
+    if (i >= n) return;
   }
 }
 

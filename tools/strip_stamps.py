@@ -24,6 +24,9 @@ lib = ctypes.CDLL(_native.LIB_PATH)
 _native.lib()
 buf = torch.zeros(4096 * 12 + 4096 * 16, dtype=torch.int64, device="cuda")
 lib.dm_debug_strip_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+if os.environ.get("DM_STAMPS_ONE"):
+  lib.dm_debug_one_kernel(int(os.environ["DM_STAMPS_ONE"]))
+  _native.lib().dm_debug_one_kernel(int(os.environ["DM_STAMPS_ONE"]))
 if os.environ.get("DM_STAMPS_LEGACY"):
   _native.lib().dm_debug_force_legacy_window(1)
 if os.environ.get("DM_STAMPS_STRIPS"):
@@ -63,7 +66,10 @@ def seg(name, i, j):
   print(f"  {name:44s} {np.median(dd):8.2f} {dd.max():8.2f}")
 print("workgroups: %d   per-WG phase time in us (median / max):" % len(st))
 seg("(thread 0 is in wave 0: start -> in front of the barrier)", 0, 1)
-if raw[:, 7].any() and raw[:, 8].any():
+TAIL = bool(os.environ.get("DM_STAMPS_TAIL"))      # the one-kernel form: stamps 7 .. 10 are the tail's
+if TAIL:
+  seg("head (start -> second loads requested)", 0, 11)
+elif raw[:, 7].any() and raw[:, 8].any():
   seg("wave 0: kernel arguments + pose record loaded", 0, 9)
   seg("wave 0: geometry", 9, 10)
   seg("wave 0: -> barrier passed", 10, 7)
@@ -71,10 +77,11 @@ if raw[:, 7].any() and raw[:, 8].any():
   seg("loop scalars reloaded + barrier", 8, 2)
 else:
   seg("row entries -> lds, barrier", 1, 2)
-seg("second loads (head of the pipeline)", 2, 11)
+if not TAIL:
+  seg("second loads (head of the pipeline)", 2, 11)
 seg("pixel loop", 11, 4)
 seg("rest of the fill duty + barrier", 4, 5)
-if False:
+if TAIL:
   seg("tail: shared groups -> slab", 5, 7)
   seg("tail: drain + barrier", 7, 8)
   seg("tail: owned groups -> map (counter in flight)", 8, 9)

@@ -833,7 +833,7 @@ void compute_fused_bound(const dm_params& p, int wp, const float* pitch4, int ma
     const float ax_lo = (float)(((double)q0 - (double)p.cx) / (double)p.fx);
     const float ax_hi = (float)(((double)(q1 - 1) - (double)p.cx) / (double)p.fx);
     amax = strip::fmax2(amax, strip::fmax2(strip::fabs_(ax_lo), strip::fabs_(ax_hi)));
-    strip::strip_corners(false, ax_lo, ax_hi, fb.g0, fb.g1, p.dmin, p.dmax, fb.inv, &cx[s * 8], &cz[s * 8]);
+    strip::strip_corners(ax_lo, ax_hi, fb.g0, fb.g1, p.dmin, p.dmax, fb.inv, &cx[s * 8], &cz[s * 8]);
     for (int k = 0; k < 8; ++k) {
       const double r = sqrt((double)cx[s * 8 + k] * cx[s * 8 + k] + (double)cz[s * 8 + k] * cz[s * 8 + k]);
       if (r > rmax) rmax = r;
@@ -844,7 +844,7 @@ void compute_fused_bound(const dm_params& p, int wp, const float* pitch4, int ma
     const int q0 = clip, q1 = p.W - clip;       // (r0 < r1 holds; a clip that eats every column leaves no live strip)
     const float ax_lo = (float)(((double)q0 - (double)p.cx) / (double)p.fx);
     const float ax_hi = (float)(((double)(q1 > q0 ? q1 - 1 : q0) - (double)p.cx) / (double)p.fx);
-    strip::strip_corners(false, ax_lo, ax_hi, fb.g0, fb.g1, p.dmin, p.dmax, fb.inv, fb.fcx, fb.fcz);
+    strip::strip_corners(ax_lo, ax_hi, fb.g0, fb.g1, p.dmin, p.dmax, fb.inv, fb.fcx, fb.fcz);
   }
   const double slack_d = 2.0 + 16.0 * ((double)mag_q + 2.0 * (double)fb.reach) * (1.0 / 8388608.0) + 0.01;
   fb.slack = slack_d > 16.0 ? -1 : (int)ceil(slack_d);

@@ -47,8 +47,7 @@ struct Cfg {
   int cone_ok;                  // every image row looks forward (g > 0): the cone model holds
   float inv;                    // cells per metre (1 / map_res)
   float reach;                  // bound of a point's distance from the camera in cells
-  int wedge;                    // the strips are cut along iso-bearing lines (Staircase below): a strip's
-                                // corners are (t * g * d, g * d) for t in {tmin, tmax} instead of (ax * d, g * d)
+  float pad;
   int live[kMaxStrips];         // 0: nothing left of the strip after clip_border
   float tmin[kMaxStrips];       // cone edges: t = ax / g over the strip's corner rays
   float tmax[kMaxStrips];
@@ -64,7 +63,6 @@ struct Cfg {
 struct RigArgs {
   int P, mw, mh, flip_h, cone_ok;
   int live_mask;                // bit s: strip s has pixels left after clip_border
-  int wedge;                    // Cfg::wedge
   float inv, reach;
   float g0, g1;                 // z1 = g * depth at the extreme live rows (cfg_rig)
   float dmin, dmax;
@@ -74,16 +72,13 @@ struct RigArgs {
 
 // Corners of a strip's truncated cone in the camera's local frame, in cells (index bit 0 =
 // near/far, bit 1 = ax lo/hi, bit 2 = ay lo/hi): one expression for host and device.
-// A wedge strip (cut along iso-bearing lines) is the set {b (t, 1) : t in [tmin, tmax], b = g d}: its
-// corners are (t g d, g d) -- ax_lo / ax_hi then hold tmin / tmax.
-__host__ __device__ inline float corner_slope(bool wedge, float a, float g) { return wedge ? a * g : a; }
-__host__ __device__ inline void strip_corners(bool wedge, float ax_lo, float ax_hi, float g0, float g1, float dmin,
+__host__ __device__ inline void strip_corners(float ax_lo, float ax_hi, float g0, float g1, float dmin,
                                               float dmax, float inv, float* cx, float* cz) {
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const float d = (k & 1) ? dmax : dmin;
+    const float ax = (k & 2) ? ax_hi : ax_lo;
     const float g = (k & 4) ? g1 : g0;
-    const float ax = corner_slope(wedge, (k & 2) ? ax_hi : ax_lo, g);
     cx[k] = ax * d * inv;
     cz[k] = g * d * inv;
   }
@@ -116,11 +111,8 @@ __host__ __device__ inline bool finite_f(float v) { return v == v && v - v == 0.
 // axis-aligned: x1 = X, z1 = Rp[5] * Y + Rp[8] * Z) and the strips' ray slopes.
 //   ax_lo / ax_hi: (q - cx) / fx of each strip's first / last live column;  ay_lo / ay_hi: the
 //   extreme (y - cy) / fy of the live rows;  depth range [dmin, dmax].
-// Wedge strips (c.wedge): tmin_w / tmax_w are each strip's bearing range over ALL its pixels (the
-// staircase's rows), ax_lo / ax_hi still the extreme ray slopes of its columns (the reach).
 __host__ inline void cfg_rig(Cfg& c, const float* Rp, const float* ax_lo, const float* ax_hi,
-                             float ay_lo, float ay_hi, float dmin, float dmax,
-                             const float* tmin_w = nullptr, const float* tmax_w = nullptr) {
+                             float ay_lo, float ay_hi, float dmin, float dmax) {
   const float p5 = Rp[5], p8 = Rp[8];
   const float g0 = p5 * ay_lo + p8, g1 = p5 * ay_hi + p8;   // z1 = g * depth
   c.cone_ok = g0 > 1e-3f && g1 > 1e-3f && finite_f(g0) && finite_f(g1);
@@ -135,10 +127,8 @@ __host__ inline void cfg_rig(Cfg& c, const float* Rp, const float* ax_lo, const 
       const float t0 = ax_lo[s] / g0, t1 = ax_lo[s] / g1, t2 = ax_hi[s] / g0, t3 = ax_hi[s] / g1;
       c.tmin[s] = fmin2(fmin2(t0, t1), fmin2(t2, t3));
       c.tmax[s] = fmax2(fmax2(t0, t1), fmax2(t2, t3));
-      if (c.wedge) { c.tmin[s] = tmin_w[s]; c.tmax[s] = tmax_w[s]; }
     }
-    if (c.wedge) strip_corners(true, c.tmin[s], c.tmax[s], g0, g1, dmin, dmax, c.inv, c.cxl[s], c.czl[s]);
-    else strip_corners(false, ax_lo[s], ax_hi[s], g0, g1, dmin, dmax, c.inv, c.cxl[s], c.czl[s]);
+    strip_corners(ax_lo[s], ax_hi[s], g0, g1, dmin, dmax, c.inv, c.cxl[s], c.czl[s]);
   }
   c.reach = dmax * c.inv * (amax + gmax);
 }
@@ -149,7 +139,6 @@ __host__ inline RigArgs rig_args(const Cfg& c, const float* Rp, const float* ax_
   RigArgs r;
   r.P = c.P; r.mw = c.mw; r.mh = c.mh; r.flip_h = c.flip_h; r.cone_ok = c.cone_ok;
   r.live_mask = 0;
-  r.wedge = c.wedge;
   r.inv = c.inv; r.reach = c.reach;
   r.g0 = Rp[5] * ay_lo + Rp[8]; r.g1 = Rp[5] * ay_hi + Rp[8];
   r.dmin = dmin; r.dmax = dmax;
@@ -158,8 +147,6 @@ __host__ inline RigArgs rig_args(const Cfg& c, const float* Rp, const float* ax_
     r.live_mask |= on ? 1 << s : 0;
     r.ax_lo[s] = on ? ax_lo[s] : 0.0f; r.ax_hi[s] = on ? ax_hi[s] : 0.0f;
     r.tmin[s] = c.tmin[s]; r.tmax[s] = c.tmax[s];
-    // (a wedge strip's corners come from its bearing range: the device picks them up as ax_lo / ax_hi)
-    if (c.wedge) { r.ax_lo[s] = on ? c.tmin[s] : 0.0f; r.ax_hi[s] = on ? c.tmax[s] : 0.0f; }
   }
   return r;
 }

@@ -119,8 +119,8 @@ __device__ inline void frame_geometry_wave64(const strip::RigArgs& c, const Stri
   }
   const bool live = (st < c.P) & (((c.live_mask >> st) & 1) != 0);
   const float d = (k & 1) ? c.dmax : c.dmin;
+  const float ax = (k & 2) ? ax_hi : ax_lo;
   const float gg = (k & 4) ? c.g1 : c.g0;
-  const float ax = corner_slope(c.wedge != 0, (k & 2) ? ax_hi : ax_lo, gg);
   float cx = ax * d * c.inv, cz = gg * d * c.inv;                 // strip_corners
   cx = live ? cx : 0.0f; cz = live ? cz : 0.0f;                   // (cfg_rig: a dead strip's corners are zero)
   const Pose p = pose_of(c, ps.y0, ps.y2, ps.y6, ps.y8, ps.tx, ps.tz, ps.wo, ps.ho);

@@ -662,6 +662,35 @@ def g12(dmap):
   print("wrote g12_api_signatures.json", len(out), "methods")
 
 
+def g13(dmap):
+  """depth_map_to_point_cloud (maps.py:462-545) and height_map_to_point_cloud (maps.py:547-612) as
+  callers use them on their own: the camera-space cloud + validity of a depth map (both flips, a valid
+  map, truncation on / off) and the cell centres of a height map (both flips, per-frame offsets)."""
+  rng = np.random.default_rng(1313)
+  h, w = 24, 32
+  depth = rng.uniform(0.05, 7.0, (2, 1, h, w)).astype(np.float32)
+  depth[0, 0, 0, :4] = [0.0, np.nan, np.inf, -1.0]
+  valid = rng.uniform(size=(2, 1, h, w)) > 0.2
+  i = dmap.utils.get_camera_intrinsics(width=w, height=h, hfov=np.radians(70.))
+  arrays = dict(depth=depth, valid=valid, intr=np.array([i.cx, i.cy, i.fx, i.fy], dtype=np.float64))
+  for tag, kw in (("flip", dict(flip_h=True, trunc_depth_min=0.15, trunc_depth_max=5.05, valid_map=T(valid, torch.bool))),
+                  ("noflip", dict(flip_h=False, trunc_depth_min=None, trunc_depth_max=None, valid_map=None))):
+    cloud, ok = dmap.maps.depth_map_to_point_cloud(
+      depth_map=T(depth), focal_x=i.fx, focal_y=i.fy, center_x=i.cx, center_y=i.cy, **kw)
+    arrays[f"cloud_{tag}"] = cloud.numpy().copy()
+    arrays[f"ok_{tag}"] = ok.numpy().copy()
+  hm = rng.uniform(-1.0, 2.0, (2, 3, 20, 28)).astype(np.float32)
+  hm[0, 0, 0, 0] = -np.inf
+  woff = np.array([14.0, 3.25], dtype=np.float32)
+  hoff = np.array([0.0, 10.5], dtype=np.float32)
+  arrays.update(height=hm, woff=woff, hoff=hoff)
+  for tag, flip in (("flip", True), ("noflip", False)):
+    pc = dmap.maps.height_map_to_point_cloud(height_map=T(hm), width_offset=T(woff), height_offset=T(hoff),
+                                             map_res=0.07, map_height=20, flip_h=flip)
+    arrays[f"points_{tag}"] = pc.numpy().copy()
+  save("g13_point_clouds", **arrays)
+
+
 def main():
   torch.set_num_threads(1)
   torch.manual_seed(0)
@@ -684,6 +713,7 @@ def main():
   g10(dmap)
   g11(dmap)
   g12(dmap)
+  g13(dmap)
 
 
 if __name__ == "__main__":

@@ -177,3 +177,24 @@ def test_object_api_signatures_match_the_reference():
   assert (c.width, c.height, c.map_width) == (80, 60, 32)
   # private plumbing stays out of the public functional signature
   assert "_fuse" not in inspect.signature(dmap.orth_project).parameters
+
+
+def test_point_cloud_helpers_against_the_reference():
+  """functional.depth_map_to_point_cloud / height_map_to_point_cloud (reference maps.py:462-612) on CPU
+  tensors against fixture g13, generated by the reference itself: clouds bit for bit, validity equal."""
+  import torch
+  from conftest import load_golden
+  from dungeon_maps_amd import functional as F
+  g, _ = load_golden("g13_point_clouds")
+  cx, cy, fx, fy = (float(v) for v in g["intr"])
+  for tag, kw in (("flip", dict(flip_h=True, trunc_depth_min=0.15, trunc_depth_max=5.05,
+                                valid_map=torch.from_numpy(g["valid"]))),
+                  ("noflip", dict(flip_h=False, trunc_depth_min=None, trunc_depth_max=None, valid_map=None))):
+    cloud, ok = F.depth_map_to_point_cloud(torch.from_numpy(g["depth"]), focal_x=fx, focal_y=fy, center_x=cx,
+                                           center_y=cy, **kw)
+    np.testing.assert_array_equal(cloud.numpy(), g[f"cloud_{tag}"])
+    np.testing.assert_array_equal(ok.numpy(), g[f"ok_{tag}"])
+  for tag, flip in (("flip", True), ("noflip", False)):
+    pc = F.height_map_to_point_cloud(torch.from_numpy(g["height"]), torch.from_numpy(g["woff"]),
+                                     torch.from_numpy(g["hoff"]), 0.07, 20, flip_h=flip)
+    np.testing.assert_array_equal(pc.numpy(), g[f"points_{tag}"])

@@ -40,6 +40,7 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MIX_CEILING_GBS = 5330.0  # measured: the best plain kernel moving cfg2's read / write mix (profiles/r05_traffic_model.log)
 
 WORKLOADS = {
     # name: (B, H, W, mh, mw, value channels)
@@ -384,6 +385,17 @@ def main():
       kernel_s = back_to_back(plain, 64 if alg < (1 << 30) else 8)
     finally:
       lib.dm_debug_force_nt_fill(-1)
+    height_s = None
+    if C:      # BASELINE.md section 4 counts cfg3 WITH the height map (maps.py:332-350, what MapBuilder.plot asks for)
+      def plain_h(j):
+        keep[j % len(keep)] = None
+        keep[j % len(keep)] = proj.orth_project(depth_sets[j % rot], value_map=value_sets[j % rot],
+                                                cam_pose=pose_sets[j % len(pose_sets)], get_height_map=True)
+      lib.dm_debug_force_nt_fill(1)
+      try:
+        height_s = back_to_back(plain_h, 8)
+      finally:
+        lib.dm_debug_force_nt_fill(-1)
     del keep
     b2b_note = ("64 orth_project calls (a new set of poses, another depth batch and other output blocks "
                 "each; the kernel variant of the timed steps: non-temporal fill stores) back to back "
@@ -439,8 +451,9 @@ def main():
           "traffic": traffic,
           "traffic_source": traffic_note,
           "kernel": "orth_project launch sequence of dm_orth_project_f32: k_strip_scatter (the poses "
-                    "of the call in its arguments; geometry, projection, owned cells and fill) + "
-                    "k_strip_combine (cells several strips share) -- everything that produces the "
+                    "of the call in its arguments; geometry, projection, owned cells and fill; the cells "
+                    "several strips share go to compact planes) + k_strip_combine_planes (one round of "
+                    "coalesced loads per shared group) -- everything that produces the "
                     "per-frame maps and masks from the depth maps and the call's poses; the batch "
                     "fuse that follows is excluded here and included in roofline_step",
           "algorithmic_bytes_per_launch": alg,
@@ -449,9 +462,12 @@ def main():
           "launch_us_single_bracketed": bracketed_s * 1e6,
           "launch_us_single_bracketed_note": "one launch sequence between its own pair of events inside the "
                                              "timed steps (includes the events' own stream time)",
-          "launch_us_min": float(proj_ms.min()) * 1e3,
-          "launch_us_median": float(np.median(proj_ms)) * 1e3,
-          "launch_us_p90": float(np.percentile(proj_ms, 90)) * 1e3,
+          "launch_us_single_bracketed_n": int(len(proj_ms)),
+          # what a kernel that only MOVES these bytes reaches on this chip (tools/model.hip `mix`: 78.6 MB of
+          # 16-byte loads + 83.9 MB of stores per launch, rotating working set, every block / chunk shape tried:
+          # 30.5 us = 5.33 TB/s; reads alone 5.9, writes alone 5.95 -- profiles/r05_traffic_model.log)
+          "mix_ceiling_GBps": MIX_CEILING_GBS,
+          "frac_of_mix_ceiling": achieved / MIX_CEILING_GBS,
       },
   }
   if step_s is not None:
@@ -464,6 +480,15 @@ def main():
                "(projection launch sequence + k_fuse_unions), 64 calls back to back between one pair of HIP "
                "events: device time per step, or the host's where the host is the slower one"}
 
+  if not fused_only and C and height_s is not None:
+    alg_h = alg + B * mh * mw * 4
+    result["roofline_with_height_map"] = {
+        "bound": "hbm", "achieved": alg_h / height_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": alg_h / height_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_h,
+        "launch_us": height_s * 1e6,
+        "how": "orth_project(..., get_height_map=True): the object map + the height map of the same frames "
+               "(maps.py:332-350: a second projection, NINF fill, max) -- BASELINE.md's byte count for this config; "
+               "8 calls back to back between one pair of HIP events"}
   result["fused_checksum"] = fused_checksum
   if trace is not None:      # host time of every timed step's enqueue, us (DM_BENCH_TRACE=1)
     result["host_step_us"] = [round((t - s0) * 1e6, 1) for s0, t in zip([t0] + trace[:-1], trace)]
@@ -592,10 +617,36 @@ def main():
     dist.destroy_process_group()
 
 
+def cfg5_sample_checks(dmap, proj, depth, pose, flow_tp, center, top, mask, fill, H, W, mh, mw):
+  """Frame 0 of a cfg5 batch against the oracle: the ego-motion flow grid (oracle.camera_affine_grid), the
+  grid of the fused projection + flow call, and the crop of its map + mask around the camera's cell
+  (oracle.crop_nearest) -- bit for bit.  depth (1, 1, H, W) device, top / mask (1, 1, mh, mw) device."""
+  from oracle import oracle
+  cx, cy, fx, fy = oracle.camera_intrinsics(W, H, np.radians(70.))
+  want_grid = oracle.camera_affine_grid(depth.cpu().numpy(), flow_tp.numpy(), np.radians(-20.), 0.88, fx, fy, cx, cy, True)
+  grid = proj.camera_affine_grid(depth, flow_tp).cpu().numpy()
+  same = lambda a, b: bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+  t2, m2, g2 = proj.orth_project_and_flow(depth, flow_tp, cam_pose=pose)
+  from dungeon_maps_amd import _native
+  _native.lib().dm_debug_flow_fused(1)
+  try:
+    t3, m3, g3 = proj.orth_project_and_flow(depth, flow_tp, cam_pose=pose)
+  finally:
+    _native.lib().dm_debug_flow_fused(0)
+  crop, crop_mask = dmap.functional.crop_nearest(top, center, CFG5_CROP, CFG5_CROP, fill_value=fill, mask=mask)
+  want_crop = oracle.crop_nearest(top.cpu().numpy(), center.cpu().numpy(), CFG5_CROP, CFG5_CROP, fill)
+  want_cmask = oracle.crop_nearest(mask.cpu().numpy(), center.cpu().numpy(), CFG5_CROP, CFG5_CROP, False)
+  return {"camera_affine_grid": same(grid, want_grid),
+          "orth_project_and_flow": same(g2.cpu().numpy(), want_grid) and bool(torch.equal(t2, top) and torch.equal(m2, mask)),
+          "orth_project_and_flow_one_kernel": same(g3.cpu().numpy(), want_grid) and bool(torch.equal(t3, top) and torch.equal(m3, mask)),
+          "crop_topdown_map": same(crop.cpu().numpy(), want_crop) and bool(np.array_equal(crop_mask.cpu().numpy(), want_cmask))}
+
+
 def cfg5_legs(dmap, proj, depth_sets, pose_sets, out_sets, centers, flow_tp, fill, rot, back_to_back,
               B, H, W, mh, mw):
   """The three legs of the cfg5 step on their own (64 calls back to back each, rotating buffers):
-  device time, algorithmic bytes and fraction of the HBM peak."""
+  device time, algorithmic bytes and fraction of the HBM peak; frame 0 of every leg is
+  checked against the oracle."""
   legs = {}
 
   def leg(name, fn, alg, note):
@@ -643,14 +694,28 @@ def cfg5_legs(dmap, proj, depth_sets, pose_sets, out_sets, centers, flow_tp, fil
   leg("crop_topdown_map", crop, 2 * B * CFG5_CROP * CFG5_CROP * 5,
       f"dm_crop_nearest_f32: {CFG5_CROP}x{CFG5_CROP} crop of every height map + mask around its camera's "
       "cell (maps.py:1959-2037, utils.py:571-652): 5 bytes per cell in, 5 out")
+  # frame 0 of every leg against the oracle (the projection itself: orth_project on frame 0)
+  from oracle import oracle
+  d0, p0 = depth_sets[0][:1], pose_sets[0][:1]
+  top0, mask0 = proj.orth_project(d0, cam_pose=p0)
+  cx, cy, fx, fy = oracle.camera_intrinsics(W, H, np.radians(70.))
+  want = oracle.orth_project(d0.cpu().numpy(), cam_pose=p0.numpy(), width_offset=mw / 2., height_offset=mh / 2.,
+                             cam_pitch=np.radians(-20.), cam_height=0.88, map_res=0.03, map_width=mw, map_height=mh,
+                             focal_x=fx, focal_y=fy, center_x=cx, center_y=cy, trunc_depth_min=0.15,
+                             trunc_depth_max=5.05, to_global=True, fill_value=fill)
+  checks = cfg5_sample_checks(dmap, proj, d0, p0, flow_tp, centers[0][:1], top0, mask0, fill, H, W, mh, mw)
+  checks["orth_project"] = bool(np.array_equal(top0.cpu().numpy(), want[0]) and np.array_equal(mask0.cpu().numpy(), want[1]))
+  for name, ok in checks.items():
+    if name in legs:
+      legs[name]["gpu_matches_cpu_on_sample"] = ok
   return legs
 
 
 def committed_traffic(workload, lib_path):
-  """(bytes per launch sequence, note) from profiles/r04_hbm_traffic.json if its `lib_md5`
+  """(bytes per launch sequence, note) from profiles/r05_hbm_traffic.json if its `lib_md5`
   is the md5 of the loaded library, else (None, why)."""
   import hashlib
-  tpath = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
+  tpath = os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")
   if workload != "cfg2" or not os.path.exists(tpath):
     return None, "no committed PMC summary for this workload"
   with open(tpath) as f:
@@ -658,10 +723,10 @@ def committed_traffic(workload, lib_path):
   with open(lib_path, "rb") as f:
     md5 = hashlib.md5(f.read()).hexdigest()
   if rec.get("lib_md5") != md5:
-    return None, (f"profiles/r04_hbm_traffic.json was measured on library build "
+    return None, (f"profiles/r05_hbm_traffic.json was measured on library build "
                   f"{rec.get('lib_md5')}, the loaded one is {md5}: not quoted")
   return rec.get("launch_sequence_bytes"), (
-      "profiles/r04_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command on "
+      "profiles/r05_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command on "
       "this library build, gfx950 correction applied; bytes per launch sequence)")
 
 
@@ -729,10 +794,30 @@ def other_configs(dmap, lib, dev):
     p[:, 2] = torch.empty(B, device=dev).uniform_(-np.pi, np.pi, generator=g)
     return p.cpu()
 
-  def entry(name, us, wall_us, alg, same, note):
+  def entry(name, us, wall_us, alg, same, note, cpu=None):
     res[name] = {"launch_us": us, "call_wall_us": wall_us, "algorithmic_bytes": alg,
                  "achieved_GBps": alg / us / 1e3, "frac": alg / us / 1e3 / HBM_PEAK_GBS,
                  "gpu_matches_cpu_on_sample": same, "workload": note}
+    if cpu is not None:
+      res[name]["cpu_baseline"] = cpu
+
+  try:
+    avail = len(os.sched_getaffinity(0))
+  except AttributeError:
+    avail = os.cpu_count() or 1
+  cores = max(1, min(oracle.max_threads(), avail))
+
+  def cpu_rate(fn, frames, threads, what, budget_s=2.0):
+    """The oracle (a port of the reference's algorithm) on a bounded sample of the config, frames/s: median of
+    the runs that fit the budget (at least two)."""
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end or len(times) < 2:
+      t0 = time.perf_counter()
+      fn()
+      times.append(time.perf_counter() - t0)
+    return {"value": frames / float(np.median(times)), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{what}; median of {len(times)} runs (~{sum(times):.1f} s)"}
 
   # cfg1: B=1, 320x240 -> 256x256 (the reference's own demo size)
   B, H, W, mh, mw, _ = WORKLOADS["cfg1"]
@@ -743,8 +828,11 @@ def other_configs(dmap, lib, dev):
   top, mask = proj.orth_project(d, cam_pose=po)
   want = oracle.orth_project(d.cpu().numpy(), cam_pose=po.numpy(), **okw(H, W, mh, mw, -np.inf))
   same = bool(np.array_equal(top.cpu().numpy(), want[0]) and np.array_equal(mask.cpu().numpy(), want[1]))
+  d_np, po_np = d.cpu().numpy(), po.numpy()
   entry("cfg1", us, wall, algorithmic_bytes(B, H, W, mh, mw, 0), same,
-        "B=1, 320x240 -> 256x256 height map, orth_project per call")
+        "B=1, 320x240 -> 256x256 height map, orth_project per call",
+        cpu_rate(lambda: oracle.orth_project(d_np, cam_pose=po_np, **okw(H, W, mh, mw, -np.inf)), 1, 1,
+                 "the config's one frame on one thread"))
   # the same frame with the camera state prepared once and the call replayed from a HIP graph (what a
   # fixed-rig loop can do: no host geometry, no copy, one graph launch per frame); events around
   # 200 back-to-back replays, total / 200
@@ -820,9 +908,27 @@ def other_configs(dmap, lib, dev):
   want = oracle.orth_project(d[:1].cpu().numpy(), value_map=v[:1].cpu().numpy(),
                              cam_pose=po[:1].numpy(), **okw(H, W, mh, mw, 0.0))
   same = bool(np.array_equal(top[:1].cpu().numpy(), want[0]) and np.array_equal(mask[:1].cpu().numpy(), want[1]))
+  n3 = min(B, max(8, cores))
+  d_np, v_np, po_np = d[:n3].cpu().numpy(), v[:n3].cpu().numpy(), po[:n3].numpy()
+  cpu3 = cpu_rate(lambda: oracle.orth_project(d_np, value_map=v_np, cam_pose=po_np, nthreads=min(cores, n3),
+                                              **okw(H, W, mh, mw, 0.0)), n3, min(cores, n3),
+                  f"{n3} frames of the batch, one OpenMP thread per frame", 3.0)
   entry("cfg3", us, wall, alg3, same,
-        "B=64, 640x480 + 40-class one-hot -> 512x512 object map (checked on frame 0)")
-  del v, top, mask, sets, fn_of, d
+        "B=64, 640x480 + 40-class one-hot -> 512x512 object map, no height map (checked on frame 0)", cpu3)
+  # ... and as BASELINE.md section 4 counts it: WITH the height map (maps.py:332-350: the second
+  # projection MapBuilder.plot always asks for, maps.py:2448-2455), + B * mh * mw * 4 bytes written
+  del top, mask
+  us_h, wall_h = _event_us(fn_of(lambda s_: proj.orth_project(s_[0], value_map=s_[1], cam_pose=po, get_height_map=True)),
+                           lib, 4)
+  top, mask, hmap = proj.orth_project(d, value_map=v, cam_pose=po, get_height_map=True)
+  want = oracle.orth_project(d[:1].cpu().numpy(), value_map=v[:1].cpu().numpy(), cam_pose=po[:1].numpy(),
+                             get_height_map=True, **okw(H, W, mh, mw, 0.0))
+  same_h = bool(np.array_equal(top[:1].cpu().numpy(), want[0]) and np.array_equal(mask[:1].cpu().numpy(), want[1])
+                and np.array_equal(hmap[:1, :1].cpu().numpy(), np.asarray(want[2])[:, :1]))
+  entry("cfg3_with_height_map", us_h, wall_h, alg3 + B * mh * mw * 4, same_h,
+        "the same + get_height_map=True (BASELINE.md's 6 646 923 264 B per batch: what MapBuilder.plot asks for; "
+        "object map, mask and height map of frame 0 checked)")
+  del v, top, mask, hmap, sets, fn_of, d
   torch.cuda.empty_cache()
 
   # cfg4 per rank: 64 frames of one trajectory fused straight into ONE 1024x1024 map
@@ -837,8 +943,11 @@ def other_configs(dmap, lib, dev):
   fused, fmask = proj.orth_project_fused(d, cam_pose=po)
   want = oracle.orth_project(d.cpu().numpy(), cam_pose=po.numpy(), fused=True, **okw(H, W, mh, mw, -np.inf))
   same = bool(np.array_equal(fused.cpu().numpy(), want[0]) and np.array_equal(fmask.cpu().numpy(), want[1]))
+  d_np, po_np = d[:8].cpu().numpy(), po[:8].numpy()
   entry("cfg4_per_gpu", us, wall, alg4, same,
-        "64 frames/GPU of one trajectory fused into one 1024x1024 map (20 calls back to back between one pair of events: the larger of the device's and the host's time per call)")
+        "64 frames/GPU of one trajectory fused into one 1024x1024 map (20 calls back to back between one pair of events: the larger of the device's and the host's time per call)",
+        cpu_rate(lambda: oracle.orth_project(d_np, cam_pose=po_np, fused=True, **okw(H, W, mh, mw, -np.inf)), 8, 1,
+                 "the trajectory's first 8 frames fused into the one map, one thread (the fused port is serial)"))
   del sets, fn_of, d
   torch.cuda.empty_cache()
 
@@ -853,18 +962,41 @@ def other_configs(dmap, lib, dev):
   top, mask = proj.orth_project(d, cam_pose=po)
   want = oracle.orth_project(d[:1].cpu().numpy(), cam_pose=po[:1].numpy(), **okw(H, W, mh, mw, -np.inf))
   same = bool(np.array_equal(top[:1].cpu().numpy(), want[0]) and np.array_equal(mask[:1].cpu().numpy(), want[1]))
+  n5 = min(B, max(4, min(cores, 8)))
+  d_np, po_np = d[:n5].cpu().numpy(), po[:n5].numpy()
   entry("cfg5_per_gpu", us, wall, alg5, same,
-        "16 frames/GPU, 1280x960 -> 2048x2048 height map (checked on frame 0)")
-  del top, mask
+        "16 frames/GPU, 1280x960 -> 2048x2048 height map (checked on frame 0)",
+        cpu_rate(lambda: oracle.orth_project(d_np, cam_pose=po_np, nthreads=min(cores, n5), **okw(H, W, mh, mw, -np.inf)),
+                 n5, min(cores, n5), f"{n5} frames of the batch, one OpenMP thread per frame"))
   tp = torch.tensor([0.05, 0.1, 0.02])
+  center0 = torch.stack((po[:1, 0] / 0.03 + mw / 2., (mh - 1) - (po[:1, 1] / 0.03 + mh / 2.)), dim=1).to(dev)
+  checks5 = cfg5_sample_checks(dmap, proj, d[:1], po[:1], tp, center0, top[:1], mask[:1], -np.inf, H, W, mh, mw)
+  centers5 = torch.stack((po[:, 0] / 0.03 + mw / 2., (mh - 1) - (po[:, 1] / 0.03 + mh / 2.)), dim=1).to(dev)
+  crops = [None] * 2
+  ncrop = [0]
+
+  def crop_call():
+    j = ncrop[0]
+    ncrop[0] += 1
+    crops[j % 2] = None
+    crops[j % 2] = dmap.functional.crop_nearest(top, centers5, CFG5_CROP, CFG5_CROP, fill_value=-np.inf, mask=mask)
+  us_c, wall_c = _event_us(crop_call, lib, 6, hooks=False)
+  alg_c = 2 * B * CFG5_CROP * CFG5_CROP * 5
+  res["cfg5_crop"] = {"launch_us": us_c, "call_wall_us": wall_c, "algorithmic_bytes": alg_c,
+                      "achieved_GBps": alg_c / us_c / 1e3, "frac": alg_c / us_c / 1e3 / HBM_PEAK_GBS,
+                      "gpu_matches_cpu_on_sample": checks5["crop_topdown_map"],
+                      "workload": f"{CFG5_CROP}x{CFG5_CROP} crop of the 16 maps + masks around their cameras' cells "
+                                  "(TopdownMap.select; frame 0 checked against oracle.crop_nearest)"}
+  del crops, top, mask
   us, wall = _event_us(fn_of(lambda d_: proj.camera_affine_grid(d_, tp)), lib, 6, hooks=False)
   alg = B * H * W * (4 + 8)
   res["cfg5_ego_flow"] = {"launch_us": us, "call_wall_us": wall, "algorithmic_bytes": alg,
                           "achieved_GBps": alg / us / 1e3, "frac": alg / us / 1e3 / HBM_PEAK_GBS,
-                          "workload": "camera_affine_grid of the same 16 frames (6 calls back to back between one pair of events)",
-                          "checked_by": "tests/test_hip_full_configs.py::test_cfg5_ego_flow_grid_1280x960 "
-                                        "(reference-generated fixture g8b; the oracle has no restatement of "
-                                        "camera_affine_grid to check a bench sample against)"}
+                          "gpu_matches_cpu_on_sample": checks5["camera_affine_grid"],
+                          "fused_call_matches_cpu_on_sample": checks5["orth_project_and_flow"],
+                          "workload": "camera_affine_grid of the same 16 frames (6 calls back to back between one pair "
+                                      "of events; frame 0 checked against oracle.camera_affine_grid, as is the grid "
+                                      "of the fused orth_project_and_flow call)"}
   res["working_sets"] = ("cfg3, cfg4 and cfg5 rotate over input batches and output blocks like the headline loop (what a call "
                          "touches comes around after > 2 x 256 MiB of other traffic); cfg1 is one 0.6 MB frame")
   return res

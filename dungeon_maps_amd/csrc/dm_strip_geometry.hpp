@@ -310,9 +310,11 @@ __host__ __device__ inline uint32_t row_owned(const uint32_t* cover, int p, int 
 }
 
 // Cells x' < x of a row that lie in TWO OR MORE of (up to) four covers -- the frame-wide numbering of the
-// shared float4 groups (compact planes): inclusion-exclusion over the covers' intersections (a cell in k covers
-// counts C(k,2) - 2 C(k,3) + 3 C(k,4) = 1 for k = 2, 3, 4).  An empty cover (0) meets nothing.
-__host__ __device__ inline int shared_before(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int x) {
+// shared float4 groups (compact planes) -- and, for the hole test, the cells x' < x in ANY cover:
+// inclusion-exclusion over the covers' intersections (a cell in k covers counts C(k,2) - 2 C(k,3) + 3 C(k,4)
+// = 1 for k = 2, 3, 4 among the shared ones, k - C(k,2) + C(k,3) - C(k,4) = 1 for k >= 1 in the union).
+// An empty cover (0) meets nothing.
+__host__ __device__ inline int cover_measures(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int x, int* covered) {
   const int l0 = (int)(c0 & 0xffffu), l1 = (int)(c1 & 0xffffu), l2 = (int)(c2 & 0xffffu), l3 = (int)(c3 & 0xffffu);
   int h0 = (int)(c0 >> 16), h1 = (int)(c1 >> 16), h2 = (int)(c2 >> 16), h3 = (int)(c3 >> 16);
   h0 = h0 < x ? h0 : x; h1 = h1 < x ? h1 : x; h2 = h2 < x ? h2 : x; h3 = h3 < x ? h3 : x;
@@ -325,7 +327,11 @@ __host__ __device__ inline int shared_before(uint32_t c0, uint32_t c1, uint32_t 
   const int triples = len(mx(l01, l2), mn(h01, h2)) + len(mx(l01, l3), mn(h01, h3)) +
                       len(mx(l0, l23), mn(h0, h23)) + len(mx(l1, l23), mn(h1, h23));
   const int quad = len(mx(l01, l23), mn(h01, h23));
+  if (covered) *covered = len(l0, h0) + len(l1, h1) + len(l2, h2) + len(l3, h3) - pairs + triples - quad;
   return pairs - 2 * triples + 3 * quad;
+}
+__host__ __device__ inline int shared_before(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int x) {
+  return cover_measures(c0, c1, c2, c3, x, nullptr);
 }
 
 __host__ __device__ inline bool in_span(uint32_t span, int x) {

@@ -514,40 +514,48 @@ k_strip_scatter(StripArgs a) {
         cov[q] = strip::row_cover(gw, gl, gr, U.z0 + r, a.mw);
         rlo = min(rlo, cov[q] ? (int)(cov[q] & 0xffffu) : 32767); rhi = max(rhi, (int)(cov[q] >> 16));
       }
-      // this strip's cover and its owned span: the cover cut by the others' in strip::row_owned's
-      // order (part ^ 1, part ^ 2, ...), picked with selects (part is wave-uniform)
-      uint32_t mine = cov[0];
+      uint32_t owned = 0u;
+      int entries;
+      bool hole = false;
+      if (PLANES && kP2 == 4) {
+        // compact planes: the row's cells in two or more covers -- the same number in every workgroup of the frame
+        // (the numbering of the shared groups) -- and the cells in any cover: fewer than the hull holds = a hole
+        int covered = 0;
+        entries = strip::cover_measures(cov[0], cov[1 % kP2], cov[2 % kP2], cov[3 % kP2], 1 << 30, &covered);
+        hole = rhi > rlo && covered < rhi - rlo;
+      } else {
+        // this strip's cover and its owned span: the cover cut by the others' in strip::row_owned's
+        // order (part ^ 1, part ^ 2, ...), picked with selects (part is wave-uniform)
+        uint32_t mine = cov[0];
 #pragma unroll
-      for (int q = 1; q < kP2; ++q) mine = part == q ? cov[q] : mine;
-      int lo = (int)(mine & 0xffffu), hi = (int)(mine >> 16);
+        for (int q = 1; q < kP2; ++q) mine = part == q ? cov[q] : mine;
+        int lo = (int)(mine & 0xffffu), hi = (int)(mine >> 16);
 #pragma unroll
-      for (int m = 1; m < kP2; ++m) {
-        const int o = part ^ m;
-        uint32_t other = cov[0];
+        for (int m = 1; m < kP2; ++m) {
+          const int o = part ^ m;
+          uint32_t other = cov[0];
 #pragma unroll
-        for (int q = 1; q < kP2; ++q) other = o == q ? cov[q] : other;
-        strip::cut_span(lo, hi, other);
+          for (int q = 1; q < kP2; ++q) other = o == q ? cov[q] : other;
+          strip::cut_span(lo, hi, other);
+        }
+        owned = hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
+        // entries of this strip's list on the row: the groups of its cover outside the owned span
+        entries = (int)((mine >> 16) - (mine & 0xffffu)) - (hi > lo ? hi - lo : 0);
+        // A hole between covers inside the hull: some cover ends inside the hull where no other cover
+        // continues.
+#pragma unroll
+        for (int q = 0; q < kP2; ++q) {
+          const int end = (int)(cov[q] >> 16);
+          bool continued = (cov[q] == 0u) | (end >= rhi);
+#pragma unroll
+          for (int o = 0; o < kP2; ++o)
+            if (o != q) continued = continued | (((int)(cov[o] & 0xffffu) <= end) & (end < (int)(cov[o] >> 16)));
+          hole = hole | !continued;
+        }
       }
-      const uint32_t owned = hi > lo ? (uint32_t)lo | ((uint32_t)hi << 16) : 0u;
-      // entries of this strip's list on the row: the groups of its cover outside the owned span
-      int entries = (int)((mine >> 16) - (mine & 0xffffu)) - (hi > lo ? hi - lo : 0);
-      // (compact planes: the row's groups in two or more covers -- the same number in every workgroup of the frame)
-      if (PLANES && kP2 == 4) entries = strip::shared_before(cov[0], cov[1 % kP2], cov[2 % kP2], cov[3 % kP2], 1 << 30);
       entries = live ? entries >> 2 : 0;
       const int before = wave_inclusive_scan(entries);       // over the wave's rows
       if (lane == 63) geom->chunk_entries[r0 >> 6] = before;
-      // A hole between covers inside the hull: some cover ends inside the hull where no other cover
-      // continues.
-      bool hole = false;
-#pragma unroll
-      for (int q = 0; q < kP2; ++q) {
-        const int end = (int)(cov[q] >> 16);
-        bool continued = (cov[q] == 0u) | (end >= rhi);
-#pragma unroll
-        for (int o = 0; o < kP2; ++o)
-          if (o != q) continued = continued | (((int)(cov[o] & 0xffffu) <= end) & (end < (int)(cov[o] >> 16)));
-        hole = hole | !continued;
-      }
       if (live) {
         if (kP2 == 4) {
           *reinterpret_cast<uint4*>(covers + r * 4) = make_uint4(cov[0], cov[1], cov[2], cov[3]);
@@ -555,7 +563,7 @@ k_strip_scatter(StripArgs a) {
           *reinterpret_cast<uint4*>(covers + r * 8) = make_uint4(cov[0], cov[1], cov[2], cov[3]);
           *reinterpret_cast<uint4*>(covers + r * 8 + 4) = make_uint4(cov[4 % kP2], cov[5 % kP2], cov[6 % kP2], cov[7 % kP2]);
         }
-        owned_t[r] = owned;
+        if (!PLANES) owned_t[r] = owned;
         reach[r] = rhi > rlo ? make_uint2((unsigned)rlo, (unsigned)(rhi - rlo)) : make_uint2(0u, 0u);
         list_at[r] = before - entries;
         // (groups of the hull in no strip's cover: stored behind the barrier by the workgroup whose fill

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DUNGEON_MAPS_AMD_LIB") or os.path.join(
     HERE, "csrc", "libdungeon_maps_amd.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # dm_reduction
 REDUCE_MAX, REDUCE_MIN, REDUCE_SUM, REDUCE_MEAN, REDUCE_PROD = range(5)
@@ -62,6 +62,7 @@ class NativeError(RuntimeError):
 
 _SIGNATURES = {
     "dm_version": (ctypes.c_int, []),
+    "dm_build_flags": (ctypes.c_char_p, []),
     "dm_last_error": (ctypes.c_char_p, []),
     "dm_orth_project_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Params)]),
     "dm_orth_project_f32": (ctypes.c_int, [
@@ -100,6 +101,7 @@ _SIGNATURES = {
     "dm_debug_last_path": (ctypes.c_int, []),
     "dm_debug_force_legacy_window": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_force_strips": (ctypes.c_int, [ctypes.c_int]),
+    "dm_debug_planes": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_fill_split": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_force_nt_fill": (ctypes.c_int, [ctypes.c_int]),
     "dm_debug_strip_value_list": (ctypes.c_int, [ctypes.c_int]),
@@ -160,7 +162,7 @@ _lib = None
 
 
 def exported_symbols():
-  """Names include/dungeon_maps_amd.h declares (checked by the CPU tests)."""
+  """Names include/dungeon_maps_amd.h and include/dungeon_maps_amd_debug.h declare (checked by the CPU tests)."""
   return sorted(_SIGNATURES)
 
 

@@ -75,6 +75,22 @@ extern "C" {
 
 int dm_version(void) { return DM_ABI_VERSION; }
 
+// Builds that change results for timing's sake (the pixel loop without its arithmetic, the kernels without their
+// fill duty or their LDS atomics: tools/experiments/measurement_switches_r4.patch) never ship: refused here.
+#if defined(DM_X_NOMATH) || defined(DM_X_NOFILL2) || defined(DM_X_NOATOMIC) || defined(DM_X_COMBINE_NOP)
+#error "a DM_X_NO* build computes wrong maps: apply it from tools/experiments, never to the product tree"
+#endif
+const char* dm_build_flags(void) {
+  return ""
+#ifdef DM_STAMPS
+         "DM_STAMPS "
+#endif
+#ifdef DM_HOST_TIMING
+         "DM_HOST_TIMING "
+#endif
+      ;
+}
+
 const char* dm_last_error(void) { return g_err; }
 
 size_t dm_orth_project_workspace_bytes(const dm_params* p) {

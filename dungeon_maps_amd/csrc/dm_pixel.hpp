@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "../../include/dungeon_maps_amd.h"
+#include "../../include/dungeon_maps_amd_debug.h"
 
 namespace dm {
 

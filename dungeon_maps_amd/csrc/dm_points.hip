@@ -191,14 +191,10 @@ k_camera_affine_grid4(View v, float fx_inv, float fy_inv, int dc, GridFrames arg
   const size_t base = ((size_t)b * dc + ch) * ((size_t)v.H * v.W);
   // the coefficients as {c, c} pairs (flow_pixel2).  Two pixels per instruction: 85 -> 58 VALU instructions
   // per pixel, 61 -> 46 us at 16 x 1280x960 with the working set beyond the Infinity Cache.  (Pinned in
-  // vector registers, -DDM_X_FLOW_VPAIRS, the pairs need no scalar moves but 128 registers per
-  // thread instead of 60: half the waves per SIMD, 69-71 us.)
+  // vector registers the pairs need no scalar moves but 128 registers per thread instead of 60: half the
+  // waves per SIMD, 69-71 us.)
   FlowPairs c;
-#ifdef DM_X_FLOW_VPAIRS
-  auto pair = [](float x) { f32x2 p = {x, x}; asm volatile("" : "+v"(p)); return p; };
-#else
   auto pair = [](float x) { return (f32x2){x, x}; };
-#endif
 #pragma unroll
   for (int i = 0; i < 9; ++i) { c.rp[i] = pair(rp[i]); c.ry[i] = pair(ry[i]); c.ri[i] = pair(ri[i]); }
   c.cam_h = pair(cam_h); c.neg_cam_h = pair(-cam_h); c.tx = pair(tx); c.tz = pair(tz);
@@ -296,7 +292,7 @@ hipError_t run_camera_affine_grid(const dm_params& p, const dm_frame* frames_hos
     thread_local GridFrames args;
     for (int b0 = 0; b0 < p.B; b0 += kGridFrames) {
       const int nb = p.B - b0 < kGridFrames ? p.B - b0 : kGridFrames;
-      static const int target = getenv("DM_X_EGO_BLOCKS") ? atoi(getenv("DM_X_EGO_BLOCKS")) : 4096;
+      constexpr int target = 4096;
       int per_image = target / (nb * p.dc);
       const int most = (chunks + 255) / 256;
       if (per_image < 1) per_image = 1;
@@ -496,15 +492,11 @@ k_crop_nearest4(const float* __restrict__ src, const uint8_t* __restrict__ src_m
   }
 }
 
-#ifndef DM_X_CROP_ROWS
-#define DM_X_CROP_ROWS 1
-#endif
-
 hipError_t run_crop_nearest(const float* src, const uint8_t* src_mask, const float* center, int B,
                             int C, int h, int w, int ch, int cw, float fill, int has_fill,
                             float* dst, uint8_t* dst_mask, hipStream_t s) {
   if (cw % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0 && reinterpret_cast<uintptr_t>(dst_mask) % 4 == 0) {
-    constexpr int kRows = DM_X_CROP_ROWS;
+    constexpr int kRows = 1;       // (two / four crop rows per thread: no better / worse)
     const dim3 grid((unsigned)(((size_t)((ch + kRows - 1) / kRows) * (cw / 4) + 255) / 256), C, B);
     hipLaunchKernelGGL(k_crop_nearest4<kRows>, grid, dim3(256), 0, s, src, src_mask, center, C, h, w, ch, cw,
                        fill, has_fill, dst, dst_mask);

@@ -18,9 +18,7 @@
 #include "dm_strip_kernels.hpp"
 #include "dm_strip_fused_kernels.hpp"
 
-#ifndef DM_X_COMBINE_ENTRIES
-#define DM_X_COMBINE_ENTRIES 4      // list entries per thread of the combine kernel for value maps of many channels
-#endif
+constexpr int kCombineEntriesMany = 4;      // list entries per thread of the combine kernel for value maps of many channels
 
 namespace dm {
 
@@ -295,12 +293,8 @@ StripKernel pick_index_kernel(bool has_valid, bool lean) {
 // fetches the unit's part of the pixel list once (PMC at cfg3: 3.72 -> 3.36 GB fetched by the pass, the list read
 // ~5.5 times per call instead of ~14) -- and the pass takes 2 % LONGER (1 442 / 1 451 against 1 416 / 1 421 us on one
 // box): the re-reads were hits in the Infinity Cache, which cost HBM nothing, while a fixed 32 units per XCD
-// balance worse than blocks dealt one by one.  Off; -DDM_X_XCD_UNITS switches it on.
-#ifdef DM_X_XCD_UNITS
-constexpr bool g_no_xcd_units = false;
-#else
+// balance worse than blocks dealt one by one.  Off.
 constexpr bool g_no_xcd_units = true;
-#endif
 
 StripKernel pick_value_kernel(bool is_max) {
   return is_max ? k_strip_scatter<kMax, false, true, true, kFromList>
@@ -363,16 +357,16 @@ inline hipError_t launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
 }
 
 hipError_t raise_lds_limit(const void* key) {
-  static thread_local const void* done[32][8] = {};
+  static thread_local const void* done[128][8] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 8)
-    for (int i = 0; i < 32; ++i)
+    for (int i = 0; i < 128; ++i)
       if (done[i][dev] == key) return hipSuccess;
   const hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
   if (e != hipSuccess) return e;
   if (dev >= 0 && dev < 8)
-    for (int i = 0; i < 32; ++i)
+    for (int i = 0; i < 128; ++i)
       if (!done[i][dev]) { done[i][dev] = key; break; }
   return hipSuccess;
 }
@@ -525,11 +519,11 @@ hipError_t strip_pass(const dm_params& p, const Plan& plan, const Rig& rg, const
           // (at least one block per strip's list segment)
           // (many channels: the chip holds 2 K blocks at a time, so the fewer blocks per (frame, channel) the
           // fewer rounds of the same chain of round trips -- 8 blocks: 131 us at cfg3, 4: 88 us)
-          const int few = kCombineSlots / DM_X_COMBINE_ENTRIES / 2;
+          const int few = kCombineSlots / kCombineEntriesMany / 2;
           const int blocks = few > plan.P ? few : plan.P;
           const dim3 g(blocks, (unsigned)(nc * oc));
-          e = is_max ? launch(k_strip_combine<kMax, DM_X_COMBINE_ENTRIES>, g, dim3(kCombineThreads), 0, s, ca)
-                     : launch(k_strip_combine<kMin, DM_X_COMBINE_ENTRIES>, g, dim3(kCombineThreads), 0, s, ca);
+          e = is_max ? launch(k_strip_combine<kMax, kCombineEntriesMany>, g, dim3(kCombineThreads), 0, s, ca)
+                     : launch(k_strip_combine<kMin, kCombineEntriesMany>, g, dim3(kCombineThreads), 0, s, ca);
         } else {
           const dim3 g(kCombineSlots > plan.P ? kCombineSlots : plan.P, (unsigned)(nc * oc));
           e = is_max ? launch(k_strip_combine_one<kMax>, g, dim3(kCombineThreads), 0, s, ca)

@@ -115,7 +115,7 @@ k_strip_fused(FusedArgs a) {
       int rr = (c * S + u) * rows_per_iter + gy;
       rr = rr < a.H ? rr : a.H - 1;
       const int at = __mul24(f * fstride + rr, a.W) + q;
-      const f32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_depth, at << 2, 0, DM_X_DEPTH_POLICY);
+      const f32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_depth, at << 2, 0, 0);
       z[u][0] = t.x; z[u][1] = t.y; z[u][2] = t.z; z[u][3] = t.w;
       if (HAS_VALID) {
         const unsigned ok4 = __builtin_amdgcn_raw_buffer_load_b32(rs_valid, __mul24(f * vstride + rr, a.W) + q, 0, 0);

@@ -235,7 +235,7 @@ struct StripArgs {
 // RED: kMin / kMax.  Always the fast geometry (axis-aligned rotations, exact FMA division),
 // 16-byte depth loads.  HAS_VALUE / HAS_VALID / LEAN as in k_window_scatter.
 //
-// The pixel loop is bound by VALU issue (tools/strip_stamps.py with the DM_X_* switches: 21 us
+// The pixel loop is bound by VALU issue (tools/strip_stamps.py with timing-only builds, tools/experiments: 21 us
 // of arithmetic against 15 us of memory traffic at cfg2), so everything a pixel does not need
 // is kept out of it: the geometry is derived once in the kernel's head, the ray slope of an image row from
 // a table in LDS, the fill duty is wave-level stores with scalar addressing, and a strip whose
@@ -251,22 +251,8 @@ struct StripArgs {
 //   kFromList    the value pass, one workgroup per (strip, channel, frame): cells from the list,
 //                values from the channel's image -- 8 + 16 bytes per thread and row, four
 //                instructions per pixel instead of twenty, four rows in flight.
-// (measurement switches: cache policy of the depth loads / value loads / the fill duty's mask stores; 0 = the
-// kernel's own choice or the default policy, 2 = nt)
-#ifndef DM_X_DEPTH_POLICY
-#define DM_X_DEPTH_POLICY 0
-#endif
-#ifndef DM_X_VALUE_POLICY
-#define DM_X_VALUE_POLICY 0
-#endif
-#ifndef DM_X_FLUSH_POLICY
-#define DM_X_FLUSH_POLICY 0
-#endif
-#ifndef DM_X_MASK_POLICY
-#define DM_X_MASK_POLICY 0
-#endif
-// PLANES (kProject, at most four strips): the shared groups go to compact planes instead of slabs + lists
-// (StripArgs::plane_cap); k_strip_combine_planes follows instead of k_strip_combine_one.
+// (cache policies that were measured and left at the default -- value loads, the flush's map stores, the fill
+// duty's mask stores non-temporal: DESIGN 4.6 -- are not switches any more; tools/experiments has the patch)
 enum { kProject = 0, kIndexOut = 1, kFromList = 2 };
 template <int RED, bool HAS_VALID, bool HAS_VALUE, bool LEAN, int MODE = kProject, bool NT_FILL = true, bool PLANES = false>
 __global__ void __launch_bounds__(kScatterThreads)
@@ -291,14 +277,11 @@ k_strip_scatter(StripArgs a) {
   // (cfg3 1 473 -> 1 545 us), k_strip_fused no different, and the window path's projection is followed by
   // the ego-motion flow kernel, which finds the depth maps in the Infinity Cache only under the default
   // policy (cfg5 flow call 153 -> 176 us).
-  constexpr int kDepthPolicy = DM_X_DEPTH_POLICY ? DM_X_DEPTH_POLICY : ((NT_FILL && MODE == kProject) ? 2 : 0);
+  constexpr int kDepthPolicy = (NT_FILL && MODE == kProject) ? 2 : 0;
   // fill steps (wave-level, 1 KB each) per pipeline half-iteration: three or four make every wait for
   // the depth loads wait for older stores too (+2 us per extra step at cfg2), none or one moves
   // the stores behind the loop for the same total
-#ifndef DM_X_FILL_PER_HALF
-#define DM_X_FILL_PER_HALF 2
-#endif
-  constexpr int kStripFillPerHalf = DM_X_FILL_PER_HALF;
+  constexpr int kStripFillPerHalf = 2;
   extern __shared__ float lds[];
   // (the value pass runs channel-major: the workgroups of one (frame, strip) -- which read the same
   // part of the pixel list -- are dispatched together)
@@ -372,7 +355,7 @@ k_strip_scatter(StripArgs a) {
           z[u][k] = ((ok4 >> (8 * k)) & 0xffu) ? z[u][k] : qnan;
       }
       if (HAS_VALUE) {
-        const f32x4 s = __builtin_amdgcn_raw_buffer_load_b128(rs_value, at << 2, 0, DM_X_VALUE_POLICY);
+        const f32x4 s = __builtin_amdgcn_raw_buffer_load_b128(rs_value, at << 2, 0, 0);
         sv[u][0] = s.x; sv[u][1] = s.y; sv[u][2] = s.z; sv[u][3] = s.w;
       }
     }
@@ -733,11 +716,7 @@ k_strip_scatter(StripArgs a) {
     j_lo = __builtin_amdgcn_readfirstlane(U.h > 0 ? min(lo, j_hi) : 0);
     j_hi = __builtin_amdgcn_readfirstlane(U.h > 0 ? min(hi, j_hi) : 0);
   }
-#ifdef DM_X_NOFILL2
-  const int fill_steps = 0;
-#else
   const int fill_steps = la->out != nullptr && j_hi > j_lo ? (j_hi - j_lo) * chunks : 0;
-#endif
   const int lane4 = lane << 2;
   int fs = 0, f_row = part + (wave + 16 * j_lo) * fparts, f_chunk = 0;       // (wave-uniform)
   // the reach of a map row ({0, 0} outside U's rows), read from LDS TWO steps ahead: the steps
@@ -768,7 +747,7 @@ k_strip_scatter(StripArgs a) {
     const int cell0 = __builtin_amdgcn_readfirstlane(live ? f_row * la->mw + (f_chunk << 8) : 0);
     buffer_store_b128_at_scalar_offset<NT_FILL ? kFillCachePolicy : 0>(
         (u32x4){fill_bits, fill_bits, fill_bits, fill_bits}, rs_out, skip ? 0x7ffffff0 : lane4 << 2, cell0 << 2);
-    __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, skip ? 0x7ffffff0 : lane4, cell0, DM_X_MASK_POLICY);
+    __builtin_amdgcn_raw_buffer_store_b32(0u, rs_mask, skip ? 0x7ffffff0 : lane4, cell0, 0);
     ++fs;
     advance(f_row, f_chunk);
     f_reach = f_reach1;
@@ -840,21 +819,11 @@ k_strip_scatter(StripArgs a) {
                 li[k] = same ? dummy : li[k];
               }
             }
-#ifndef DM_X_NOATOMIC
 #pragma unroll
             for (int k = 0; k < VEC; ++k) lds_reduce<RED>(lds_at(li[k]), hv[k]);
-#else
-            if (li[0] + li[1] + li[2] + li[3] == 12345u && hv[0] + hv[1] + hv[2] + hv[3] == 1.5f) lds_reduce<RED>(lds_at(dummy), hv[0]);
-#endif
           }
           return;
         }
-#ifdef DM_X_NOMATH
-#pragma unroll
-        for (int u = 0; u < kRowsInFlight; ++u)
-          lds_reduce<RED>(lds_at(dummy), fmaxf(fmaxf(z[u][0], z[u][1]), fmaxf(z[u][2], z[u][3])));
-        return;
-#endif
         // (LEAN heights: the two depth compares of a pixel go straight into the execution mask of
         // its LDS atomic -- v_cmpx twice, ds_max, mask back -- instead of into a select between
         // the cell and a dummy cell: 1.25 instructions per pixel less.  The LDS operation inside
@@ -983,38 +952,16 @@ k_strip_scatter(StripArgs a) {
         // favours the oldest wave otherwise, and the last wave left on a SIMD runs latency
         // bound).  Only now: under static priorities the four waves of a SIMD run the code
         // above one after the other instead of hiding each other's latencies.
-#ifdef DM_X_ROTPRIO
-        const int cls = wave >> 2;
-        // s_setprio takes an immediate: one opaque block of scalar code picks it (a branch the
-        // compiler sees would make it drain the loop's counted waits)
-        auto set_prio = [](int p) {
-          asm volatile("s_cmp_eq_u32 %0, 3\n\ts_cbranch_scc1 .Lp3_%=\n\t"
-                       "s_cmp_eq_u32 %0, 2\n\ts_cbranch_scc1 .Lp2_%=\n\t"
-                       "s_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 .Lp1_%=\n\t"
-                       "s_setprio 0\n\ts_branch .Lpe_%=\n"
-                       ".Lp3_%=:\n\ts_setprio 3\n\ts_branch .Lpe_%=\n"
-                       ".Lp2_%=:\n\ts_setprio 2\n\ts_branch .Lpe_%=\n"
-                       ".Lp1_%=:\n\ts_setprio 1\n"
-                       ".Lpe_%=:\n" :: "s"(p) : "scc");
-        };
-#elif !defined(DM_X_NOPRIO)
         if (wave >= 12) __builtin_amdgcn_s_setprio(3);
         else if (wave >= 8) __builtin_amdgcn_s_setprio(2);
         else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
         for (int it = 0; it < niter; it += 2) {
-#ifdef DM_X_ROTPRIO
-          set_prio((cls + it) & 3);
-#endif
 #pragma unroll
           for (int t = 0; t < kStripFillPerHalf; ++t) fill_step();
           project_rows(tested, za, va, aya, r);
           if (it + 1 < niter) {
             load_rows(za, va, r + 2 * step);
             load_ay(aya, r + 2 * step);
-#ifdef DM_X_ROTPRIO
-            set_prio((cls + it + 1) & 3);
-#endif
 #pragma unroll
             for (int t = 0; t < kStripFillPerHalf; ++t) fill_step();
             project_rows(tested, zb_, vb_, ayb, r + step);
@@ -1084,7 +1031,7 @@ k_strip_scatter(StripArgs a) {
           }
           if (mine) {
             const int cell = z * fa->mw + x;
-            __builtin_amdgcn_raw_buffer_store_b128((f32x4){v.x, v.y, v.z, v.w}, rs_out, cell << 2, 0, DM_X_FLUSH_POLICY);
+            __builtin_amdgcn_raw_buffer_store_b128((f32x4){v.x, v.y, v.z, v.w}, rs_out, cell << 2, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(mask_bits(v), rs_mask, cell, 0, 0);
           } else {
             *reinterpret_cast<float4*>(slab + cell0 + x) = v;
@@ -1147,7 +1094,7 @@ k_strip_scatter(StripArgs a) {
                                 (strip::in_span(c0.z, x) ? 4u : 0u) | (strip::in_span(c0.w, x) ? 8u : 0u);
           const int cell = z * fa->mw + x;
           if (hits == me) {
-            __builtin_amdgcn_raw_buffer_store_b128((f32x4){v.x, v.y, v.z, v.w}, rs_out, cell << 2, 0, DM_X_FLUSH_POLICY);
+            __builtin_amdgcn_raw_buffer_store_b128((f32x4){v.x, v.y, v.z, v.w}, rs_out, cell << 2, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(mask_bits(v), rs_mask, cell, 0, 0);
           } else {
             const int pos = base + (strip::shared_before(c0.x, c0.y, c0.z, c0.w, x) >> 2);
@@ -1192,10 +1139,7 @@ constexpr int kCombineThreads = 256;
 // blocks per frame: the kernel is one chain of round trips), four for value maps of many channels
 // (the chip holds 2 K blocks at a time: with one entry per thread 40 channels were twenty rounds
 // of that chain, 200 us; with four, 80 us).
-#ifndef DM_X_COMBINE_SLOTS
-#define DM_X_COMBINE_SLOTS 32
-#endif
-constexpr int kCombineSlots = DM_X_COMBINE_SLOTS;       // (the lists hold about as many dead entries as live ones: twice the blocks of round 2)
+constexpr int kCombineSlots = 32;       // (the lists hold about as many dead entries as live ones: twice the blocks of round 2)
 
 // The combine kernel's share of the fill duty (StripArgs::defer_outer): the map rows z of (frame b,
 // channel chl) outside the union window's rows [uz0, uz0 + uh) whose index among their wave's rows

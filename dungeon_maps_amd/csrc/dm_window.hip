@@ -234,14 +234,14 @@ hipError_t window_pass(const dm_params& p, const Staged& st, float* slabs,
                                : pick_kernel(red, st.fast, has_valid, has_value, vec4, lean, stream);
   hipError_t e = hipSuccess;
   {   // raise the dynamic-LDS limit once per kernel variant and device
-    static thread_local const void* done[64][8] = {};
+    static thread_local const void* done[160][8] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const void* key = reinterpret_cast<const void*>(kfn);
     bool seen = false;
     int free_slot = -1;
     if (dev >= 0 && dev < 8) {
-      for (int i = 0; i < 64; ++i) {
+      for (int i = 0; i < 160; ++i) {
         if (done[i][dev] == key) { seen = true; break; }
         if (!done[i][dev] && free_slot < 0) free_slot = i;
       }

@@ -595,10 +595,7 @@ struct MergeArgs {
 };
 
 constexpr int kMergeThreads = 256;
-#ifndef DM_X_MERGE_DEPTH
-#define DM_X_MERGE_DEPTH 8
-#endif
-constexpr int kMergeDepth = DM_X_MERGE_DEPTH;      // slab loads a thread of the merge kernels keeps in flight
+constexpr int kMergeDepth = 8;      // slab loads a thread of the merge kernels keeps in flight
 
 // Writes the union window U of every (frame, channel): max/min over the slabs covering
 // each cell, fill where none does.  One float4 group per thread, row-major inside U, so
@@ -772,36 +769,21 @@ struct FuseArgs {
   uint8_t* fused_mask;
 };
 
-#ifndef DM_X_FUSEWIN_GROUPS
-#define DM_X_FUSEWIN_GROUPS 16
-#endif
-#ifndef DM_X_FUSEWIN_LANES
-#define DM_X_FUSEWIN_LANES 16
-#endif
 // (16 groups x 16 lanes x 16 loads in flight: 8.0 us per launch at cfg4; 32 x 8 x 16: 8.9-9.2, 32 x 16: 8.2, 16 x 32: 9.2,
 // 8 x 32: 9.8, 64 x 8: 11.3, 64 x 4 / 32 x 4 with 32 loads: 13.2 / 13.4 -- a tile's 100-200 candidates want many lanes)
-constexpr int kFuseGroups = DM_X_FUSEWIN_GROUPS;     // k_fuse_windows: float4 groups of the fused map per block
-constexpr int kFuseLanes = DM_X_FUSEWIN_LANES;       //   threads sharing one group (they split the candidate windows)
+constexpr int kFuseGroups = 16;     // k_fuse_windows: float4 groups of the fused map per block
+constexpr int kFuseLanes = 16;       //   threads sharing one group (they split the candidate windows)
 
-#ifndef DM_X_UNION_GROUPS
-#define DM_X_UNION_GROUPS 64
-#endif
-#ifndef DM_X_UNION_LANES
-#define DM_X_UNION_LANES 4
-#endif
-#ifndef DM_X_UNION_DEPTH
-#define DM_X_UNION_DEPTH 16
-#endif
-constexpr int kUnionGroups = DM_X_UNION_GROUPS;   // k_fuse_unions: float4 groups of the fused map per block,
-constexpr int kUnionLanes = DM_X_UNION_LANES;     //   threads sharing one group (frames b = lane mod that many),
-constexpr int kUnionDepth = DM_X_UNION_DEPTH;     //   map loads a thread keeps in flight
+constexpr int kUnionGroups = 64;   // k_fuse_unions: float4 groups of the fused map per block,
+constexpr int kUnionLanes = 4;     //   threads sharing one group (frames b = lane mod that many),
+constexpr int kUnionDepth = 16;     //   map loads a thread keeps in flight
 // Block = 64 groups x 4 frame lanes.  Each thread tests the unions of its frames
 // (lane, lane + 4, ...) sixteen at a time, loads the covered maps (independent
 // 16-byte loads), and the 4 partial results of a group are combined through LDS.
 // (Round 4: 1 KB of a frame's map row per block instead of 512 B -- longer bursts per frame -- and
 // all of a thread's 16 loads of a 64-frame batch in flight at once: 163 -> 136 us per cfg3 step
 // (40 channels), 6.5 -> 5.7 us at cfg2; 32 x 8 x 8 before, 64 x 8, 128 x 2 / x 4, 64 x 2, 32 x 4
-// measured worse: -DDM_X_UNION_GROUPS / _LANES / _DEPTH.)
+// measured worse.)
 template <bool IS_MAX>
 __global__ void __launch_bounds__(kUnionGroups * kUnionLanes)
 k_fuse_unions(FuseArgs a) {
@@ -891,10 +873,7 @@ struct FuseWinArgs {
 };
 
 constexpr int kFuseChunk = 1024;    // windows examined per candidate-list round
-#ifndef DM_X_FUSE_DEPTH
-#define DM_X_FUSE_DEPTH 16
-#endif
-constexpr int kFuseDepth = DM_X_FUSE_DEPTH;   // slab loads a lane keeps in flight
+constexpr int kFuseDepth = 16;   // slab loads a lane keeps in flight
 
 template <bool IS_MAX>
 __global__ void __launch_bounds__(kFuseGroups * kFuseLanes)

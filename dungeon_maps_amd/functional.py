@@ -69,7 +69,9 @@ def _compute_device(target: torch.device) -> torch.device:
   """The GPU the kernels run on: the tensors' own device when that is a GPU,
   else the current GPU.  No GPU -> error (no CPU path by design)."""
   if target.type == "cuda":
-    return target
+    # (with an index: device='cuda' names the current GPU, and a caller's tensors on cuda:0 compare unequal
+    # to torch.device('cuda'))
+    return target if target.index is not None else torch.device("cuda", torch.cuda.current_device())
   if not torch.cuda.is_available():
     raise RuntimeError(
         "dungeon_maps_amd computes on an AMD GPU through its HIP library and has no CPU "

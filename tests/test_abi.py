@@ -11,12 +11,22 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "dungeon_maps_amd.h")
+DEBUG_HEADER = os.path.join(ROOT, "include", "dungeon_maps_amd_debug.h")
 
 
-def _declared_functions():
-  src = open(HEADER).read()
-  src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-  return sorted(set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", src)))
+def _declared_functions(*headers):
+  found = set()
+  for h in headers or (HEADER, DEBUG_HEADER):
+    src = open(h).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    found |= set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", src))
+  return sorted(found)
+
+
+def test_debug_hooks_live_in_their_own_header():
+  """The drop-in boundary declares no test / measurement hook; the debug header declares nothing else."""
+  assert not [n for n in _declared_functions(HEADER) if n.startswith("dm_debug_")]
+  assert all(n.startswith("dm_debug_") for n in _declared_functions(DEBUG_HEADER))
 
 
 def test_library_exports_every_declared_symbol():

@@ -20,7 +20,7 @@ import pytest
 from dungeon_maps_amd import _native
 
 LLVM = "/opt/rocm/lib/llvm/bin"
-HOT = ("k_strip_scatter", "k_strip_combine", "k_strip_fused", "k_fuse_unions", "k_fuse_windows", "k_window_merge",
+HOT = ("k_strip_scatter", "k_strip_combine", "k_strip_combine_planes", "k_strip_fused", "k_fuse_unions", "k_fuse_windows", "k_window_merge",
        "k_camera_affine_grid4", "k_crop_nearest4")
 
 
@@ -75,3 +75,19 @@ def test_kernels_use_no_scratch_and_spill_no_vector_registers():
     assert not bad, "\n".join("%s: %s" % b for b in bad)
   finally:
     shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_shipped_library_is_the_product_build():
+  """No measurement / instrumentation flag in the library the package loads (dm_build_flags): timing-only
+  builds that compute wrong maps do not exist in this tree (tools/experiments keeps them as patches, the
+  sources #error on their macros), instrumented ones (-DDM_STAMPS) live under tools/tmp."""
+  lib = _native.lib()
+  assert lib.dm_build_flags() == b"", lib.dm_build_flags()
+  src = os.path.join(os.path.dirname(_native.LIB_PATH))
+  hits = []
+  for f in sorted(os.listdir(src)):
+    if f.endswith((".hip", ".hpp")):
+      for i, line in enumerate(open(os.path.join(src, f)), 1):
+        if re.search(r"#\s*if.*DM_X_", line) and "#error" not in line and "defined(DM_X_NO" not in line:
+          hits.append(f"{f}:{i}: {line.strip()}")
+  assert not hits, "measurement switches inside the product sources:\n" + "\n".join(hits)

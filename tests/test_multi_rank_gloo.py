@@ -54,13 +54,14 @@ def _worker(rank, world, port, out_dir):
   rng = np.random.default_rng(3)
   labels = rng.integers(0, 3, size=depth.shape[:1] + depth.shape[2:])
   onehot = np.eye(3, dtype=np.float32)[labels].transpose(0, 3, 1, 2).copy()
-  for tag, value, fill in (("counts", onehot, 0.0), ("heights", None, 1.5)):
+  for tag, value, fill in (("counts", onehot, 0.0), ("heights", None, 1.5), ("heights01", None, 0.1)):
     kw = dict(_cfg(oracle), fill_value=fill, reduction="sum")
-    maps, _ = oracle.orth_project(depth[lo:hi], value_map=None if value is None else value[lo:hi],
-                                  cam_pose=pose[lo:hi], **kw)
-    part = parallel.partial_sum_map(torch.from_numpy(maps.copy()), fill)
-    parallel.all_reduce_fused(part, "sum", fill_value=fill)
+    maps, masks = oracle.orth_project(depth[lo:hi], value_map=None if value is None else value[lo:hi],
+                                      cam_pose=pose[lo:hi], **kw)
+    part, occ = parallel.partial_sum_map(torch.from_numpy(maps.copy()), torch.from_numpy(masks.copy()), fill)
+    parallel.all_reduce_fused(part, "sum", fill_value=fill, occupied=occ)
     np.save(os.path.join(out_dir, f"sum_{tag}_{rank}.npy"), part.numpy())
+    np.save(os.path.join(out_dir, f"occ_{tag}_{rank}.npy"), occ.numpy())
   dist.destroy_process_group()
 
 
@@ -80,17 +81,26 @@ def test_two_ranks_equal_one_rank(oracle, tmp_path):
   rng = np.random.default_rng(3)
   labels = rng.integers(0, 3, size=depth.shape[:1] + depth.shape[2:])
   onehot = np.eye(3, dtype=np.float32)[labels].transpose(0, 3, 1, 2).copy()
-  for tag, value, fill in (("counts", onehot, 0.0), ("heights", None, 1.5)):
+  # (fill 0.1 is not exactly summable in float32: B * fill - (B - 1) * fill != fill -- emptiness must come
+  # from the masks, never from a subtraction)
+  for tag, value, fill in (("counts", onehot, 0.0), ("heights", None, 1.5), ("heights01", None, 0.1)):
     kw = dict(_cfg(oracle), fill_value=fill, reduction="sum")
-    maps, _ = oracle.orth_project(depth, value_map=value, cam_pose=pose, **kw)
-    one = (maps.astype(np.float64) - fill).sum(0) + fill
+    maps, masks = oracle.orth_project(depth, value_map=value, cam_pose=pose, **kw)
+    hit = masks.any(0)
+    one = np.where(hit, np.where(masks, maps.astype(np.float64) - np.float32(fill), 0.0).sum(0) + np.float32(fill),
+                   np.float32(fill))
     for r in range(world):
       got = np.load(tmp_path / f"sum_{tag}_{r}.npy")
+      occ = np.load(tmp_path / f"occ_{tag}_{r}.npy")
+      np.testing.assert_array_equal(occ, hit)                       # the job-wide occupancy, on every rank
+      np.testing.assert_array_equal(got[~hit], np.float32(fill))    # empty cells hold EXACTLY the fill value
       if tag == "counts":
         np.testing.assert_array_equal(got, one.astype(np.float32))
         assert got.max() >= 2                       # cells several frames of both ranks hit
       else:
         np.testing.assert_allclose(got, one, rtol=1e-5, atol=1e-5)
+      # the mask of the fused map (mask_from_map: map - fill != 0) marks no empty cell
+      assert not ((got - np.float32(fill)) != 0)[~hit].any()
 
 
 def test_shard_range_partitions_the_batch():

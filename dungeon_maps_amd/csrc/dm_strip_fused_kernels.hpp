@@ -109,16 +109,20 @@ k_strip_fused(FusedArgs a) {
   // repeats the last frame -- max / min are idempotent, and straight-line code lets the S rows'
   // instruction streams interleave.
   auto load_stage = [&](float (&z)[S][VEC], int f, int c) {
-    f = f < nf ? f : nf - 1;
+    // (the pipeline requests one stage more than the group has -- never projected: its loads get an offset
+    // past the end of the buffer and move no bytes.  Until round 5 they repeated the last frame's rows: a
+    // fifth stage of loads for the four of a one-frame group, 100 MB fetched for 79 MB of depth maps at cfg4)
+    const bool past = f >= nf;
+    f = past ? nf - 1 : f;
 #pragma unroll
     for (int u = 0; u < S; ++u) {
       int rr = (c * S + u) * rows_per_iter + gy;
       rr = rr < a.H ? rr : a.H - 1;
       const int at = __mul24(f * fstride + rr, a.W) + q;
-      const f32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_depth, at << 2, 0, 0);
+      const f32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_depth, past ? 0x7ffffff0 : at << 2, 0, 0);
       z[u][0] = t.x; z[u][1] = t.y; z[u][2] = t.z; z[u][3] = t.w;
       if (HAS_VALID) {
-        const unsigned ok4 = __builtin_amdgcn_raw_buffer_load_b32(rs_valid, __mul24(f * vstride + rr, a.W) + q, 0, 0);
+        const unsigned ok4 = __builtin_amdgcn_raw_buffer_load_b32(rs_valid, past ? 0x7ffffff0 : __mul24(f * vstride + rr, a.W) + q, 0, 0);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) z[u][k] = ((ok4 >> (8 * k)) & 0xffu) ? z[u][k] : qnan;
       }

@@ -8,7 +8,9 @@ from dungeon_maps_amd import _native
 lib = _native.lib()
 B, H, W, mh, mw = 64, 480, 640, 1024, 1024
 g = torch.Generator().manual_seed(1)
-depth = torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g).cuda()
+ROT = int(os.environ.get("DM_ROT", "8"))       # depth batches in rotation: HBM-served
+depths = [torch.empty(B, 1, H, W).uniform_(0.1, 10.0, generator=g).cuda() for _ in range(ROT)]
+depth = depths[0]
 k = torch.arange(B, dtype=torch.float32)
 pose = torch.stack((0.02 * k, 0.01 * k, 0.01 * k), dim=1)
 proj = dmap.MapProjector(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.), cam_height=0.88,
@@ -24,11 +26,12 @@ for wp, F in [(0, 0), (160, 1), (80, 1), (80, 2), (40, 2), (40, 4), (32, 4), (20
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(30):
-      out = proj.orth_project_fused(depth, cam_pose=pose)
+    for j in range(32):
+      out = proj.orth_project_fused(depths[j % ROT], cam_pose=pose)
     e1.record(); torch.cuda.synchronize()
+    out = proj.orth_project_fused(depth, cam_pose=pose)
     if ref is None: ref = out
     same = torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
-    print("wp %3d F %d -> split %s  %.1f us/call  same=%s" % (wp, F, list(split), e0.elapsed_time(e1) * 1e3 / 30, same))
+    print("wp %3d F %d -> split %s  %.1f us/call  same=%s" % (wp, F, list(split), e0.elapsed_time(e1) * 1e3 / 32, same))
   finally:
     lib.dm_debug_force_fused_split(0, 0)

@@ -362,6 +362,14 @@ int main(int argc, char** argv) {
       cfgs.push_back({"1024 x 4 strips, type by id & 1 (fill first / last)", 1024, 4, valu, 6, 570, 0, 0, 1, 0});
     }
   }
+  if (want("skel")) {
+    // the bare traffic (no head, no arithmetic, no flush burst): does an anti-phase pair of 512-thread workgroups
+    // per CU beat the product's grid?
+    cfgs.push_back({"skeleton: 1024 x 4 strips (the product's grid)", 1024, 4, 0, 0, 0, 0, 0, 0, 0});
+    cfgs.push_back({"skeleton: 512 x 8 strips, in phase", 512, 8, 0, 0, 0, 0, 0, 0, 0});
+    cfgs.push_back({"skeleton: 512 x 8 strips, anti-phase by id & 1", 512, 8, 0, 0, 0, 0, 0, 1, 0});
+    cfgs.push_back({"skeleton: 512 x 8 strips, anti-phase by id / 256", 512, 8, 0, 0, 0, 0, 0, 2, 0});
+  }
   for (const auto& c : cfgs) run(c);
   if (want("mix")) {
     // 64 frames: 4 915 200 float4 groups of depth, 4 194 304 of maps (+ as many 4-byte mask words)

@@ -12,7 +12,7 @@ import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("k_strip_scatter", "k_strip_combine", "k_fuse_unions", "k_strip_fused", "k_fuse_windows", "k_window_scatter",
+KERNELS = ("k_strip_scatter", "k_strip_combine_planes", "k_strip_combine", "k_fuse_unions", "k_strip_fused", "k_fuse_windows", "k_window_scatter",
            "k_window_merge", "k_camera_affine_grid", "k_crop_nearest")
 SEQUENCE = {"cfg2": ("k_strip_scatter", "k_strip_combine"), "cfg3": ("k_strip_scatter", "k_strip_combine"),
             "cfg4": ("k_strip_fused", "k_fuse_windows"), "cfg5": ("k_window_scatter", "k_window_merge")}

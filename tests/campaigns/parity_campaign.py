@@ -139,6 +139,8 @@ def one(seed):
     LIB.dm_debug_force_strips(int(rng.integers(0, 9)))
   if FILL_SPLIT:
     LIB.dm_debug_fill_split(int(rng.choice([-1, 0, 3, 5, 8])))
+  # (the strip path's shared groups through compact planes -- the default -- or through slabs + lists, at random)
+  LIB.dm_debug_planes(int(rng.choice([-1, -1, 0])))
   d_dev = torch.from_numpy(depth).cuda()
   v_dev = None if value is None else torch.from_numpy(value).cuda()
   m_dev = None if valid is None else torch.from_numpy(valid).cuda()
@@ -234,6 +236,7 @@ def configure(env=None):
 def reset_switches():
   """Back to the library's defaults (the modes leave per-thread debug switches set)."""
   LIB.dm_debug_force_bands(0); LIB.dm_debug_force_strips(0); LIB.dm_debug_fill_split(-1); LIB.dm_debug_flow_fused(0)
+  LIB.dm_debug_planes(-1)
   LIB.dm_debug_force_fused_split(0, 0)
 
 

@@ -14,7 +14,9 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ("k_strip_scatter", "k_strip_combine_planes", "k_strip_combine", "k_fuse_unions", "k_strip_fused", "k_fuse_windows", "k_window_scatter",
            "k_window_merge", "k_camera_affine_grid", "k_crop_nearest")
-SEQUENCE = {"cfg2": ("k_strip_scatter", "k_strip_combine"), "cfg3": ("k_strip_scatter", "k_strip_combine"),
+# (exact names: at cfg3 the height pass of the with-height-map leg runs k_strip_scatter + k_strip_combine_planes too)
+SEQUENCE = {"cfg2": ("k_strip_scatter", "k_strip_combine_planes"),
+            "cfg3": ("k_strip_scatter (index pass)", "k_strip_scatter (value pass)", "k_strip_combine"),
             "cfg4": ("k_strip_fused", "k_fuse_windows"), "cfg5": ("k_window_scatter", "k_window_merge")}
 ALG = {"cfg2": 64 * (480 * 640 * 4 + 512 * 512 * 5), "cfg3": 64 * (480 * 640 * 4 * 41 + 40 * 512 * 512 * 5),
        "cfg4": 64 * 480 * 640 * 4 + 1024 * 1024 * 5, "cfg5": 16 * (960 * 1280 * 4 + 2048 * 2048 * 5)}
@@ -75,7 +77,7 @@ def main():
                     "dispatches": fetch[k]["FETCH_SIZE"][1]}
       if k in dur:
         kernels[k]["avg_us"] = dur[k][1] / 1e3
-  seq_names = [k for k in kernels if any(k.startswith(s) for s in SEQUENCE[w])]
+  seq_names = [k for k in kernels if k in SEQUENCE[w]]
   # per launch sequence: a kernel that runs n times per call (channel groups) counts n times
   calls = min((kernels[k]["dispatches"] for k in seq_names), default=1)
   seq = sum((kernels[k]["read"] + kernels[k]["written"]) * kernels[k]["dispatches"] / calls for k in seq_names)

@@ -148,6 +148,57 @@ def test_strip_path_equals_oracle_and_other_paths(dmap, oracle, seed):
   _LISTED.append(listed)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_compact_planes_equal_slabs_and_lists_and_the_oracle(dmap, oracle, seed):
+  """Round 5: the groups several strips share go through compact planes (frame-wide numbering from the covers,
+  k_strip_combine_planes) for calls of at most four strips and two output channels.  The same calls with the
+  planes switched off (slabs + lists + k_strip_combine_one, rounds 2-4) and the oracle must agree bit for
+  bit: height maps, one- and two-channel value maps, valid maps, min, 1-4 strips; the launch counters say
+  which combine kernel ran."""
+  lib = _lib()
+  rng = np.random.default_rng(5200 + seed)
+  ran = 0
+  for it in range(16):
+    B, H, W, depth, pose, cfg = _case(rng, big_offsets=(it % 5 == 4))
+    if W % 4:
+      continue
+    value = valid = None
+    if it % 3 == 1:
+      C = int(rng.integers(1, 3))
+      value = rng.uniform(-1, 2, size=(B, C, H, W)).astype(np.float32)
+      cfg["fill_value"] = 0.0 if it % 2 else -np.inf
+    if it % 4 == 2:
+      valid = rng.uniform(0, 1, size=(B, 1, H, W)) > 0.2
+    if it % 7 == 3:
+      cfg["reduction"] = "min"; cfg["fill_value"] = np.inf
+    kw = dict(project_kwargs(cfg, oracle.camera_intrinsics), cam_pose=pose)
+    want = oracle.orth_project(depth, value_map=value, valid_map=valid, get_height_map=True, **kw)
+    proj = _projector(dmap, cfg)
+    d = torch.from_numpy(depth).cuda()
+    v = None if value is None else torch.from_numpy(value).cuda()
+    m = None if valid is None else torch.from_numpy(valid).cuda()
+    strips = int(rng.integers(1, 5))
+    lib.dm_debug_force_strips(strips)
+    try:
+      outs = []
+      for planes in (1, 0):
+        lib.dm_debug_planes(planes)
+        outs.append(proj.orth_project(d, value_map=v, valid_map=m, cam_pose=pose, get_height_map=True))
+        path = lib.dm_debug_last_path()
+    finally:
+      lib.dm_debug_force_strips(0); lib.dm_debug_planes(-1)
+    torch.cuda.synchronize()
+    if path != 2:
+      continue
+    ran += 1
+    for a_, b_ in zip(outs[0], outs[1]):
+      assert torch.equal(a_, b_) or bool(((a_ == b_) | (a_.isnan() & b_.isnan())).all()), (cfg, strips)
+    np.testing.assert_array_equal(outs[0][1].cpu().numpy(), want[1], err_msg=str((cfg, strips)))
+    np.testing.assert_array_equal(outs[0][0].cpu().numpy(), want[0], err_msg=str((cfg, strips)))
+    np.testing.assert_array_equal(outs[0][2].cpu().numpy(), np.ascontiguousarray(want[2]))
+  assert ran >= 5
+
+
 def test_value_list_path_was_exercised(dmap):
   assert sum(_LISTED) >= 4, _LISTED
 

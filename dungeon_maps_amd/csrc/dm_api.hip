@@ -473,6 +473,30 @@ int dm_crop_nearest_f32(const float* image_dev, const uint8_t* mask_dev, const f
   return DM_OK;
 }
 
+int dm_crop_sample_f32(const float* image_dev, const uint8_t* mask_dev, const float* center_dev,
+                       int64_t B, int64_t C, int64_t h, int64_t w, int64_t crop_h, int64_t crop_w,
+                       float fill, int has_fill, int mode, float* out_dev, uint8_t* out_mask_dev,
+                       void* stream) {
+  if (mode == DM_SAMPLE_NEAREST)
+    return dm_crop_nearest_f32(image_dev, mask_dev, center_dev, B, C, h, w, crop_h, crop_w, fill, has_fill, out_dev,
+                               out_mask_dev, stream);
+  if (mode != DM_SAMPLE_BILINEAR && mode != DM_SAMPLE_BICUBIC)
+    return fail(DM_ERR_INVALID_ARGUMENT, "sampling mode %d", mode);
+  if (B < 0 || C < 0 || B > 65535 || C > 65535 || h < 1 || w < 1 || crop_h < 0 || crop_w < 0 ||
+      h > (1 << 23) - 4 || w > (1 << 23) - 4 || crop_h * crop_w >= (1ll << 31) || h * w >= (1ll << 31))
+    return fail(DM_ERR_INVALID_ARGUMENT, "bad shape B=%lld C=%lld %lldx%lld -> %lldx%lld",
+                (long long)B, (long long)C, (long long)h, (long long)w, (long long)crop_h,
+                (long long)crop_w);
+  if (B == 0 || C == 0 || crop_h == 0 || crop_w == 0) return DM_OK;
+  if (!image_dev || !center_dev || !out_dev || (mask_dev != nullptr) != (out_mask_dev != nullptr))
+    return fail(DM_ERR_INVALID_ARGUMENT, "image/center/out must not be NULL; mask and out_mask go together");
+  hipError_t e = dm::run_crop_interp(image_dev, mask_dev, center_dev, (int)B, (int)C, (int)h, (int)w, (int)crop_h,
+                                     (int)crop_w, fill, has_fill, mode, out_dev, out_mask_dev,
+                                     static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return DM_OK;
+}
+
 int dm_affine_points_f32(const float* pts_dev, const float* R_dev, const float* t_dev, int64_t B,
                          size_t n, int translate_first, float* out_dev, void* stream) {
   if (B < 0 || B > 65535) return fail(DM_ERR_INVALID_ARGUMENT, "bad batch %lld", (long long)B);

@@ -70,6 +70,9 @@ hipError_t run_map_quantize(const float* x, const float* z, const float* woff, c
                             long long* xb, long long* zb, hipStream_t s);
 hipError_t run_camera_affine_grid(const dm_params& p, const dm_frame* frames_host,
                                   const float* depth, float* grid, void* ws, hipStream_t s);
+hipError_t run_crop_interp(const float* src, const uint8_t* src_mask, const float* center, int B, int C, int h, int w,
+                           int ch, int cw, float fill, int has_fill, int mode, float* dst, uint8_t* dst_mask,
+                           hipStream_t s);
 hipError_t run_crop_nearest(const float* src, const uint8_t* src_mask, const float* center, int B,
                             int C, int h, int w, int ch, int cw, float fill, int has_fill,
                             float* dst, uint8_t* dst_mask, hipStream_t s);

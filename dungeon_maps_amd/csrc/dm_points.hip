@@ -492,6 +492,98 @@ k_crop_nearest4(const float* __restrict__ src, const uint8_t* __restrict__ src_m
   }
 }
 
+// crop_topdown_map with the interpolating modes: generate_crop_grid + image_sample(mode='bilinear' | 'bicubic')
+// (utils.py:571-652) as torch's grid_sample evaluates them on the image padded by one pixel per side
+// (align_corners=True; padding 'border' with the pad = fill, or 'zeros' for fill None), one thread per cell:
+//   bilinear: coordinates clipped for 'border'; the four neighbours weighted (x_e - ix)(y_s - iy), ..., summed
+//             nw, ne, sw, se; neighbours outside the padded image contribute zero;
+//   bicubic:  un-clipped coordinates, t = ix - floor(ix), cubic-convolution coefficients (A = -0.75), every tap's
+//             coordinate clipped ('border') or bounds-checked ('zeros') on its own; rows first, then the column.
+// Float32, one rounding per operation (no contraction): equal to torch's CPU kernel within a few ulp (its vector
+// path sums in another order), the same NaN / inf where an empty (-inf) cell meets a zero weight.  A bool image
+// (the companion mask, fill False) is sampled as 0 / 1 and written back as "nonzero".
+template <int MODE, bool IS_MASK>      // MODE 1: bilinear, 2: bicubic
+__global__ void __launch_bounds__(256)
+k_crop_interp(const void* __restrict__ src_, const float* __restrict__ center, int C, int h, int w, int ch, int cw,
+              float fill, int has_fill, void* __restrict__ dst_) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ch * cw) return;
+  const int i = o / cw, j = o - i * cw;
+  const float pw = (float)(w + 2), ph = (float)(h + 2);
+  const float cxp = center[2 * b] + 1.0f, cyp = center[2 * b + 1] + 1.0f;
+  const float gx = (((float)j - (float)cw / 2.0f) + (cxp - pw / 2.0f)) / (pw / 2.0f);
+  const float gy = (((float)i - (float)ch / 2.0f) + (cyp - ph / 2.0f)) / (ph / 2.0f);
+  float ix = ((gx + 1.0f) / 2.0f) * (pw - 1.0f);
+  float iy = ((gy + 1.0f) / 2.0f) * (ph - 1.0f);
+  const size_t plane = ((size_t)b * C + c) * (size_t)h * w;
+  const float pad = has_fill ? fill : 0.0f;
+  // value of the padded image at integral float coordinates; outside the padded image: 0
+  auto tap = [&](float px, float py) -> float {
+    if (!(px >= 0.0f && px <= pw - 1.0f && py >= 0.0f && py <= ph - 1.0f)) return 0.0f;
+    if (px >= 1.0f && px <= (float)w && py >= 1.0f && py <= (float)h) {
+      const size_t at = plane + (size_t)((int)py - 1) * w + ((int)px - 1);
+      return IS_MASK ? (static_cast<const uint8_t*>(src_)[at] ? 1.0f : 0.0f) : static_cast<const float*>(src_)[at];
+    }
+    return pad;
+  };
+  auto clip = [&](float v, float hi) { return fminf(hi, fmaxf(v, 0.0f)); };
+  float out;
+  if (MODE == 1) {
+    if (has_fill) { ix = clip(ix, pw - 1.0f); iy = clip(iy, ph - 1.0f); }
+    const float x_w = floorf(ix), y_n = floorf(iy), x_e = x_w + 1.0f, y_s = y_n + 1.0f;
+    const float nw = (x_e - ix) * (y_s - iy), ne = (ix - x_w) * (y_s - iy);
+    const float sw = (x_e - ix) * (iy - y_n), se = (ix - x_w) * (iy - y_n);
+    out = tap(x_w, y_n) * nw;
+    out = out + tap(x_e, y_n) * ne;
+    out = out + tap(x_w, y_s) * sw;
+    out = out + tap(x_e, y_s) * se;
+  } else {
+    constexpr float A = -0.75f;
+    auto conv1 = [&](float x) { return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f; };
+    auto conv2 = [&](float x) { return ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A; };
+    const float x_nw = floorf(ix), y_nw = floorf(iy);
+    const float tx = ix - x_nw, ty = iy - y_nw, ux = 1.0f - tx, uy = 1.0f - ty;
+    const float kx[4] = {conv2(tx + 1.0f), conv1(tx), conv1(ux), conv2(ux + 1.0f)};
+    const float ky[4] = {conv2(ty + 1.0f), conv1(ty), conv1(uy), conv2(uy + 1.0f)};
+    out = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float py = y_nw - 1.0f + (float)r;
+      if (has_fill) py = clip(py, ph - 1.0f);
+      float row = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float px = x_nw - 1.0f + (float)q;
+        if (has_fill) px = clip(px, pw - 1.0f);
+        const float term = tap(px, py) * kx[q];
+        row = q == 0 ? term : row + term;
+      }
+      const float term = row * ky[r];
+      out = r == 0 ? term : out + term;
+    }
+  }
+  const size_t to = ((size_t)b * C + c) * (size_t)ch * cw + o;
+  if (IS_MASK) static_cast<uint8_t*>(dst_)[to] = out != 0.0f ? 1 : 0;
+  else static_cast<float*>(dst_)[to] = out;
+}
+
+hipError_t run_crop_interp(const float* src, const uint8_t* src_mask, const float* center, int B, int C, int h, int w,
+                           int ch, int cw, float fill, int has_fill, int mode, float* dst, uint8_t* dst_mask,
+                           hipStream_t s) {
+  const dim3 grid((unsigned)(((size_t)ch * cw + 255) / 256), C, B);
+  if (mode == 1) {
+    hipLaunchKernelGGL((k_crop_interp<1, false>), grid, dim3(256), 0, s, src, center, C, h, w, ch, cw, fill, has_fill, dst);
+    if (src_mask)      // (the mask: fill False, 'border')
+      hipLaunchKernelGGL((k_crop_interp<1, true>), grid, dim3(256), 0, s, src_mask, center, C, h, w, ch, cw, 0.0f, 1, dst_mask);
+  } else {
+    hipLaunchKernelGGL((k_crop_interp<2, false>), grid, dim3(256), 0, s, src, center, C, h, w, ch, cw, fill, has_fill, dst);
+    if (src_mask)
+      hipLaunchKernelGGL((k_crop_interp<2, true>), grid, dim3(256), 0, s, src_mask, center, C, h, w, ch, cw, 0.0f, 1, dst_mask);
+  }
+  return hipGetLastError();
+}
+
 hipError_t run_crop_nearest(const float* src, const uint8_t* src_mask, const float* center, int B,
                             int C, int h, int w, int ch, int cw, float fill, int has_fill,
                             float* dst, uint8_t* dst_mask, hipStream_t s) {

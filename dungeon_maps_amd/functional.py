@@ -594,6 +594,42 @@ def mask_from_map(topdown: torch.Tensor, fill_value: Optional[float]) -> torch.T
   return mask
 
 
+SAMPLE_MODES = {"nearest": 0, "bilinear": 1, "bicubic": 2}
+
+
+def crop_sample(image: torch.Tensor, center: torch.Tensor, crop_width: int, crop_height: int,
+                fill_value: Optional[float] = None, mask: Optional[torch.Tensor] = None, mode: str = "nearest"):
+  """generate_crop_grid + image_sample(mode=...) (reference utils.py:571-652) as one HIP kernel per image
+  (dm_crop_sample_f32): 'nearest' is crop_nearest; 'bilinear' / 'bicubic' follow torch's
+  grid_sample(align_corners=True) on the image padded by one pixel (float32, within a few ulp of torch's CPU
+  kernel; NaN / inf where an empty cell meets a zero weight, as there).  The optional bool ``mask`` is sampled
+  on the same coordinates with fill False and comes back as "nonzero".  Returns the crop (and the mask's)."""
+  if mode not in SAMPLE_MODES:
+    raise ValueError(f"mode must be one of {sorted(SAMPLE_MODES)}, not {mode!r}")
+  if mode == "nearest":
+    return crop_nearest(image, center, crop_width, crop_height, fill_value=fill_value, mask=mask)
+  if image.device.type != "cuda":
+    raise RuntimeError("crop_sample runs on the GPU")
+  img = image.to(torch.float32).contiguous()
+  b, c, h, w = img.shape
+  ctr = utils.to_tensor(center, device=img.device).to(torch.float32).reshape(-1, 2)
+  if ctr.shape[0] == 1 and b > 1:
+    ctr = ctr.expand(b, 2)
+  assert ctr.shape[0] == b, (ctr.shape, b)
+  ctr = ctr.contiguous()
+  out = torch.empty((b, c, crop_height, crop_width), dtype=torch.float32, device=img.device)
+  msk = out_mask = None
+  if mask is not None:
+    msk = mask.to(device=img.device, dtype=torch.bool).expand(img.shape).contiguous()
+    out_mask = torch.empty(out.shape, dtype=torch.bool, device=img.device)
+  with _on_device(img.device):
+    _native.check(_native.lib().dm_crop_sample_f32(
+        _ptr(img), _ptr(msk), _ptr(ctr), b, c, h, w, crop_height, crop_width,
+        0.0 if fill_value is None else float(fill_value), 0 if fill_value is None else 1, SAMPLE_MODES[mode],
+        _ptr(out), _ptr(out_mask), _stream_ptr(img.device)))
+  return (out, out_mask) if mask is not None else out
+
+
 def crop_nearest(image: torch.Tensor, center: torch.Tensor, crop_width: int, crop_height: int,
                  fill_value: Optional[float] = None,
                  mask: Optional[torch.Tensor] = None):

@@ -300,14 +300,15 @@ def crop_topdown_map(source: TopdownMap, center, crop_width: int, crop_height: i
   dev = source.height_map.device
   woff = utils.to_tensor(proj.width_offset, device=center.device)
   hoff = utils.to_tensor(proj.height_offset, device=center.device)
-  if dev.type == "cuda" and mode == "nearest":
-    # one fused HIP gather per image instead of pad + grid + grid_sample
-    height_map, mask = F.crop_nearest(source.height_map, center, crop_width, crop_height,
-                                      fill_value=NINF, mask=source.mask)
+  if dev.type == "cuda" and mode in F.SAMPLE_MODES:
+    # one fused HIP kernel per image instead of pad + grid + grid_sample (nearest: a gather; bilinear / bicubic:
+    # torch's grid_sample arithmetic, dm_crop_sample_f32)
+    height_map, mask = F.crop_sample(source.height_map, center, crop_width, crop_height,
+                                     fill_value=NINF, mask=source.mask, mode=mode)
     topdown = height_map
     if not source.is_height_map:
-      topdown = F.crop_nearest(source.topdown_map, center, crop_width, crop_height,
-                               fill_value=get(fill_value, proj.fill_value))
+      topdown = F.crop_sample(source.topdown_map, center, crop_width, crop_height,
+                              fill_value=get(fill_value, proj.fill_value), mode=mode)
   else:
     grid = utils.generate_crop_grid(center.to(dev), proj.map_width, proj.map_height,
                                     crop_width, crop_height)

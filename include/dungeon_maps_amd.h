@@ -277,6 +277,20 @@ int dm_crop_nearest_f32(const float* image_dev, const uint8_t* mask_dev, const f
                         void* stream);
 
 /*
+ * The same crop with any of image_sample's modes (utils.py:613-652, maps.py:1959-2037): `mode` nearest (the
+ * gather above), bilinear or bicubic as torch's grid_sample(align_corners=True) evaluates them on the image padded
+ * by one pixel per side ('border' with the pad = fill, 'zeros' for has_fill == 0) -- float32, one rounding per
+ * operation; within a few ulp of torch's CPU kernel (which sums in another order), the same NaN / inf where an
+ * empty (-inf) cell meets a zero weight.  The companion mask (fill False) is sampled as 0 / 1 and written as
+ * "nonzero", as the reference does.
+ */
+typedef enum dm_sample_mode { DM_SAMPLE_NEAREST = 0, DM_SAMPLE_BILINEAR = 1, DM_SAMPLE_BICUBIC = 2 } dm_sample_mode;
+int dm_crop_sample_f32(const float* image_dev, const uint8_t* mask_dev, const float* center_dev,
+                       int64_t B, int64_t C, int64_t h, int64_t w, int64_t crop_h, int64_t crop_w,
+                       float fill, int has_fill, int mode, float* out_dev, uint8_t* out_mask_dev,
+                       void* stream);
+
+/*
  * utils.rotate + utils.translate on materialised points (utils.py:229-330; used
  * by camera_to_local_space / local_to_global_space / global_to_local_space /
  * local_to_camera_space, maps.py:753-942).  pts_dev, out_dev (B, n, 3) f32;

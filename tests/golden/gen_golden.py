@@ -691,6 +691,42 @@ def g13(dmap):
   save("g13_point_clouds", **arrays)
 
 
+def g9c(dmap):
+  """crop_topdown_map with the interpolating modes (maps.py:1959-2037; utils.image_sample with
+  mode='bilinear' / 'bicubic', utils.py:613-652): a height map with empty (-inf) cells -- interpolation next
+  to them gives inf / NaN exactly where the reference's arithmetic does -- and an all-finite value map with
+  fill None ('zeros' padding) and a finite fill ('border'); fractional, integral and out-of-range centres."""
+  rng = np.random.default_rng(9393)
+  n_h, n_w = 40, 56
+  top = rng.uniform(-1.0, 3.0, (2, 1, n_h, n_w)).astype(np.float32)
+  mask = rng.uniform(size=(2, 1, n_h, n_w)) > 0.2
+  height = top.copy()
+  height[~mask] = -np.inf
+  value = rng.uniform(0.0, 2.0, (2, 3, n_h, n_w)).astype(np.float32)
+  cfg = dict(width=64, height=48, hfov=np.radians(70.), cam_pose=[0., 0., 0.], width_offset=28.,
+             height_offset=20., cam_pitch=np.radians(-20.), cam_height=0.88, map_res=0.05,
+             map_width=n_w, map_height=n_h, to_global=True, fill_value=-np.inf)
+  arrays = dict(height=height, mask=mask, value=value)
+  centers = np.array([[[27.25, 19.5], [10.0, 30.0]], [[55.75, -0.25], [-3.5, 41.0]], [[28.0, 20.0], [28.5, 20.5]]],
+                     dtype=np.float32)
+  arrays["centers"] = centers
+  for mode in ("bilinear", "bicubic"):
+    for ci, center in enumerate(centers):
+      tm = dmap.TopdownMap(topdown_map=T(height), mask=torch.from_numpy(mask), height_map=T(height),
+                           map_projector=dmap.MapProjector(**cfg))
+      crop = dmap.maps.crop_topdown_map(tm, T(center).clone(), 24, 20, mode=mode)
+      arrays[f"{mode}_h{ci}_map"] = crop.topdown_map.numpy().copy()
+      arrays[f"{mode}_h{ci}_mask"] = crop.mask.numpy().copy()
+      for tag, fill in (("none", None), ("half", 0.5)):
+        proj = dmap.MapProjector(**dict(cfg, fill_value=fill))
+        tv = dmap.TopdownMap(topdown_map=T(value), mask=torch.from_numpy(np.broadcast_to(mask, value.shape).copy()),
+                             height_map=T(np.broadcast_to(height, value.shape).copy()), map_projector=proj,
+                             is_height_map=False)
+        cv = dmap.maps.crop_topdown_map(tv, T(center).clone(), 24, 20, fill_value=fill, mode=mode)
+        arrays[f"{mode}_v{ci}_{tag}"] = cv.topdown_map.numpy().copy()
+  save("g9c_crop_interpolated", **pack_kwargs(cfg), **arrays)
+
+
 def main():
   torch.set_num_threads(1)
   torch.manual_seed(0)
@@ -714,6 +750,7 @@ def main():
   g11(dmap)
   g12(dmap)
   g13(dmap)
+  g9c(dmap)
 
 
 if __name__ == "__main__":

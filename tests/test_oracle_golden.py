@@ -320,3 +320,29 @@ def test_point_clouds_oracle_g13(oracle):
     ok = (g["depth"] <= np.float32(5.05)) & (g["depth"] >= np.float32(0.15)) & g["valid"]      # maps.py:537-544
   np.testing.assert_array_equal(ok, g["ok_flip"])
   assert g["ok_noflip"].all()
+
+
+def _close_with_same_specials(got, want, what):
+  """Interpolated values: float arithmetic whose order torch's vector kernel does not fix -- within north_star's
+  1e-5 (here: 2e-6 absolute on values of a few units), NaN / inf exactly where the reference has them."""
+  np.testing.assert_array_equal(np.isnan(got), np.isnan(want), err_msg=what)
+  np.testing.assert_array_equal(np.isposinf(got), np.isposinf(want), err_msg=what)
+  np.testing.assert_array_equal(np.isneginf(got), np.isneginf(want), err_msg=what)
+  fin = np.isfinite(want)
+  np.testing.assert_allclose(got[fin], want[fin], rtol=1e-5, atol=2e-6, err_msg=what)
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
+def test_crop_interpolated_oracle_g9c(oracle, mode):
+  """crop_topdown_map(mode='bilinear' | 'bicubic') (maps.py:1959-2037, utils.py:571-652) on fixture g9c: a
+  height map with empty (-inf) cells, its mask, and a value map with fill None / 0.5, at fractional, integral
+  and out-of-range centres -- values within tolerance, masks and NaN / inf patterns equal."""
+  g, _ = load_golden("g9c_crop_interpolated")
+  for ci in range(3):
+    c = g["centers"][ci]
+    _close_with_same_specials(oracle.crop_interpolated(g["height"], c, 24, 20, -np.inf, mode), g[f"{mode}_h{ci}_map"],
+                              f"{mode} height {ci}")
+    np.testing.assert_array_equal(oracle.crop_interpolated(g["mask"], c, 24, 20, False, mode), g[f"{mode}_h{ci}_mask"])
+    for tag, fill in (("none", None), ("half", 0.5)):
+      _close_with_same_specials(oracle.crop_interpolated(g["value"], c, 24, 20, fill, mode), g[f"{mode}_v{ci}_{tag}"],
+                                f"{mode} value {ci} {tag}")

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DUNGEON_MAPS_AMD_LIB") or os.path.join(
     HERE, "csrc", "libdungeon_maps_amd.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # dm_reduction
 REDUCE_MAX, REDUCE_MIN, REDUCE_SUM, REDUCE_MEAN, REDUCE_PROD = range(5)
@@ -125,6 +125,7 @@ _SIGNATURES = {
         ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dm_fuse_bbox_multi_f32": (ctypes.c_int, [
         ctypes.POINTER(FuseSrc), ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "dm_fuse_bbox_read_i32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dm_fuse_scatter_multi_f32": (ctypes.c_int, [
         ctypes.POINTER(FuseSrc), ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_int,
         ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -436,6 +436,26 @@ int dm_fuse_bbox_multi_f32(const dm_fuse_src* srcs, int32_t n, int32_t* stats_de
   return DM_OK;
 }
 
+int dm_fuse_bbox_read_i32(const int32_t* stats_dev, int32_t* stats_host, void* stream) {
+  if (!stats_dev || !stats_host) return fail(DM_ERR_INVALID_ARGUMENT, "stats must not be NULL");
+  // one pinned staging block per host thread and GPU (a copy into pageable memory goes through the runtime's own
+  // staging and costs about twice the time)
+  static thread_local int32_t* pinned[8] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= 8) return fail(DM_ERR_LAUNCH, "hipGetDevice failed");
+  if (!pinned[dev]) {
+    e = hipHostMalloc(reinterpret_cast<void**>(&pinned[dev]), 64, hipHostMallocDefault);
+    if (e != hipSuccess) { pinned[dev] = nullptr; return fail(DM_ERR_LAUNCH, "hipHostMalloc failed: %s", hipGetErrorString(e)); }
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  e = hipMemcpyAsync(pinned[dev], stats_dev, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return fail(DM_ERR_LAUNCH, "reading the bounding box failed: %s", hipGetErrorString(e));
+  memcpy(stats_host, pinned[dev], 5 * sizeof(int32_t));
+  return DM_OK;
+}
+
 int dm_fuse_scatter_multi_f32(const dm_fuse_src* srcs, int32_t n, float width_offset, float height_offset,
                               int flip_h, int64_t map_height, int64_t map_width, int reduction,
                               float* canvas_dev, float* height_canvas_dev, void* stream) {

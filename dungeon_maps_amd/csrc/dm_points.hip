@@ -705,6 +705,10 @@ k_fuse_scatter(dm_fuse_src s, float woff, float hoff, int flip, float mhm1, int 
   if (hcanvas) atomic_max_f(hcanvas + ((size_t)bi * s.c + ci) * M + cell, yy);
 }
 
+constexpr int kBboxThreads = 1024;            // k_fuse_bbox_multi
+constexpr int kBboxCellsPerThread = 8;        // ... cells per thread and pass (blocks per plane capped at kBboxMaxBlocks)
+constexpr size_t kBboxMaxBlocks = 64;
+
 // Several source maps in one launch (MapBuilder.merge fuses two maps per frame: the launches
 // were a third of its device time).  blockIdx.z = source * b + batch row.
 struct FuseSources {
@@ -715,7 +719,7 @@ struct FuseSources {
 // The bounding box as FIVE MAXIMA of unsigned words that start at zero (so a zero-filled stats
 // buffer needs no initialising launch): u = x ^ 0x80000000 orders like x;
 // stats = {max ~u(col), max u(col), max ~u(row), max u(row), any}.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kBboxThreads)
 k_fuse_bbox_multi(FuseSources a, unsigned* __restrict__ stats) {
   __shared__ unsigned sh[5];
   if (threadIdx.x < 5) sh[threadIdx.x] = 0u;
@@ -723,21 +727,52 @@ k_fuse_bbox_multi(FuseSources a, unsigned* __restrict__ stats) {
   const int si = blockIdx.z / a.s[0].b, bi = blockIdx.z - si * a.s[0].b, ci = blockIdx.y;
   const dm_fuse_src& s = a.s[si];
   const int n = s.h * s.w;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const size_t plane = (size_t)s.h * s.w;
-    if (s.mask_dev[((size_t)bi * s.mc + (s.mc == 1 ? 0 : ci)) * plane + i]) {
+  const size_t plane = (size_t)s.h * s.w;
+  const uint8_t* mask = s.mask_dev + ((size_t)bi * s.mc + (s.mc == 1 ? 0 : ci)) * plane;
+  const float* height = s.height_dev + ((size_t)bi * s.hc + (s.hc == 1 ? 0 : ci)) * plane;
+  // A block walks its share of the plane, kBboxCellsPerThread cells per thread and pass (their mask bytes
+  // requested together, then their heights: two round trips per pass, not two per cell), and joins the five words
+  // ONCE, wave by wave.  One block per 256 cells put 5 x 512 atomics on ONE cache line for two 256 x 256 maps:
+  // 15-18 us of every MapBuilder.merge, all of it that line's round trips (round 5).
+  unsigned m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
+  for (int base = blockIdx.x * kBboxThreads * kBboxCellsPerThread + threadIdx.x; base < n;
+       base += gridDim.x * kBboxThreads * kBboxCellsPerThread) {
+    bool ok[kBboxCellsPerThread];
+    float y[kBboxCellsPerThread];
+#pragma unroll
+    for (int u = 0; u < kBboxCellsPerThread; ++u) {
+      const int i = base + u * kBboxThreads;
+      ok[u] = i < n && mask[i] != 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kBboxCellsPerThread; ++u) {
+      const int i = base + u * kBboxThreads;
+      y[u] = ok[u] ? height[i] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < kBboxCellsPerThread; ++u) {
+      if (!ok[u]) continue;
+      const int i = base + u * kBboxThreads;
       const int row = i / s.w, col = i - row * s.w;
-      const float y = s.height_dev[((size_t)bi * s.hc + (s.hc == 1 ? 0 : ci)) * plane + i];
       float x, yy, z;
-      fuse_point(s, bi, row, col, y, x, yy, z);
+      fuse_point(s, bi, row, col, y[u], x, yy, z);
       // map_quantize with zero offsets, unflipped (maps.py:2146-2160)
       const unsigned c0 = (unsigned)sat_i32(__builtin_floorf((x / s.target_res + 0.0f) + 0.5f)) ^ 0x80000000u;
       const unsigned r0 = (unsigned)sat_i32(__builtin_floorf((z / s.target_res + 0.0f) + 0.5f)) ^ 0x80000000u;
-      atomicMax(&sh[0], ~c0); atomicMax(&sh[1], c0);
-      atomicMax(&sh[2], ~r0); atomicMax(&sh[3], r0);
-      sh[4] = 1u;
+      m0 = max(m0, ~c0); m1 = max(m1, c0);
+      m2 = max(m2, ~r0); m3 = max(m3, r0);
     }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    m0 = max(m0, (unsigned)__shfl_xor((int)m0, d)); m1 = max(m1, (unsigned)__shfl_xor((int)m1, d));
+    m2 = max(m2, (unsigned)__shfl_xor((int)m2, d)); m3 = max(m3, (unsigned)__shfl_xor((int)m3, d));
+  }
+  // (a wave that saw a valid cell has m0 | m1 != 0: c0 and ~c0 cannot both be zero)
+  if ((threadIdx.x & 63) == 0 && (m0 | m1)) {
+    atomicMax(&sh[0], m0); atomicMax(&sh[1], m1);
+    atomicMax(&sh[2], m2); atomicMax(&sh[3], m3);
+    sh[4] = 1u;
   }
   __syncthreads();
   if (threadIdx.x == 0 && sh[4]) {
@@ -790,8 +825,11 @@ hipError_t run_fuse_bbox_multi(const dm_fuse_src* srcs, int n, int* stats, hipSt
   FuseSources a;
   size_t cells;
   gather_sources(srcs, n, a, cells);
-  const dim3 g((unsigned)((cells + 255) / 256), srcs[0].c, srcs[0].b * n);
-  hipLaunchKernelGGL(k_fuse_bbox_multi, g, dim3(256), 0, st, a, reinterpret_cast<unsigned*>(stats));
+  size_t blocks = (cells + kBboxThreads * kBboxCellsPerThread - 1) / (kBboxThreads * kBboxCellsPerThread);
+  if (blocks > kBboxMaxBlocks) blocks = kBboxMaxBlocks;
+  if (blocks < 1) blocks = 1;
+  const dim3 g((unsigned)blocks, srcs[0].c, srcs[0].b * n);
+  hipLaunchKernelGGL(k_fuse_bbox_multi, g, dim3(kBboxThreads), 0, st, a, reinterpret_cast<unsigned*>(stats));
   return hipGetLastError();
 }
 

@@ -35,6 +35,16 @@ def _is_scalar(v) -> bool:
   return isinstance(v, (int, float, np.floating, np.integer))
 
 
+def _as_scalar(v):
+  """A one-element CPU tensor or array as a python float; anything else unchanged."""
+  if type(v) is torch.Tensor:
+    if v.numel() == 1 and v.device.type == "cpu" and v.dtype is torch.float32 and not v.requires_grad:
+      return v.item()
+  elif type(v) is np.ndarray and v.size == 1 and v.dtype == _F32:
+    return float(v.reshape(-1)[0])
+  return v
+
+
 def _column(value, batch: int, width: Optional[int] = None) -> np.ndarray:
   """float32 (batch,) or (batch, width) array from a scalar / list / array /
   tensor that has either 1 or ``batch`` rows."""
@@ -117,6 +127,10 @@ def build_frame_table(batch: int, cam_pose, cam_pitch, cam_height, width_offset,
   """(batch, 32) float32 CPU tensor laid out as ``dm_frame``:
   [0:9] Rp, [9] cam_height, [10:19] Ry, [19] tx, [20] tz, [21] woff, [22] hoff,
   [23:32] rotate(X, -pitch) when ``inverse_pitch`` (camera_affine_grid)."""
+  # (one-element tensors / arrays count as scalars: MapBuilder hands the offsets over as 0-d tensors,
+  # compute_center_offsets' return values -- float32 -> python float -> float32 is exact)
+  cam_pitch, cam_height = _as_scalar(cam_pitch), _as_scalar(cam_height)
+  width_offset, height_offset = _as_scalar(width_offset), _as_scalar(height_offset)
   scalar_rig = _is_scalar(cam_pitch) and _is_scalar(cam_height) and _is_scalar(width_offset) \
       and _is_scalar(height_offset)
   if scalar_rig and cam_pose is not None:
@@ -132,11 +146,14 @@ def build_frame_table(batch: int, cam_pose, cam_pitch, cam_height, width_offset,
       static = torch.from_numpy(_static_columns(batch, cam_pitch, cam_height, width_offset,
                                                 height_offset, inverse_pitch))
       entry = (static, static.data_ptr(), _native.lib().dm_frames_fill_f32)
-      if len(_static_tensors) < 256:
-        _static_tensors[key] = entry
+      if len(_static_tensors) >= 256:      # (offsets that change from call to call: start over, stay bounded)
+        _static_tensors.clear()
+      _static_tensors[key] = entry
     pose = cam_pose
-    if not (type(pose) is torch.Tensor and pose.dtype is torch.float32 and pose.shape == (batch, 3)
-            and pose.is_contiguous() and pose.device.type == "cpu" and not pose.requires_grad):
+    if type(pose) is np.ndarray and pose.dtype == _F32 and pose.size == 3 * batch and pose.flags.c_contiguous:
+      pose = torch.from_numpy(pose.reshape(batch, 3))        # (the demo's pose: a float32 (3,) array)
+    elif not (type(pose) is torch.Tensor and pose.dtype is torch.float32 and pose.shape == (batch, 3)
+              and pose.is_contiguous() and pose.device.type == "cpu" and not pose.requires_grad):
       pose = torch.from_numpy(np.ascontiguousarray(_column(cam_pose, batch, 3)))
     yaw = pose[:, 2]
     s, c = torch.sin(yaw), torch.cos(yaw)

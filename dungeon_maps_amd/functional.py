@@ -172,9 +172,23 @@ class _Call:
   def workspace(self) -> Tuple[Optional[torch.Tensor], int]:
     if self.ws_bytes == 0:
       return None, 0
-    return torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev), self.ws_bytes
+    if self.ws_bytes > _WS_KEEP_BYTES or torch.cuda.is_current_stream_capturing():    # (a graph keeps its own)
+      return torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev), self.ws_bytes
+    # Small workspaces (few frames: the host-bound calls) are kept per (GPU, stream) and handed to the next call
+    # on that stream: the kernels of two calls on one stream run in order, and the workspace holds nothing
+    # between calls.  (A stream's address can come back for a new stream after the old one is destroyed:
+    # also then all earlier work on it has finished.)
+    key = (self.dev.index, _stream_ptr(self.dev))
+    ws = _WS_KEPT.get(key)
+    if ws is None or ws.numel() < self.ws_bytes:
+      if len(_WS_KEPT) >= 32:
+        _WS_KEPT.clear()
+      ws = _WS_KEPT[key] = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
+    return ws, self.ws_bytes
 
 
+_WS_KEEP_BYTES = 16 << 20
+_WS_KEPT = {}        # (GPU index, stream) -> uint8 workspace of a small call, reused by the next one on that stream
 _PARAMS_CACHE = {}   # call signature -> (dm_params, workspace bytes); both immutable afterwards
 
 
@@ -893,7 +907,11 @@ def compute_center_offsets(cam_pose, width_offset, height_offset, map_res, map_w
                            _validate_args=True) -> Tuple[torch.Tensor, torch.Tensor]:
   """Offsets that put the global origin / the camera at the map centre
   (reference maps.py:1175-1248)."""
-  mode = CenterMode(center_mode)
+  mode = center_mode if type(center_mode) is CenterMode else CenterMode(center_mode)
+  if mode is CenterMode.none and device is None and (not torch.is_tensor(cam_pose) or cam_pose.device.type == "cpu") \
+      and isinstance(width_offset, (int, float)) and isinstance(height_offset, (int, float)):
+    # (the demo's call -- numbers in, nothing to centre: the two 0-d float32 tensors the general route returns)
+    return torch.tensor(width_offset, dtype=torch.float32), torch.tensor(height_offset, dtype=torch.float32)
   pose = utils.to_tensor(torch.zeros(3) if cam_pose is None else cam_pose,
                          device=device).to(torch.float32)
   woff = utils.to_tensor(0. if width_offset is None else width_offset,

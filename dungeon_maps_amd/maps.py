@@ -13,6 +13,7 @@ from typing import Any, Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
+from . import frames
 from . import functional as F
 from . import utils
 from .functional import *  # noqa: F401,F403  (module-level functional twins)
@@ -368,15 +369,33 @@ def _offset_rows(v) -> list:
   return np.asarray(v, dtype=np.float32).reshape(-1).tolist()
 
 
+def _yaw_rows(pose, b: int, inverse: bool) -> list:
+  """Per batch row the 12 floats [R | t] of local_to_global_space (rotate by yaw, then + (x, 0, z)) or, ``inverse``,
+  of global_to_local_space (- (x, 0, z), then rotate by -yaw): R = utils.rotation_matrix([0, 1, 0], +-yaw) in its
+  closed form (frames.py: [[d, 0, s], [0, 1, 0], [-s, 0, d]], the same float32 operations element by element;
+  tests/test_host_api.py compares the two)."""
+  rows = []
+  for x, z, yaw in _pose_rows(pose, b).tolist():
+    s, d = frames._terms(-yaw if inverse else yaw, 1)
+    s, d = float(s), float(d)
+    t = (-x, -0.0, -z) if inverse else (x, 0.0, z)
+    rows.append((d, 0.0, s, 0.0, 1.0, 0.0, 0.0 - s, 0.0, d) + t)
+  return rows
+
+
+def _on(t: torch.Tensor, dev, dtype) -> torch.Tensor:
+  return t if t.device == dev and t.dtype is dtype else t.to(dev, dtype)
+
+
 def _fuse_source(m: TopdownMap, proj: MapProjector, dev):
   """dm_fuse_src of one source map (reference maps.py:2039-2069, 2137-2144), or None if it
   cannot go through the native path."""
   from . import _native
   sp = m.proj
-  hm = _unbroadcast_channels(m.height_map.to(dev, torch.float32))
+  hm = _unbroadcast_channels(_on(m.height_map, dev, torch.float32))
   b, hc, h, w = hm.shape
-  mk = _unbroadcast_channels(m.mask.to(dev, torch.bool))
-  val = None if m.is_height_map else m.topdown_map.to(dev, torch.float32).contiguous()
+  mk = _unbroadcast_channels(_on(m.mask, dev, torch.bool))
+  val = None if m.is_height_map else _on(m.topdown_map, dev, torch.float32).contiguous()
   c = hc if val is None else val.shape[1]
   if b > _native.FUSE_MAX_BATCH or mk.shape[1] not in (1, c) or hc not in (1, c):
     return None
@@ -389,30 +408,30 @@ def _fuse_source(m: TopdownMap, proj: MapProjector, dev):
   src.flip_h = int(bool(sp.flip_h))
   src.res, src.target_res = float(sp.map_res), float(proj.map_res)
   woff, hoff = _offset_rows(sp.width_offset), _offset_rows(sp.height_offset)
-  for i in range(b):
-    src.woff[i] = woff[i if len(woff) > 1 else 0]
-    src.hoff[i] = hoff[i if len(hoff) > 1 else 0]
+  src.woff[0:b] = woff if len(woff) == b else woff[:1] * b
+  src.hoff[0:b] = hoff if len(hoff) == b else hoff[:1] * b
   src.has_l2g = int(sp.to_global is False)
   if src.has_l2g:       # local_to_global_space: rotate by yaw, then + (x, 0, z)
-    pose = _pose_rows(sp.cam_pose, b)
-    rot = utils.rotation_matrix(torch.tensor([[0., 1., 0.]]), pose[:, 2].contiguous()).reshape(-1, 9)
-    for i in range(b):
-      row = rot[i].tolist() + [float(pose[i, 0]), 0.0, float(pose[i, 1])]
-      for k in range(12):
-        src.l2g[i][k] = row[k]
+    for i, row in enumerate(_yaw_rows(sp.cam_pose, b, False)):
+      src.l2g[i][0:12] = row
   src.has_g2l = int(proj.to_global is False)
   if src.has_g2l:       # global_to_local_space: - (x, 0, z), then rotate by -yaw
-    pose = _pose_rows(proj.cam_pose, b)
-    rot = utils.rotation_matrix(torch.tensor([[0., 1., 0.]]), (-pose[:, 2]).contiguous()).reshape(-1, 9)
-    for i in range(b):
-      row = rot[i].tolist() + [float(-pose[i, 0]), -0.0, float(-pose[i, 1])]
-      for k in range(12):
-        src.g2l[i][k] = row[k]
+    for i, row in enumerate(_yaw_rows(proj.cam_pose, b, True)):
+      src.g2l[i][0:12] = row
   return src, (hm, mk, val)      # keep the tensors alive
 
 
 _STATS_SLOTS = 512
 _stats_local = threading.local()     # .rings: (device, stream) -> [zero-filled (slots, 8) int32 tensor, next slot]
+
+
+def _stats_host():
+  """(five int32 of this host thread, their address) for dm_fuse_bbox_read_i32."""
+  host = getattr(_stats_local, "host", None)
+  if host is None:
+    words = (ctypes.c_int32 * 5)()
+    host = _stats_local.host = (words, ctypes.addressof(words))
+  return host
 
 
 def _zeroed_stats(dev) -> torch.Tensor:
@@ -467,14 +486,16 @@ def _fuse_topdown_maps_native(maps, proj: MapProjector, fill_value, reduction):
     for arr in arrays:
       _native.check(lib.dm_fuse_bbox_multi_f32(arr, len(arr), stats.data_ptr(), stream))
     # the one host sync; five maxima of order-preserving unsigned words (dm_fuse_bbox_multi_f32)
-    u = stats.cpu().numpy().view(np.uint32)
+    host = _stats_host()
+    _native.check(lib.dm_fuse_bbox_read_i32(stats.data_ptr(), host[1], stream))
+    u = [v & 0xffffffff for v in host[0]]
     if not u[4]:
       last = maps[-1]
       return TopdownMap(topdown_map=last.topdown_map, mask=last.mask, height_map=last.height_map,
                         map_projector=proj)
-    min_x, max_x, min_z, max_z = (int(v) for v in (
-        (~u[0]) ^ np.uint32(0x80000000), u[1] ^ np.uint32(0x80000000),
-        (~u[2]) ^ np.uint32(0x80000000), u[3] ^ np.uint32(0x80000000)))
+    # (int32 -> ordered word: x ^ 0x80000000; the minima travel complemented)
+    min_x, max_x, min_z, max_z = ((~u[0] & 0xffffffff) ^ 0x80000000, u[1] ^ 0x80000000,
+                                  (~u[2] & 0xffffffff) ^ 0x80000000, u[3] ^ 0x80000000)
     min_x, max_x, min_z, max_z = (v - (1 << 32) if v >= (1 << 31) else v for v in (min_x, max_x, min_z, max_z))
     map_width = int(max_x - min_x) + 2
     map_height = int(max_z - min_z) + 2
@@ -493,8 +514,8 @@ def _fuse_topdown_maps_native(maps, proj: MapProjector, fill_value, reduction):
           stream))
     new_mask = F.mask_from_map(topdown, fill)
   height_map = topdown if is_height_map else heights
-  woff = torch.tensor([woff_v], dtype=torch.float32)
-  hoff = torch.tensor([hoff_v], dtype=torch.float32)
+  woff = torch.tensor((float(woff_v),), dtype=torch.float32)
+  hoff = torch.tensor((float(hoff_v),), dtype=torch.float32)
   new_proj = proj.clone(width_offset=woff, height_offset=hoff, map_width=map_width,
                         map_height=map_height)
   return TopdownMap(topdown_map=topdown, mask=new_mask, height_map=height_map,
@@ -639,6 +660,14 @@ class MapBuilder:
   def _compute_offsets(self, cam_pose, width_offset=None, height_offset=None, map_res=None,
                        map_width=None, map_height=None, to_global=None, center_mode=None,
                        **_unused):
+    if center_mode is CenterMode.none or center_mode is None:
+      # nothing to centre: the projector's own offsets or the given ones, as compute_center_offsets returns them
+      # for numbers (two 0-d float32 tensors) -- without the trip through the forwarding method
+      woff = self.proj.width_offset if width_offset is None else width_offset
+      hoff = self.proj.height_offset if height_offset is None else height_offset
+      if isinstance(woff, (int, float)) and isinstance(hoff, (int, float)) and self.proj.device is None \
+          and (not torch.is_tensor(cam_pose) or cam_pose.device.type == "cpu"):
+        return torch.tensor(woff, dtype=torch.float32), torch.tensor(hoff, dtype=torch.float32)
     return self.proj.compute_center_offsets(
         cam_pose=cam_pose, width_offset=width_offset, height_offset=height_offset,
         map_res=map_res, map_width=map_width, map_height=map_height, to_global=to_global,

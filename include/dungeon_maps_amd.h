@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 9
+#define DM_ABI_VERSION 10
 
 typedef enum dm_status {
   DM_OK = 0,
@@ -256,6 +256,10 @@ int dm_fuse_scatter_f32(const dm_fuse_src* src, float width_offset, float height
                         int flip_h, int64_t map_height, int64_t map_width, int reduction,
                         float* canvas_dev, float* height_canvas_dev, void* stream);
 int dm_fuse_bbox_multi_f32(const dm_fuse_src* srcs, int32_t n, int32_t* stats_dev, void* stream);
+/* The five words of a bounding box on the host: enqueues the copy on `stream` (through a pinned block the
+ * library keeps per host thread) and WAITS for the stream -- the one host synchronisation of fuse_topdown_maps
+ * (the reference has two .item() calls there, maps.py:2146-2179).  ABI v10. */
+int dm_fuse_bbox_read_i32(const int32_t* stats_dev, int32_t* stats_host, void* stream);
 int dm_fuse_scatter_multi_f32(const dm_fuse_src* srcs, int32_t n, float width_offset,
                               float height_offset, int flip_h, int64_t map_height,
                               int64_t map_width, int reduction, float* canvas_dev,

@@ -198,3 +198,61 @@ def test_point_cloud_helpers_against_the_reference():
     pc = F.height_map_to_point_cloud(torch.from_numpy(g["height"]), torch.from_numpy(g["woff"]),
                                      torch.from_numpy(g["hoff"]), 0.07, 20, flip_h=flip)
     np.testing.assert_array_equal(pc.numpy(), g[f"points_{tag}"])
+
+
+def test_frame_table_takes_one_element_tensors_and_a_flat_pose_array():
+  """MapBuilder hands the offsets over as 0-d tensors and the demo its pose as a float32 (3,) array
+  (demos/height_map/run.py:104): the same table as from numbers and a (1, 3) tensor."""
+  pose = torch.tensor([[0.1, -0.2, 0.3]])
+  want = frames.build_frame_table(1, pose, -0.349, 0.88, 128.0, 7.5)
+  got = frames.build_frame_table(1, pose, torch.tensor(-0.349), torch.tensor([0.88]), torch.tensor(128.0),
+                                 np.array([7.5], dtype=np.float32))
+  assert torch.equal(want, got)
+  got = frames.build_frame_table(1, np.array([0.1, -0.2, 0.3], dtype=np.float32), -0.349, 0.88, torch.tensor(128.0), 7.5)
+  assert torch.equal(want, got)
+  # offsets that change from call to call do not grow the cache without bound
+  for i in range(600):
+    frames.build_frame_table(1, pose, -0.349, 0.88, float(i), 0.0)
+  assert len(frames._static_tensors) <= 256
+  assert torch.equal(want, frames.build_frame_table(1, pose, -0.349, 0.88, 128.0, 7.5))
+
+
+def test_fuse_pose_rows_equal_the_rotation_matrix_route():
+  """maps._yaw_rows (closed form, what MapBuilder.merge sends to dm_fuse_*) == utils.rotation_matrix about Y
+  + the translation, bit for bit and sign for sign (reference maps.py:2039-2069, utils.py:303-327)."""
+  from dungeon_maps_amd import maps
+  rng = np.random.default_rng(3)
+  for trial in range(200):
+    b = int(rng.integers(1, 5))
+    pose = torch.from_numpy(rng.uniform(-4, 4, (b, 3)).astype(np.float32))
+    if trial % 7 == 0:
+      pose[:, 2] = torch.from_numpy(rng.uniform(-2e-3, 2e-3, b).astype(np.float32))
+    if trial % 11 == 0:
+      pose[0, 2] = 0.0
+    for inverse in (False, True):
+      ang = (-pose[:, 2]).contiguous() if inverse else pose[:, 2].contiguous()
+      rot = utils.rotation_matrix(torch.tensor([[0., 1., 0.]]), ang).reshape(-1, 9)
+      want = [rot[i].tolist() + ([float(-pose[i, 0]), -0.0, float(-pose[i, 1])] if inverse
+                                 else [float(pose[i, 0]), 0.0, float(pose[i, 1])]) for i in range(b)]
+      w, g = np.array(want, dtype=np.float32), np.array(maps._yaw_rows(pose, b, inverse), dtype=np.float32)
+      np.testing.assert_array_equal(w, g)
+      np.testing.assert_array_equal(np.signbit(w), np.signbit(g))
+
+
+def test_center_offsets_short_cut_equals_the_general_route():
+  from dungeon_maps_amd import functional as F
+  for woff, hoff in ((300., 0.), (128, 64), (0.5, -3.25)):
+    fast = F.compute_center_offsets(np.zeros(3, dtype=np.float32), woff, hoff, 0.03, 600, 600, False, "none")
+    slow = F.compute_center_offsets(torch.zeros(3), torch.tensor(float(woff)), torch.tensor(float(hoff)), 0.03, 600,
+                                    600, False, F.CenterMode.none)
+    for a, b in zip(fast, slow):
+      assert a.dtype == b.dtype == torch.float32 and a.shape == b.shape == () and torch.equal(a, b)
+  proj = dmap.MapProjector(width=32, height=24, hfov=1.2, width_offset=12.0, height_offset=3.0, map_res=0.1,
+                           map_width=64, map_height=64)
+  builder = dmap.MapBuilder(proj)
+  got = builder._compute_offsets(cam_pose=np.zeros(3, dtype=np.float32), center_mode=dmap.CenterMode.none)
+  want = proj.compute_center_offsets(cam_pose=np.zeros(3, dtype=np.float32), center_mode=dmap.CenterMode.none)
+  assert all(torch.equal(a, b) and a.dtype == b.dtype and a.shape == b.shape for a, b in zip(got, want))
+  got = builder._compute_offsets(cam_pose=np.zeros(3, dtype=np.float32), center_mode=dmap.CenterMode.camera)
+  want = proj.compute_center_offsets(cam_pose=np.zeros(3, dtype=np.float32), center_mode=dmap.CenterMode.camera)
+  assert all(torch.equal(a, b) for a, b in zip(got, want))

@@ -33,7 +33,13 @@ for w in cfg3 cfg4 cfg5; do cp $(find $O/stats_$w -name '*kernel_stats.csv' | he
   echo "# (the GB/s column divides 162.5 MB by the time whatever the variant moves: read only moves 78.6 MB, write only 83.9 MB)"
   cat $O/skeleton.log
 } > ${P}_traffic_skeleton.log
-{ grep -v amdgpu $O/small_frame.log; grep -v amdgpu $O/host_pieces.log; } > ${P}_small_frame.log
+{ grep -v amdgpu $O/small_frame.log; grep -v amdgpu $O/host_pieces.log
+  echo; echo "# tools/demo_loop_time.py: the reference demo's loop (800x600 frames, local 600x600 maps at 1.5 cm, step + merge) and cfg1's pieces"
+  grep -v amdgpu $O/demo_loop.log
+  echo; echo "# tools/small_frame_graph.py: DEVICE time of one cfg1 projection (HIP graph replays) by forced strips / planes"
+  grep -v amdgpu $O/small_graph.log
+  echo; echo "# tools/merge_profile.py: MapBuilder.merge at cfg1, piece by piece"
+  grep -v amdgpu $O/merge_profile.log | head -14; } > ${P}_small_frame.log
 echo "profiles/r05_* regenerated from $O (library $md5)"
 {
   echo "# tools/model.hip on the same box: the traffic + issue model of the cfg2 launch (calibration, hand-off protocols, anti-phase workgroups) and the chip's rate for cfg2's read / write mix with no structure at all (mix)"

@@ -31,3 +31,6 @@ tools/tmp/model all > $O/model.log 2>&1; echo "model rc=$?"
 python tools/cfg4_time.py > $O/cfg4_time.log 2>&1; echo "cfg4 time rc=$?"
 python tools/small_frame_time.py > $O/small_frame.log 2>&1; echo "small rc=$?"
 python tools/host_pieces.py > $O/host_pieces.log 2>&1; echo "host rc=$?"
+python tools/demo_loop_time.py > $O/demo_loop.log 2>&1; echo "demo rc=$?"
+python tools/small_frame_graph.py > $O/small_graph.log 2>&1; echo "graph rc=$?"
+python tools/merge_profile.py > $O/merge_profile.log 2>&1; echo "merge rc=$?"

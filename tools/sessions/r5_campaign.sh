@@ -20,3 +20,4 @@ run 800 DM_CAMPAIGN_ODD=1
 run 800 DM_CAMPAIGN_OFFSETS=1 DM_CAMPAIGN_ONE_PITCH=1 DM_CAMPAIGN_CALLS=1
 run 800 DM_CAMPAIGN_DC=1 DM_CAMPAIGN_CALLS=1
 echo -n "crop campaign " >> $L; timeout -k 10 170 python tests/campaigns/crop_campaign.py $SEED0 1500 2>&1 | grep -E "MISMATCH|done:|Error|error" >> $L || echo "(stopped by its time limit or failed)" >> $L; tail -1 $L
+echo -n "fuse campaign " >> $L; timeout -k 10 170 python tests/campaigns/fuse_campaign.py $SEED0 ${FUSE_N:-600} 2>&1 | grep -E "MISMATCH|EXCEPTION|done:|Error|error" >> $L || echo "(stopped by its time limit or failed)" >> $L; tail -1 $L

@@ -218,11 +218,17 @@ def main():
   # once per RING steps ONE RCCL all-reduce(max) fuses the whole ring (fewer, larger
   # collectives: xGMI rings are latency bound at 1 MiB) on RCCL's own stream while the
   # next steps project; the masks of the reduced maps are recomputed afterwards.
-  RING_MAX = max(1, int(os.environ.get("DM_BENCH_RING", "32")))
-  ring = ring_mask = None
+  # Ring size: half of the timed steps, at most 32 -- the LAST collective of a run has nothing to hide under, so a
+  # ring as long as the run (32 slots for the harness's 20 steps) would leave all of the run's maps to one exposed
+  # all-reduce behind the last step; many short rings cost the host an enqueue + wait + mask launch each (one rank
+  # over RCCL on one GPU, 20 steps: rings of 7 / 10 / 20 / 32 within the noise of each other, 59-68 us per step).
+  RING_MAX = max(1, int(os.environ.get("DM_BENCH_RING", str(min(32, max(1, args.steps // 2))))))
+  ring = ring_mask = ring_slots = None
   if dist is not None:
     ring = [torch.empty((RING_MAX, C_out, mh, mw), dtype=torch.float32, device=dev) for _ in range(2)]
     ring_mask = [torch.empty((RING_MAX, C_out, mh, mw), dtype=torch.bool, device=dev) for _ in range(2)]
+    # (the slots as views made once: two indexing calls per step are 6 us of host time)
+    ring_slots = [[(ring[b][k], ring_mask[b][k]) for k in range(RING_MAX)] for b in range(2)]
   state = {"slot": 0, "buf": 0, "pending": None, "ring": RING_MAX}
 
   def finish_reduce():
@@ -246,7 +252,7 @@ def main():
   def next_slot():
     buf, slot = state["buf"], state["slot"]
     state["slot"] = slot + 1
-    return ring[buf][slot], ring_mask[buf][slot]
+    return ring_slots[buf][slot]
 
   def step(i=None):
     if i is not None and i not in bracketed_steps:

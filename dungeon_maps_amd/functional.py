@@ -30,6 +30,7 @@ __all__ = [
 ]
 
 import enum
+import threading
 
 
 class CenterMode(str, enum.Enum):
@@ -174,21 +175,25 @@ class _Call:
       return None, 0
     if self.ws_bytes > _WS_KEEP_BYTES or torch.cuda.is_current_stream_capturing():    # (a graph keeps its own)
       return torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev), self.ws_bytes
-    # Small workspaces (few frames: the host-bound calls) are kept per (GPU, stream) and handed to the next call
-    # on that stream: the kernels of two calls on one stream run in order, and the workspace holds nothing
-    # between calls.  (A stream's address can come back for a new stream after the old one is destroyed:
-    # also then all earlier work on it has finished.)
+    # Small workspaces (few frames: the host-bound calls) are kept per (host thread, GPU, stream) and handed to
+    # that thread's next call on that stream: the kernels of two calls one thread makes on one stream run in
+    # order, and the workspace holds nothing between calls.  (Per thread: two threads on ONE stream enqueue their
+    # launch sequences interleaved.  A stream's address can come back for a new stream after the old one is
+    # destroyed: also then all earlier work on it has finished.)
+    kept = getattr(_WS_LOCAL, "kept", None)
+    if kept is None:
+      kept = _WS_LOCAL.kept = {}
     key = (self.dev.index, _stream_ptr(self.dev))
-    ws = _WS_KEPT.get(key)
+    ws = kept.get(key)
     if ws is None or ws.numel() < self.ws_bytes:
-      if len(_WS_KEPT) >= 32:
-        _WS_KEPT.clear()
-      ws = _WS_KEPT[key] = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
+      if len(kept) >= 16:
+        kept.clear()
+      ws = kept[key] = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
     return ws, self.ws_bytes
 
 
 _WS_KEEP_BYTES = 16 << 20
-_WS_KEPT = {}        # (GPU index, stream) -> uint8 workspace of a small call, reused by the next one on that stream
+_WS_LOCAL = threading.local()     # .kept: (GPU index, stream) -> uint8 workspace of this thread's small calls
 _PARAMS_CACHE = {}   # call signature -> (dm_params, workspace bytes); both immutable afterwards
 
 

@@ -616,6 +616,56 @@ def test_two_threads_two_streams(dmap):
   assert not errors, errors
 
 
+def test_two_threads_one_stream(dmap):
+  """Two host threads that project on the SAME stream enqueue their launch sequences interleaved (the native
+  call runs without the GIL): each call needs a workspace of its own -- the small workspaces the host side keeps
+  are kept per thread."""
+  import threading
+  from dungeon_maps_amd import _native
+  lib = _native.lib()
+  B, H, W, mh, mw = 2, 96, 128, 128, 128
+  depth, _ = _synthetic(B, H, W, seed=12)
+  depth_d = torch.from_numpy(depth).cuda()
+  proj = dmap.MapProjector(width=W, height=H, hfov=np.radians(70.), cam_pitch=np.radians(-20.),
+                           cam_height=0.88, width_offset=mw / 2., height_offset=mh / 2., map_res=0.03,
+                           map_width=mw, map_height=mh, trunc_depth_min=0.15, trunc_depth_max=5.05,
+                           to_global=True, fill_value=-np.inf)
+  g = torch.Generator().manual_seed(4)
+  poses, refs = [], []
+  lib.dm_debug_force_generic_path(1)
+  try:
+    for _ in range(3):
+      pose = torch.empty(B, 3).uniform_(-1, 1, generator=g)
+      pose[:, 2] = torch.empty(B).uniform_(-np.pi, np.pi, generator=g)
+      poses.append(pose)
+      refs.append(proj.orth_project(depth_d, cam_pose=pose))
+  finally:
+    lib.dm_debug_force_generic_path(0)
+  torch.cuda.synchronize()
+  stream = torch.cuda.Stream()
+  errors = []
+
+  def worker(k):
+    try:
+      bad = torch.zeros((), dtype=torch.int64, device="cuda")
+      with torch.cuda.stream(stream):
+        for _ in range(300):
+          top, mask = proj.orth_project(depth_d, cam_pose=poses[k])
+          bad += (top != refs[k][0]).sum() + (mask != refs[k][1]).sum()
+      stream.synchronize()
+      if int(bad.item()) != 0:
+        errors.append(f"thread {k}: {int(bad.item())} cells differ")
+    except Exception as exc:      # noqa: BLE001 - reported by the main thread
+      errors.append(f"thread {k}: {exc!r}")
+
+  threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join()
+  assert not errors, errors
+
+
 @pytest.mark.parametrize("red,fill", [("sum", 0.0), ("mean", 2.0), ("prod", 1.0), ("min", np.inf),
                                       ("max", 0.25)])
 def test_generic_path_on_large_sparse_maps(dmap, oracle, red, fill):

@@ -155,11 +155,19 @@ def build_frame_table(batch: int, cam_pose, cam_pitch, cam_height, width_offset,
     elif not (type(pose) is torch.Tensor and pose.dtype is torch.float32 and pose.shape == (batch, 3)
               and pose.is_contiguous() and pose.device.type == "cpu" and not pose.requires_grad):
       pose = torch.from_numpy(np.ascontiguousarray(_column(cam_pose, batch, 3)))
-    yaw = pose[:, 2]
-    s, c = torch.sin(yaw), torch.cos(yaw)
+    if batch == 1:
+      # one frame: sin / cos of the whole (1, 3) record, the yaw's at float offset 2 -- no slicing call.  (Three
+      # elements or one: torch's CPU kernel takes them through the same tail of its loop, so the yaw's sine is the
+      # value sin(pose[:, 2]) gives; tests/test_host_api.py compares the two routes.)
+      s, c = torch.sin(pose), torch.cos(pose)
+      sp, cp = s.data_ptr() + 8, c.data_ptr() + 8
+    else:
+      yaw = pose[:, 2]
+      s, c = torch.sin(yaw), torch.cos(yaw)
+      sp, cp = s.data_ptr(), c.data_ptr()
     # (a fresh table per call: the library reads it inside the call, but a prepared batch keeps it)
     table = torch.empty((batch, FRAME_FLOATS), dtype=torch.float32)
-    if entry[2](entry[1], batch, pose.data_ptr(), s.data_ptr(), c.data_ptr(), table.data_ptr()) != 0:
+    if entry[2](entry[1], batch, pose.data_ptr(), sp, cp, table.data_ptr()) != 0:
       raise ValueError("dm_frames_fill_f32 refused its arguments")
     return table
   if scalar_rig:

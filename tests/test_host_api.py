@@ -256,3 +256,15 @@ def test_center_offsets_short_cut_equals_the_general_route():
   got = builder._compute_offsets(cam_pose=np.zeros(3, dtype=np.float32), center_mode=dmap.CenterMode.camera)
   want = proj.compute_center_offsets(cam_pose=np.zeros(3, dtype=np.float32), center_mode=dmap.CenterMode.camera)
   assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+def test_single_frame_table_equals_the_sliced_route():
+  """B = 1 takes sin / cos of the whole pose record (no slicing call): the same table as the general route, which
+  a two-frame batch with the frame repeated goes through, for 2 000 random yaws and the clamp's neighbourhood."""
+  rng = np.random.default_rng(5)
+  yaws = np.concatenate([rng.uniform(-7, 7, 2000), [0.0, 1e-3, -1e-3, 1.0000001e-3, 5e-4, np.pi, -np.pi / 2]]).astype(np.float32)
+  for yaw in yaws:
+    pose = torch.tensor([[0.25, -1.5, float(yaw)]])
+    one = frames.build_frame_table(1, pose, -0.349, 0.88, 128.0, 64.0)
+    two = frames.build_frame_table(2, pose.repeat(2, 1), -0.349, 0.88, 128.0, 64.0)
+    assert torch.equal(one[0], two[0]) and torch.equal(one[0], two[1]), float(yaw)
